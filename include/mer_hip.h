@@ -1,0 +1,281 @@
+/*
+ * mer_hip.h — C ABI of libmer_hip.so, the MI355X (gfx950 / CDNA4) implementation of the MERTools
+ * feature-extraction + fusion hot path.
+ *
+ * The reference (zeroQiaoba/MERTools) is pure Python and has no FFI of its own: its "operator
+ * API" for this path is the call signature of a HuggingFace model object at four call sites
+ * (SURVEY.md §8b).  Each encoder-level entry point below names the reference call it replaces;
+ * the op-level entry points are the building blocks those are made of and exist so every kernel
+ * can be parity-tested on its own through the same ABI.
+ *
+ * Conventions
+ *   - every pointer named d_* or documented "device" is a HIP device pointer; the library never
+ *     allocates, frees or copies caller memory.  Scratch comes from a caller-provided workspace.
+ *   - all shapes are explicit ints, row-major, strides in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream;
+ *   - return value: 0 = MER_OK, <0 = error (mer_last_error() gives a thread-local message);
+ *     no C++ exceptions cross this boundary;
+ *   - handles are immutable after create and may be used concurrently from several host threads
+ *     provided each call uses its own workspace and stream.
+ *   - "16-bit planes": an fp32 tensor x is carried as hi = rn16(x) and optionally
+ *     lo = rn16(x - hi) (MER_DT_F16 or MER_DT_BF16).  A GEMM with both operands in two planes
+ *     runs three MFMA passes (hi*hi + hi*lo + lo*hi) and is fp32-grade accurate; with one plane
+ *     it is a plain fp16/bf16 MFMA GEMM with fp32 accumulation.
+ */
+#ifndef MER_HIP_H
+#define MER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mer_stream_t; /* hipStream_t */
+
+enum { MER_OK = 0, MER_EINVAL = -1, MER_ESHAPE = -2, MER_ELAUNCH = -3, MER_ENOMEM = -4, MER_EUNSUPPORTED = -5 };
+enum { MER_DT_F16 = 0, MER_DT_BF16 = 1 };
+enum { MER_ACT_NONE = 0, MER_ACT_GELU = 1, MER_ACT_QUICK_GELU = 2, MER_ACT_RELU = 3 };
+
+const char* mer_version(void);
+const char* mer_last_error(void);
+/* Hardware the library was built for ("gfx950"). */
+const char* mer_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Op level                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* C = epilogue(A * W^T).  A: [M,K] 16-bit planes, W: [N,K] 16-bit planes (the torch Linear
+ * layout), fp32 accumulate.  epilogue: v = acc + bias[n]; v = act(v); v += residual[m,n];
+ * stores fp32 (c32) and/or 16-bit planes (c16_hi / c16_lo).
+ * Implicit-im2col row mapping for strided Conv1d over a channels-last tensor
+ * (HF:hubert/modeling_hubert.py:106-124 conv layers, :45-92 positional conv):
+ *   address(A row m) = a + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda
+ * (a_rows_per_batch <= 0 -> plain row-major).
+ * Batched form: z in [0,nbatch); zo = z / nb_inner, zi = z % nb_inner;
+ *   A += zo*a_so + zi*a_si; W += zi*w_si; bias += zi*bias_si;
+ *   {c32,c16,residual} += zo*c_so + zi*c_si.
+ * Requirements: K % 8 == 0, lda % 8 == 0, ldw % 8 == 0, all strides % 8 == 0 (16-byte loads).
+ */
+typedef struct {
+  int M, N, K;
+  int dtype;
+  const void* a_hi; const void* a_lo; long long lda;
+  int a_rows_per_batch; long long a_batch_stride;
+  const void* w_hi; const void* w_lo; long long ldw;
+  const float* bias;
+  int act;
+  const float* residual; long long ldr;
+  float* c32; long long ldc32;
+  void* c16_hi; void* c16_lo; long long ldc16;
+  int nbatch, nb_inner;
+  long long a_so, a_si, w_si, bias_si, c_so, c_si;
+  int passes;   /* 1 = hi*hi only; 3 = hi*hi + hi*lo + lo*hi (needs a_lo and w_lo) */
+  int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N) */
+} mer_gemm16_args;
+int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
+
+/* Exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain): C = act(A*W^T + bias).
+ * A [M,K] fp32 (lda), W [N,K] fp32 (ldw), C [M,N] fp32 (ldc).  Used by the fusion classifier
+ * (reference: MERBench/toolkit/models/modules/encoder.py:30-41) and as a tight-parity check.
+ * trans_a: A is given as [K,M] (A^T), trans_w: W is given as [K,N]; both needed by the backward
+ * pass.  accumulate != 0: C += result. */
+int mer_gemm32(const float* a, long long lda, int trans_a, const float* w, long long ldw, int trans_w,
+               const float* bias, int act, float* c, long long ldc, int accumulate,
+               int M, int N, int K, mer_stream_t stream);
+
+/* y = act(LayerNorm(x) * gamma + beta) over the last dim D (biased variance, two-pass fp32) —
+ * torch.nn.LayerNorm semantics.  x: fp32 rows with stride ldx.  Optional outputs: fp32 (out32,
+ * ld32) and 16-bit planes (out16_hi, out16_lo, ld16).  D % 4 == 0. */
+int mer_layernorm(const float* x, long long ldx, const float* gamma, const float* beta, float eps,
+                  int M, int D, int act, float* out32, long long ld32,
+                  void* out16_hi, void* out16_lo, long long ld16, int dtype, mer_stream_t stream);
+
+/* Multi-head self-attention, softmax(q k^T * scale) v, no causal mask; optional per-sequence key
+ * length (keys >= kv_len[b] are masked out; rows >= kv_len[b] produce unspecified output).
+ * q,k,v: 16-bit [B*T, ld] with head h at columns [h*64, h*64+64) of each pointer; head_dim = 64.
+ * out: 16-bit planes [B*T, ldo].  T <= 288 uses the single-pass kernel (K and V^T of one head
+ * resident in LDS); larger T uses the streaming (online-softmax) kernel.
+ * (HF:hubert/modeling_hubert.py:236-259 eager_attention_forward; same math in CLIP/RoBERTa.) */
+int mer_attention(const void* q, const void* k, const void* v, long long ld,
+                  void* out_hi, void* out_lo, long long ldo,
+                  int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
+
+/* fp32 -> 16-bit planes (lo may be NULL). n elements. */
+int mer_split16(const float* x, void* hi, void* lo, long long n, int dtype, mer_stream_t stream);
+
+/* HuBERT / wav2vec2 layer-0 feature extractor for feat_extract_norm == "group":
+ * Conv1d(1->C, k, stride, no bias) -> GroupNorm(C groups == per-channel over time, eps 1e-5,
+ * affine) -> GELU, written channels-last as 16-bit planes [B, T0, C].
+ * (HF:hubert/modeling_hubert.py:154-175.)  stats: device scratch of 2*B*C doubles. */
+int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* w /*[C,k]*/, int C, int k, int stride,
+                        const float* gamma, const float* beta, float eps, double* stats,
+                        void* out_hi, void* out_lo, int dtype, mer_stream_t stream);
+
+/* Channels-last hidden [B,T,D] fp32 -> zero-padded, group-major 16-bit planes [B, G, T+K, D/G]
+ * with x[b,t,g*Dg+c] at row t + K/2, so that the grouped positional Conv1d becomes one batched
+ * implicit-im2col GEMM (HF:hubert/modeling_hubert.py:45-92). */
+int mer_posconv_pack(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo,
+                     int dtype, mer_stream_t stream);
+
+/* ViT patchify: pixel_values fp32 [N,3,H,W] -> 16-bit planes [N*(H/P)*(W/P), 3*P*P] with the
+ * (c, i, j) ordering of a flattened Conv2d weight (HF:clip/modeling_clip.py:138-217). */
+int mer_vit_patchify(const float* pixels, int N, int C, int H, int W, int P, void* out_hi, void* out_lo,
+                     int dtype, mer_stream_t stream);
+
+/* ViT token assembly + optional LayerNorm: tok[n,0,:] = cls + pos[0]; tok[n,1+p,:] = patch[n,p,:]
+ * + pos[1+p]; y = LN(tok) if gamma != NULL else tok.  out32 [N*(1+P), D]; optional 16-bit. */
+int mer_vit_assemble(const float* patch, const float* cls, const float* pos, const float* gamma,
+                     const float* beta, float eps, int N, int P, int D, float* out32,
+                     void* out16_hi, void* out16_lo, int dtype, mer_stream_t stream);
+
+/* BERT/RoBERTa embeddings + LayerNorm: x = word[ids] + pos[position] + type[tt]; y = LN(x).
+ * ids: int64 [B,T]; token_type may be NULL (-> 0).  pos_mode 0: position = t (BERT);
+ * pos_mode 1: RoBERTa, position = pad_id + cumsum(ids != pad_id) for non-pad tokens, pad_id
+ * otherwise (HF:roberta/modeling_roberta.py:56-155). */
+int mer_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int T, int D,
+                   const float* word, const float* pos, const float* type, int pos_mode, int pad_id,
+                   const float* gamma, const float* beta, float eps, float* out32,
+                   void* out16_hi, void* out16_lo, int dtype, mer_stream_t stream);
+
+/* out_frames[r,:] = h0[r,:] (+ h1 + h2 + h3)   (sequential fp32 adds, the order of
+ * torch.stack(hs)[[-4,-3,-2,-1]].sum(0): extract_audio_huggingface.py:98);
+ * out_pool[i,:]  = mean over rows [seg_start[i], seg_start[i] + seg_len[i]) of that sum
+ *                  (extract_audio_huggingface.py:104-108 / extract_text_huggingface.py:243-249).
+ * h1..h3, out_frames, out_pool may be NULL.  seg_* are device int32 arrays of nseg entries. */
+int mer_sum_pool(const float* h0, const float* h1, const float* h2, const float* h3, long long M, int D,
+                 float* out_frames, const int* seg_start, const int* seg_len, int nseg, float* out_pool,
+                 mer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Encoder level                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { const void* hi; const void* lo; } mer_w16; /* 16-bit weight planes [N,K] */
+
+/* One transformer block (HuBERT / wav2vec2 / CLIP-ViT / VideoMAE / BERT / RoBERTa).
+ * wqkv = cat(q,k,v) rows [3D, D]; bqkv fp32 [3D] (zeros where the model has no bias). */
+typedef struct {
+  mer_w16 wqkv; const float* bqkv;
+  mer_w16 wo; const float* bo;
+  const float* ln1_g; const float* ln1_b;
+  mer_w16 w1; const float* b1;
+  mer_w16 w2; const float* b2;
+  const float* ln2_g; const float* ln2_b;
+} mer_tf_layer;
+
+typedef struct {
+  int hidden, heads, ffn, layers;
+  int pre_ln;     /* 0: post-LN blocks (HuBERT-base, BERT, RoBERTa); 1: pre-LN (CLIP, VideoMAE, HuBERT-large) */
+  int act;        /* MER_ACT_GELU | MER_ACT_QUICK_GELU */
+  float ln_eps;
+  int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
+  int passes;     /* GEMM passes inside the blocks: 1 or 3 */
+} mer_tf_config;
+
+/* ---- HuBERT / wav2vec2 audio encoder --------------------------------------------------------
+ * Replaces `model(input_values, output_hidden_states=True).hidden_states` at
+ * MERBench/feature_extraction/audio/extract_audio_huggingface.py:97 and the last-4 sum / mean
+ * of :98-108. */
+#define MER_MAX_CONV 8
+typedef struct {
+  mer_tf_config tf;
+  int n_conv; int conv_dim; int conv_kernel[MER_MAX_CONV]; int conv_stride[MER_MAX_CONV];
+  int feat_norm_group;      /* 1: GroupNorm on conv0 only ("group"); 0: LayerNorm after every conv ("layer") */
+  int conv_bias;
+  int feat_proj_layer_norm;
+  int pos_k, pos_groups;
+  int stable_layer_norm;    /* 1: HubertEncoderStableLayerNorm (large) */
+  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1 or 3 */
+} mer_hubert_config;
+
+typedef struct {
+  const float* conv0_w;                 /* [C, k0] fp32 */
+  const float* conv_norm_g[MER_MAX_CONV]; const float* conv_norm_b[MER_MAX_CONV];
+  mer_w16 conv_w[MER_MAX_CONV];         /* i>=1: [C, k_i*C] with column index kk*C + ci */
+  const float* conv_b[MER_MAX_CONV];
+  const float* fp_ln_g; const float* fp_ln_b;
+  mer_w16 fp_w; const float* fp_b;      /* [D, C] */
+  mer_w16 pos_w; const float* pos_b;    /* [G, D/G, pos_k * D/G] (weight-norm folded), column kk*Dg + ci */
+  const float* enc_ln_g; const float* enc_ln_b;
+  const mer_tf_layer* layers;           /* host array of tf.layers entries */
+} mer_hubert_weights;
+
+typedef struct mer_hubert mer_hubert;
+int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_weights* w, mer_hubert** out);
+void mer_hubert_destroy(mer_hubert* h);
+/* frames after the conv stack for L input samples (HF _get_feat_extract_output_lengths) */
+int mer_hubert_out_frames(const mer_hubert* h, int L);
+long long mer_hubert_workspace_bytes(const mer_hubert* h, int B, int L, int want_hidden_states);
+/* wav: device fp32 [B,L].  Outputs (each may be NULL):
+ *   hidden_states fp32 [layers+1, B, T, D]    (the HF tuple, stacked)
+ *   frames        fp32 [B*T, D]               sum of the last four hidden states
+ *   pooled        fp32 [nseg, D]              mean of `frames` rows over each segment; seg_start /
+ *                 seg_len are device int32 [nseg] in units of rows of the flattened [B*T] axis
+ *                 (one segment per clip; a >10 s clip split into chunks is one segment spanning
+ *                 its chunks, as in the reference). */
+int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, int L,
+                       void* workspace, long long workspace_bytes,
+                       float* hidden_states, float* frames,
+                       const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                       mer_stream_t stream);
+
+/* ---- CLIP vision tower ----------------------------------------------------------------------
+ * Replaces `model.get_image_features(pixel_values)` at
+ * MERBench/feature_extraction/visual/extract_vision_huggingface.py:118-122 and the frame mean of
+ * :183-189. */
+typedef struct {
+  mer_tf_config tf;
+  int image_size, patch_size, channels, proj_dim;
+} mer_vit_config;
+typedef struct {
+  mer_w16 patch_w;                      /* [D, C*P*P] (no bias) */
+  const float* cls; const float* pos;   /* [D], [1+P, D] */
+  const float* pre_ln_g; const float* pre_ln_b;
+  const float* post_ln_g; const float* post_ln_b;
+  mer_w16 proj_w;                       /* [proj_dim, D] (no bias) */
+  const mer_tf_layer* layers;
+} mer_vit_weights;
+typedef struct mer_vit mer_vit;
+int mer_vit_create(const mer_vit_config* cfg, const mer_vit_weights* w, mer_vit** out);
+void mer_vit_destroy(mer_vit* h);
+long long mer_vit_workspace_bytes(const mer_vit* h, int N);
+/* pixels: device fp32 [N,3,S,S].  image_features fp32 [N, proj_dim] (may be NULL);
+ * pooled fp32 [nseg, proj_dim] = mean of image_features rows per segment (may be NULL). */
+int mer_vit_forward(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
+                    float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                    mer_stream_t stream);
+
+/* ---- BERT / RoBERTa text encoder ------------------------------------------------------------
+ * Replaces `model(**inputs, output_hidden_states=True).hidden_states` at
+ * MERBench/feature_extraction/text/extract_text_huggingface.py:225 and the sum/slice/mean of
+ * :226-249. */
+typedef struct {
+  mer_tf_config tf;
+  int vocab, max_pos, type_vocab, pad_id, pos_mode;
+  float emb_ln_eps;
+} mer_bert_config;
+typedef struct {
+  const float* word; const float* pos; const float* type;
+  const float* emb_ln_g; const float* emb_ln_b;
+  const mer_tf_layer* layers;
+} mer_bert_weights;
+typedef struct mer_bert mer_bert;
+int mer_bert_create(const mer_bert_config* cfg, const mer_bert_weights* w, mer_bert** out);
+void mer_bert_destroy(mer_bert* h);
+long long mer_bert_workspace_bytes(const mer_bert* h, int B, int T, int want_hidden_states);
+/* ids: device int64 [B,T] (right-padded with pad_id); token_type may be NULL; lengths: device
+ * int32 [B] = number of real tokens per row (keys beyond it are masked; NULL = all T).
+ * Outputs as for mer_hubert_forward; seg_start/seg_len select e.g. rows [b*T+start, b*T+len+end)
+ * to drop the special tokens (extract_text_huggingface.py:228-231). */
+int mer_bert_forward(const mer_bert* h, const int64_t* ids, const int64_t* token_type, const int* lengths,
+                     int B, int T, void* workspace, long long workspace_bytes,
+                     float* hidden_states, float* frames,
+                     const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                     mer_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MER_HIP_H */

@@ -1,0 +1,191 @@
+// attention.hip — softmax(q k^T * scale) v for head_dim 64 on the 16x16x32 f16/bf16 MFMA.
+// (HF:hubert/modeling_hubert.py:236-259, HF:clip/modeling_clip.py:280-335,
+//  HF:roberta/modeling_roberta.py:186-250 — identical math, no causal mask on this path.)
+//
+// Single-pass kernel (T <= 512): one workgroup = (batch b, head h, 64 queries); the whole K
+// [T,64] and V^T [64,T] of that head live in LDS, every wave owns 16 queries.
+//   S^T = K Q^T   is computed "swapped" (A = K rows, B = Q^T) so that a lane holds, for ONE query
+//                 (lane & 15), the scores of keys {16*kt + 4*(lane>>4) + r}: the row max / sum are
+//                 in-lane reductions plus two cross-lane steps (xor 16, 32), no LDS round trip;
+//   O^T = V^T P^T the exponentiated scores of two neighbouring key tiles are already, lane for
+//                 lane, a valid MFMA B fragment when the 32-key k-slice is enumerated as
+//                 (tile 2c: keys 4g..4g+3 | tile 2c+1: keys 4g..4g+3); V^T is read from LDS with the
+//                 same enumeration (two ds_read_b64), so P never leaves registers.
+// K rows are padded to 144 B and V^T rows to (TP+4)*2 B, which makes both fragment reads
+// bank-conflict free.  Scores, softmax and the 1/sum normalisation are fp32.
+#include "common.h"
+
+namespace mer {
+
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                      const T* __restrict__ v, long long ld, T* oh, T* ol,
+                                                      long long ldo, int Tn, float scale_log2e, const int* kv_len) {
+  typedef typename T16<T>::v8 v8;
+  typedef typename T16<T>::v4 v4;
+  constexpr int TP = NKT * 16;
+  constexpr int KS = 72;       // K row stride in elements (144 B)
+  constexpr int VS = TP + 4;   // V^T row stride in elements
+  __shared__ __attribute__((aligned(16))) T Ks[TP * KS];
+  __shared__ __attribute__((aligned(16))) T Vt[64 * VS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+  int klen = Tn;
+  if (kv_len) {
+    klen = kv_len[b];
+    klen = klen < Tn ? klen : Tn;
+  }
+  const long long row0 = (long long)b * Tn;
+  const T* kb = k + row0 * ld + h * 64;
+  const T* vb = v + row0 * ld + h * 64;
+  const T* qb = q + row0 * ld + h * 64;
+
+  // ---- stage K (row-major, padded) and V^T into LDS; rows >= klen are zero ----
+  for (int c = tid; c < TP * 8; c += 256) {
+    const int row = c >> 3, ch = c & 7;
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (row < klen) {
+      kv = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
+      vv = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
+    }
+    *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kv;
+    const v8 vh = __builtin_bit_cast(v8, vv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
+  }
+
+  // ---- this lane's query fragment (B operand: n = query li, k = d) ----
+  const int qi = qt * 64 + wave * 16 + li;
+  const int qrow = qi < Tn ? qi : Tn - 1;
+  v8 qf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const v8*>(qb + (long long)qrow * ld + kk * 32 + lg * 8);
+
+  __syncthreads();
+
+  // ---- S^T tiles: s[kt][r] = score(key = 16*kt + 4*lg + r, query = li) ----
+  f32x4 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const v8 kf = *reinterpret_cast<const v8*>(Ks + (kt * 16 + li) * KS + kk * 32 + lg * 8);
+      a = T16<T>::mfma(kf, qf[kk], a);
+    }
+    s[kt] = a;
+  }
+
+  // ---- softmax over keys (fp32, base-2 exponent) ----
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + lg * 4 + r;
+      const float x = key < klen ? s[kt][r] * scale_log2e : -INFINITY;
+      s[kt][r] = x;
+      mx = fmaxf(mx, x);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (!(mx > -INFINITY)) mx = 0.f;  // klen == 0: all keys masked -> zeros out
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pexp = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+      s[kt][r] = pexp;
+      sum += pexp;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+  // ---- O^T = V^T P^T ----
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NKT / 2; ++c) {
+    v8 pf;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pf[j] = T16<T>::from_f32(s[2 * c][j]);
+      pf[4 + j] = T16<T>::from_f32(s[2 * c + 1][j]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const T* vr = Vt + (dt * 16 + li) * VS + lg * 4;
+      const v4 v0 = *reinterpret_cast<const v4*>(vr + (2 * c) * 16);
+      const v4 v1 = *reinterpret_cast<const v4*>(vr + (2 * c + 1) * 16);
+      v8 vf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vf[j] = v0[j];
+        vf[4 + j] = v1[j];
+      }
+      o[dt] = T16<T>::mfma(vf, pf, o[dt]);
+    }
+  }
+
+  // ---- store: lane holds O[query li][d = 16*dt + 4*lg + r] ----
+  if (qi < Tn) {
+    const long long orow = (row0 + qi) * ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      v4 hh, ll;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T a, c;
+        split16<T>(o[dt][r] * inv, a, c);
+        hh[r] = a;
+        ll[r] = c;
+      }
+      *reinterpret_cast<v4*>(oh + orow + dt * 16 + lg * 4) = hh;
+      if (ol) *reinterpret_cast<v4*>(ol + orow + dt * 16 + lg * 4) = ll;
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn(const void* q, const void* k, const void* v, long long ld, void* oh, void* ol, long long ldo,
+                       int B, int Tn, int H, float scale, const int* kv_len, hipStream_t st) {
+  const float sl2 = scale * 1.4426950408889634f;
+  dim3 grid((unsigned)cdiv(Tn, 64), H, B), block(256);
+#define MER_ATTN_CASE(N)                                                                                       \
+  hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
+                     (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len)
+  if (Tn <= 64) MER_ATTN_CASE(4);
+  else if (Tn <= 128) MER_ATTN_CASE(8);
+  else if (Tn <= 224) MER_ATTN_CASE(14);
+  else if (Tn <= 256) MER_ATTN_CASE(16);
+  else if (Tn <= 288) MER_ATTN_CASE(18);
+  else if (Tn <= 512) MER_ATTN_CASE(32);
+  else {
+    set_error("mer_attention: T=%d > 512 needs the streaming kernel (not built yet)", Tn);
+    return MER_EUNSUPPORTED;
+  }
+#undef MER_ATTN_CASE
+  return check_launch("attention");
+}
+
+}  // namespace mer
+
+extern "C" int mer_attention(const void* q, const void* k, const void* v, long long ld, void* out_hi, void* out_lo,
+                             long long ldo, int B, int T, int H, float scale, const int* kv_len, int dtype,
+                             mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(q && k && v && out_hi, MER_EINVAL, "mer_attention: null pointer");
+  MER_REQUIRE(B > 0 && T > 0 && H > 0, MER_ESHAPE, "mer_attention: bad shape B=%d T=%d H=%d", B, T, H);
+  MER_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, MER_ESHAPE, "mer_attention: ld %% 8 / ldo %% 4 alignment");
+  MER_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, MER_EINVAL, "mer_attention: q/k/v must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, st);
+  if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, st);
+  set_error("mer_attention: bad dtype %d", dtype);
+  return MER_EINVAL;
+}

@@ -1,0 +1,96 @@
+// Shared device/host helpers for the MI355X (gfx950) kernels of mertools_amd.
+// Everything here is written for wave64 / CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mer_hip.h"
+
+namespace mer {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// 16-bit element traits: conversion + the 16x16x32 MFMA for that type.
+template <typename T> struct T16;
+template <> struct T16<f16> {
+  typedef f16x8 v8; typedef f16x4 v4;
+  static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
+  static __device__ __forceinline__ float to_f32(f16 x) { return (float)x; }
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct T16<bf16> {
+  typedef bf16x8 v8; typedef bf16x4 v4;
+  static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
+  static __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// hi/lo split of an fp32 value into two 16-bit planes (hi = rn(x), lo = rn(x - hi)).
+template <typename T>
+__device__ __forceinline__ void split16(float x, T& hi, T& lo) {
+  hi = T16<T>::from_f32(x);
+  lo = T16<T>::from_f32(x - T16<T>::to_f32(hi));
+}
+
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 5 FMAs + rcp + exp. The libm erff
+// costs ~3x more VALU issue slots, which is visible next to the MFMA loop in GEMM epilogues.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case MER_ACT_GELU: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    case MER_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    case MER_ACT_RELU: return x > 0.f ? x : 0.f;
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- host-side error plumbing (thread-local message, int status across the C ABI) ----
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MER_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::mer::set_error(__VA_ARGS__);        \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+}  // namespace mer

@@ -1,0 +1,455 @@
+// encoders.cpp — host-side sequencing of the three encoder forwards on top of the op-level ABI.
+// No device code here: every step is one of the mer_* ops (HIP kernels) launched on the caller's
+// stream, with all scratch carved from the caller-provided workspace by a bump allocator.  The
+// same planning code runs in "dry" mode to answer mer_*_workspace_bytes().
+//
+// Reference call sites this replaces:
+//   audio : MERBench/feature_extraction/audio/extract_audio_huggingface.py:97-108
+//   visual: MERBench/feature_extraction/visual/extract_vision_huggingface.py:118-122,183-189
+//   text  : MERBench/feature_extraction/text/extract_text_huggingface.py:225-249
+#include "common.h"
+#include <vector>
+#include <string.h>
+#include <math.h>
+
+namespace mer {
+
+struct Arena {
+  char* base;
+  long long cap, off;
+  bool dry;
+  Arena(void* b, long long c, bool d) : base((char*)b), cap(c), off(0), dry(d) {}
+  void* take(long long bytes) {
+    off = (off + 255) & ~255LL;
+    void* p = dry ? nullptr : (void*)(base + off);
+    off += bytes;
+    return p;
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+struct P16 { void* hi; void* lo; };  // 16-bit activation planes
+
+static P16 take16(Arena& a, long long elems, bool need_lo) {
+  P16 p;
+  p.hi = a.take(elems * 2);
+  p.lo = need_lo ? a.take(elems * 2) : nullptr;
+  return p;
+}
+
+// hidden-state addressing: either the caller's [layers+1, M, D] tensor or a small ring.
+struct HsMap {
+  float* base;
+  long long stride;
+  int ring;  // 0 = no ring (full tensor)
+  float* at(int l) const { return base + (long long)(ring ? (l % ring) : l) * stride; }
+};
+
+static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 a, long long lda, const mer_w16& w,
+                const float* bias, int act, const float* residual, long long ldr, float* c32, long long ldc32, P16 c16,
+                long long ldc16) {
+  mer_gemm16_args g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.K = K; g.dtype = dtype;
+  g.a_hi = a.hi; g.a_lo = a.lo; g.lda = lda;
+  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = K;
+  g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
+  g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
+  g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
+  return mer_gemm16(&g, (mer_stream_t)st);
+}
+
+#define MER_TRY(expr)        \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc != MER_OK) return _rc; \
+  } while (0)
+
+struct TfBufs {
+  float* t32;
+  float* h1_32;
+  P16 cur16, qkv16, ctx16, h1_16, f16;
+};
+
+static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
+  const bool lo = c.passes == 3;
+  const long long D = c.hidden, F = c.ffn;
+  b.t32 = (float*)ar.take(M * D * 4);
+  b.h1_32 = c.pre_ln ? nullptr : (float*)ar.take(M * D * 4);
+  b.cur16 = take16(ar, M * D, lo);
+  b.qkv16 = take16(ar, M * 3 * D, false);
+  b.ctx16 = take16(ar, M * D, lo);
+  b.h1_16 = take16(ar, M * D, lo);
+  b.f16 = take16(ar, M * F, lo);
+}
+
+// Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
+// input; pre-LN: hs.at(0) holds the raw residual stream.  Writes hs.at(l+1) for every layer.
+static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer* L, int Bseq, int T, const HsMap& hs,
+                      TfBufs& b, const int* kv_len) {
+  const int M = Bseq * T, D = c.hidden, F = c.ffn, H = c.heads;
+  const int dt = c.dtype, ps = c.passes;
+  const float scale = 1.0f / sqrtf((float)(D / H));
+  const P16 none = {nullptr, nullptr};
+  for (int l = 0; l < c.layers; ++l) {
+    const mer_tf_layer& w = L[l];
+    float* x = hs.at(l);
+    float* y = hs.at(l + 1);
+    if (c.pre_ln)
+      MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.cur16.hi, b.cur16.lo, D, dt, st));
+    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
+    MER_TRY(mer_attention(b.qkv16.hi, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
+                          b.ctx16.hi, b.ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, st));
+    MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0));
+    if (c.pre_ln) {
+      MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.h1_16.hi, b.h1_16.lo, D, dt, st));
+      MER_TRY(gemm(st, dt, ps, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
+      MER_TRY(gemm(st, dt, ps, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0));
+    } else {
+      MER_TRY(mer_layernorm(b.t32, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.h1_32, D, b.h1_16.hi, b.h1_16.lo, D, dt, st));
+      MER_TRY(gemm(st, dt, ps, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
+      MER_TRY(gemm(st, dt, ps, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0));
+      MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, y, D, b.cur16.hi, b.cur16.lo, D, dt, st));
+    }
+  }
+  return MER_OK;
+}
+
+static int check_tf(const mer_tf_config& c, const char* who) {
+  MER_REQUIRE(c.hidden > 0 && c.heads > 0 && c.hidden % c.heads == 0, MER_EINVAL, "%s: bad hidden/heads", who);
+  MER_REQUIRE(c.hidden / c.heads == 64, MER_EUNSUPPORTED, "%s: head_dim %d != 64 unsupported", who, c.hidden / c.heads);
+  MER_REQUIRE(c.hidden % 8 == 0 && c.ffn % 8 == 0, MER_ESHAPE, "%s: hidden/ffn must be multiples of 8", who);
+  MER_REQUIRE(c.passes == 1 || c.passes == 3, MER_EINVAL, "%s: passes must be 1 or 3", who);
+  MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
+  MER_REQUIRE(c.dtype == MER_DT_F16 || c.dtype == MER_DT_BF16, MER_EINVAL, "%s: bad dtype", who);
+  return MER_OK;
+}
+
+static int last4_pool(hipStream_t st, const HsMap& hs, int layers, long long M, int D, float* frames, const int* seg_start,
+                      const int* seg_len, int nseg, float* pooled) {
+  if (!frames && !pooled) return MER_OK;
+  // hidden_states[-4..-1] (extract_audio_huggingface.py:93,98); fewer than 4 states -> as many as exist
+  const float* h[4] = {nullptr, nullptr, nullptr, nullptr};
+  int n = 0;
+  for (int l = layers - 3; l <= layers; ++l)
+    if (l >= 0) h[n++] = hs.at(l);
+  return mer_sum_pool(h[0], h[1], h[2], h[3], M, D, frames, seg_start, seg_len, nseg, pooled, st);
+}
+
+}  // namespace mer
+
+using namespace mer;
+
+// =============================================================================================
+// HuBERT / wav2vec2
+// =============================================================================================
+struct mer_hubert {
+  mer_hubert_config cfg;
+  mer_hubert_weights w;
+  std::vector<mer_tf_layer> layers;
+};
+
+extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_weights* w, mer_hubert** out) {
+  MER_REQUIRE(cfg && w && out, MER_EINVAL, "mer_hubert_create: null argument");
+  MER_TRY(check_tf(cfg->tf, "mer_hubert_create"));
+  MER_REQUIRE(cfg->n_conv >= 2 && cfg->n_conv <= MER_MAX_CONV, MER_EINVAL, "mer_hubert_create: n_conv=%d", cfg->n_conv);
+  MER_REQUIRE(cfg->conv_dim % 8 == 0, MER_ESHAPE, "mer_hubert_create: conv_dim %% 8 != 0");
+  MER_REQUIRE(cfg->feat_norm_group == 1, MER_EUNSUPPORTED,
+              "mer_hubert_create: feat_extract_norm='layer' (HuBERT-large front end) is not built yet");
+  MER_REQUIRE(cfg->conv_passes == 1 || cfg->conv_passes == 3, MER_EINVAL, "mer_hubert_create: conv_passes must be 1 or 3");
+  MER_REQUIRE(cfg->tf.hidden % cfg->pos_groups == 0 && (cfg->tf.hidden / cfg->pos_groups) % 8 == 0, MER_ESHAPE,
+              "mer_hubert_create: hidden/pos_groups must be a multiple of 8");
+  MER_REQUIRE(w->layers && w->conv0_w && w->fp_w.hi && w->pos_w.hi, MER_EINVAL, "mer_hubert_create: missing weights");
+  mer_hubert* h = new mer_hubert();
+  h->cfg = *cfg;
+  h->w = *w;
+  h->layers.assign(w->layers, w->layers + cfg->tf.layers);
+  h->w.layers = h->layers.data();
+  *out = h;
+  return MER_OK;
+}
+extern "C" void mer_hubert_destroy(mer_hubert* h) { delete h; }
+
+static void hubert_lengths(const mer_hubert_config& c, int L, int* T) {
+  int t = L;
+  for (int i = 0; i < c.n_conv; ++i) {
+    t = (t - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+    T[i] = t;
+  }
+}
+extern "C" int mer_hubert_out_frames(const mer_hubert* h, int L) {
+  if (!h) return MER_EINVAL;
+  int T[MER_MAX_CONV];
+  hubert_lengths(h->cfg, L, T);
+  return T[h->cfg.n_conv - 1];
+}
+
+struct HubertPlan {
+  double* stats;
+  P16 convA, convB;
+  float* conv_last32;
+  P16 fp16;
+  float* hproj;
+  P16 pospack;
+  float* ring;
+  TfBufs tf;
+  int T[MER_MAX_CONV];
+};
+
+static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool want_hs, HubertPlan& p) {
+  const mer_hubert_config& c = h->cfg;
+  hubert_lengths(c, L, p.T);
+  const long long C = c.conv_dim, D = c.tf.hidden;
+  const int Tn = p.T[c.n_conv - 1];
+  const long long M = (long long)B * Tn;
+  const bool clo = c.conv_passes == 3;
+  p.stats = (double*)ar.take((long long)B * C * 2 * 8);
+  p.convA = take16(ar, (long long)B * p.T[0] * C, clo);
+  p.convB = take16(ar, (long long)B * p.T[1] * C, clo);
+  p.conv_last32 = (float*)ar.take(M * C * 4);
+  p.fp16 = take16(ar, M * C, clo);
+  p.hproj = (float*)ar.take(M * D * 4);
+  p.pospack = take16(ar, (long long)B * (Tn + c.pos_k) * D, clo);
+  p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
+  tf_plan(ar, c.tf, M, p.tf);
+  return ar.off;
+}
+
+extern "C" long long mer_hubert_workspace_bytes(const mer_hubert* h, int B, int L, int want_hidden_states) {
+  if (!h || B <= 0 || L <= 0) return MER_EINVAL;
+  Arena ar(nullptr, 0, true);
+  HubertPlan p;
+  return hubert_plan(h, ar, B, L, want_hidden_states != 0, p) + 256;
+}
+
+extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, int L, void* workspace,
+                                  long long workspace_bytes, float* hidden_states, float* frames, const int* seg_start,
+                                  const int* seg_len, int nseg, float* pooled, mer_stream_t stream) {
+  MER_REQUIRE(h && wav && workspace, MER_EINVAL, "mer_hubert_forward: null argument");
+  MER_REQUIRE(B > 0 && L >= 400, MER_ESHAPE, "mer_hubert_forward: need B>0 and L>=400 samples (B=%d L=%d)", B, L);
+  MER_REQUIRE(((uintptr_t)workspace & 255) == 0, MER_EINVAL, "mer_hubert_forward: workspace must be 256-byte aligned");
+  const mer_hubert_config& c = h->cfg;
+  const mer_hubert_weights& w = h->w;
+  hipStream_t st = (hipStream_t)stream;
+  Arena ar(workspace, workspace_bytes, false);
+  HubertPlan p;
+  hubert_plan(h, ar, B, L, hidden_states != nullptr, p);
+  MER_REQUIRE(ar.ok(), MER_ENOMEM, "mer_hubert_forward: workspace too small (%lld < %lld bytes)", workspace_bytes, ar.off);
+  const int C = c.conv_dim, D = c.tf.hidden, dt = c.tf.dtype, cps = c.conv_passes;
+  const int Tn = p.T[c.n_conv - 1];
+  MER_REQUIRE(Tn >= 1, MER_ESHAPE, "mer_hubert_forward: input too short");
+  const int M = B * Tn;
+  const P16 none = {nullptr, nullptr};
+
+  // conv0 + GroupNorm + GELU -> channels-last planes
+  MER_TRY(mer_hubert_conv0_gn(wav, B, L, w.conv0_w, C, c.conv_kernel[0], c.conv_stride[0], w.conv_norm_g[0], w.conv_norm_b[0],
+                              1e-5f, p.stats, p.convA.hi, p.convA.lo, dt, st));
+  // conv1.. as implicit-im2col GEMMs (row m=(b,t) starts at b*T_in*C + t*stride*C, K = k*C contiguous)
+  P16 src = p.convA, dst = p.convB;
+  for (int i = 1; i < c.n_conv; ++i) {
+    const bool last = i == c.n_conv - 1;
+    mer_gemm16_args g;
+    memset(&g, 0, sizeof(g));
+    g.M = B * p.T[i]; g.N = C; g.K = c.conv_kernel[i] * C; g.dtype = dt;
+    g.a_hi = src.hi; g.a_lo = src.lo; g.lda = (long long)c.conv_stride[i] * C;
+    g.a_rows_per_batch = p.T[i]; g.a_batch_stride = (long long)p.T[i - 1] * C;
+    g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.ldw = g.K;
+    g.bias = c.conv_bias ? w.conv_b[i] : nullptr; g.act = MER_ACT_GELU;
+    if (last) { g.c32 = p.conv_last32; g.ldc32 = C; }
+    if (!last || !c.feat_proj_layer_norm) { g.c16_hi = (last ? p.fp16.hi : dst.hi); g.c16_lo = (last ? p.fp16.lo : dst.lo); g.ldc16 = C; }
+    g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
+    MER_TRY(mer_gemm16(&g, stream));
+    P16 t = src; src = dst; dst = t;
+  }
+  // feature projection: LayerNorm(C) -> Linear(C -> D)   (HF:hubert/modeling_hubert.py:216-231)
+  if (c.feat_proj_layer_norm)
+    MER_TRY(mer_layernorm(p.conv_last32, C, w.fp_ln_g, w.fp_ln_b, c.tf.ln_eps, M, C, MER_ACT_NONE, nullptr, 0, p.fp16.hi, p.fp16.lo, C, dt, st));
+  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0));
+
+  // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
+  HsMap hs;
+  hs.stride = (long long)M * D;
+  if (hidden_states) { hs.base = hidden_states; hs.ring = 0; } else { hs.base = p.ring; hs.ring = 5; }
+  {
+    const int G = c.pos_groups, Dg = D / G, K = c.pos_k;
+    MER_TRY(mer_posconv_pack(p.hproj, B, Tn, D, G, K, p.pospack.hi, p.pospack.lo, dt, st));
+    mer_gemm16_args g;
+    memset(&g, 0, sizeof(g));
+    g.M = Tn; g.N = Dg; g.K = K * Dg; g.dtype = dt;
+    g.a_hi = p.pospack.hi; g.a_lo = p.pospack.lo; g.lda = Dg;
+    g.w_hi = w.pos_w.hi; g.w_lo = w.pos_w.lo; g.ldw = g.K;
+    g.bias = w.pos_b; g.act = MER_ACT_GELU;
+    g.residual = p.hproj; g.ldr = D;
+    g.c32 = c.stable_layer_norm ? hs.at(0) : p.tf.t32; g.ldc32 = D;
+    g.nbatch = B * G; g.nb_inner = G;
+    g.a_so = (long long)G * (Tn + K) * Dg; g.a_si = (long long)(Tn + K) * Dg;
+    g.w_si = (long long)Dg * K * Dg; g.bias_si = Dg;
+    g.c_so = (long long)Tn * D; g.c_si = Dg;
+    g.passes = cps;
+    MER_TRY(mer_gemm16(&g, stream));
+  }
+  if (!c.stable_layer_norm)
+    MER_TRY(mer_layernorm(p.tf.t32, D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(0), D, p.tf.cur16.hi, p.tf.cur16.lo, D, dt, st));
+
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, Tn, hs, p.tf, nullptr));
+
+  if (c.stable_layer_norm)  // final LayerNorm only on the last state (HF:hubert/modeling_hubert.py:612)
+    MER_TRY(mer_layernorm(hs.at(c.tf.layers), D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(c.tf.layers), D, nullptr, nullptr, 0, dt, st));
+
+  return last4_pool(st, hs, c.tf.layers, M, D, frames, seg_start, seg_len, nseg, pooled);
+}
+
+// =============================================================================================
+// CLIP vision tower
+// =============================================================================================
+struct mer_vit {
+  mer_vit_config cfg;
+  mer_vit_weights w;
+  std::vector<mer_tf_layer> layers;
+};
+
+extern "C" int mer_vit_create(const mer_vit_config* cfg, const mer_vit_weights* w, mer_vit** out) {
+  MER_REQUIRE(cfg && w && out, MER_EINVAL, "mer_vit_create: null argument");
+  MER_TRY(check_tf(cfg->tf, "mer_vit_create"));
+  MER_REQUIRE(cfg->tf.pre_ln == 1, MER_EUNSUPPORTED, "mer_vit_create: ViT blocks are pre-LN");
+  MER_REQUIRE(cfg->image_size % cfg->patch_size == 0 && cfg->patch_size % 4 == 0, MER_ESHAPE, "mer_vit_create: image/patch size");
+  MER_REQUIRE((cfg->channels * cfg->patch_size * cfg->patch_size) % 8 == 0, MER_ESHAPE, "mer_vit_create: C*P*P %% 8 != 0");
+  MER_REQUIRE(w->layers && w->patch_w.hi && w->cls && w->pos, MER_EINVAL, "mer_vit_create: missing weights");
+  mer_vit* h = new mer_vit();
+  h->cfg = *cfg;
+  h->w = *w;
+  h->layers.assign(w->layers, w->layers + cfg->tf.layers);
+  h->w.layers = h->layers.data();
+  *out = h;
+  return MER_OK;
+}
+extern "C" void mer_vit_destroy(mer_vit* h) { delete h; }
+
+struct VitPlan {
+  P16 patches;
+  float* patch32;
+  float* x;
+  P16 cls16;
+  float* feats;
+  TfBufs tf;
+};
+
+static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
+  const mer_vit_config& c = h->cfg;
+  const long long g = c.image_size / c.patch_size, P = g * g, D = c.tf.hidden;
+  const long long cols = (long long)c.channels * c.patch_size * c.patch_size;
+  const bool lo = c.tf.passes == 3;
+  p.patches = take16(ar, N * P * cols, lo);
+  p.patch32 = (float*)ar.take(N * P * D * 4);
+  p.x = (float*)ar.take(N * (P + 1) * D * 4);
+  p.cls16 = take16(ar, (long long)N * D, lo);
+  p.feats = (float*)ar.take((long long)N * c.proj_dim * 4);
+  tf_plan(ar, c.tf, N * (P + 1), p.tf);
+  return ar.off;
+}
+
+extern "C" long long mer_vit_workspace_bytes(const mer_vit* h, int N) {
+  if (!h || N <= 0) return MER_EINVAL;
+  Arena ar(nullptr, 0, true);
+  VitPlan p;
+  return vit_plan(h, ar, N, p) + 256;
+}
+
+extern "C" int mer_vit_forward(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
+                               float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                               mer_stream_t stream) {
+  MER_REQUIRE(h && pixels && workspace && N > 0, MER_EINVAL, "mer_vit_forward: bad argument");
+  MER_REQUIRE(((uintptr_t)workspace & 255) == 0, MER_EINVAL, "mer_vit_forward: workspace must be 256-byte aligned");
+  const mer_vit_config& c = h->cfg;
+  const mer_vit_weights& w = h->w;
+  hipStream_t st = (hipStream_t)stream;
+  Arena ar(workspace, workspace_bytes, false);
+  VitPlan p;
+  vit_plan(h, ar, N, p);
+  MER_REQUIRE(ar.ok(), MER_ENOMEM, "mer_vit_forward: workspace too small (%lld < %lld bytes)", workspace_bytes, ar.off);
+  const int g = c.image_size / c.patch_size, P = g * g, D = c.tf.hidden, dt = c.tf.dtype, ps = c.tf.passes;
+  const int cols = c.channels * c.patch_size * c.patch_size;
+  const P16 none = {nullptr, nullptr};
+  // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
+  MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
+  MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, nullptr, MER_ACT_NONE, nullptr, 0, p.patch32, D, none, 0));
+  // [CLS] + position embeddings + pre_layrnorm
+  MER_TRY(mer_vit_assemble(p.patch32, w.cls, w.pos, w.pre_ln_g, w.pre_ln_b, c.tf.ln_eps, N, P, D, p.x, nullptr, nullptr, dt, st));
+  HsMap hs;
+  hs.base = p.x; hs.stride = 0; hs.ring = 1;  // pre-LN blocks update the residual stream in place
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), N, P + 1, hs, p.tf, nullptr));
+  // pooled = post_layernorm(x[:, 0]); features = visual_projection(pooled)   (HF:clip/modeling_clip.py:719-748)
+  MER_TRY(mer_layernorm(p.x, (long long)(P + 1) * D, w.post_ln_g, w.post_ln_b, c.tf.ln_eps, N, D, MER_ACT_NONE, nullptr, 0,
+                        p.cls16.hi, p.cls16.lo, D, dt, st));
+  float* feats = image_features ? image_features : p.feats;
+  MER_TRY(gemm(st, dt, ps, N, c.proj_dim, D, p.cls16, D, w.proj_w, nullptr, MER_ACT_NONE, nullptr, 0, feats, c.proj_dim, none, 0));
+  if (pooled) MER_TRY(mer_sum_pool(feats, nullptr, nullptr, nullptr, N, c.proj_dim, nullptr, seg_start, seg_len, nseg, pooled, st));
+  return MER_OK;
+}
+
+// =============================================================================================
+// BERT / RoBERTa
+// =============================================================================================
+struct mer_bert {
+  mer_bert_config cfg;
+  mer_bert_weights w;
+  std::vector<mer_tf_layer> layers;
+};
+
+extern "C" int mer_bert_create(const mer_bert_config* cfg, const mer_bert_weights* w, mer_bert** out) {
+  MER_REQUIRE(cfg && w && out, MER_EINVAL, "mer_bert_create: null argument");
+  MER_TRY(check_tf(cfg->tf, "mer_bert_create"));
+  MER_REQUIRE(cfg->tf.pre_ln == 0, MER_EUNSUPPORTED, "mer_bert_create: BERT blocks are post-LN");
+  MER_REQUIRE(w->layers && w->word && w->pos, MER_EINVAL, "mer_bert_create: missing weights");
+  mer_bert* h = new mer_bert();
+  h->cfg = *cfg;
+  h->w = *w;
+  h->layers.assign(w->layers, w->layers + cfg->tf.layers);
+  h->w.layers = h->layers.data();
+  *out = h;
+  return MER_OK;
+}
+extern "C" void mer_bert_destroy(mer_bert* h) { delete h; }
+
+struct BertPlan {
+  float* ring;
+  TfBufs tf;
+};
+static long long bert_plan(const mer_bert* h, Arena& ar, int B, int T, bool want_hs, BertPlan& p) {
+  const long long M = (long long)B * T, D = h->cfg.tf.hidden;
+  p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
+  tf_plan(ar, h->cfg.tf, M, p.tf);
+  return ar.off;
+}
+extern "C" long long mer_bert_workspace_bytes(const mer_bert* h, int B, int T, int want_hidden_states) {
+  if (!h || B <= 0 || T <= 0) return MER_EINVAL;
+  Arena ar(nullptr, 0, true);
+  BertPlan p;
+  return bert_plan(h, ar, B, T, want_hidden_states != 0, p) + 256;
+}
+
+extern "C" int mer_bert_forward(const mer_bert* h, const int64_t* ids, const int64_t* token_type, const int* lengths, int B,
+                                int T, void* workspace, long long workspace_bytes, float* hidden_states, float* frames,
+                                const int* seg_start, const int* seg_len, int nseg, float* pooled, mer_stream_t stream) {
+  MER_REQUIRE(h && ids && workspace && B > 0 && T > 0, MER_EINVAL, "mer_bert_forward: bad argument");
+  MER_REQUIRE(T <= 512, MER_EUNSUPPORTED, "mer_bert_forward: T=%d > 512", T);
+  MER_REQUIRE(((uintptr_t)workspace & 255) == 0, MER_EINVAL, "mer_bert_forward: workspace must be 256-byte aligned");
+  const mer_bert_config& c = h->cfg;
+  const mer_bert_weights& w = h->w;
+  MER_REQUIRE(c.pos_mode == 0 ? T <= c.max_pos : T + c.pad_id + 1 <= c.max_pos, MER_ESHAPE,
+              "mer_bert_forward: T=%d exceeds the position table (%d)", T, c.max_pos);
+  hipStream_t st = (hipStream_t)stream;
+  Arena ar(workspace, workspace_bytes, false);
+  BertPlan p;
+  bert_plan(h, ar, B, T, hidden_states != nullptr, p);
+  MER_REQUIRE(ar.ok(), MER_ENOMEM, "mer_bert_forward: workspace too small (%lld < %lld bytes)", workspace_bytes, ar.off);
+  const int D = c.tf.hidden, dt = c.tf.dtype;
+  const long long M = (long long)B * T;
+  HsMap hs;
+  hs.stride = M * D;
+  if (hidden_states) { hs.base = hidden_states; hs.ring = 0; } else { hs.base = p.ring; hs.ring = 5; }
+  MER_TRY(mer_bert_embed(ids, token_type, B, T, D, w.word, w.pos, w.type, c.pos_mode, c.pad_id, w.emb_ln_g, w.emb_ln_b,
+                         c.emb_ln_eps, hs.at(0), p.tf.cur16.hi, p.tf.cur16.lo, dt, st));
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, T, hs, p.tf, lengths));
+  return last4_pool(st, hs, c.tf.layers, M, D, frames, seg_start, seg_len, nseg, pooled);
+}

@@ -1,0 +1,267 @@
+// frontend.hip — the non-GEMM front ends and the pooling tail of the three encoders.
+//   mer_hubert_conv0_gn  Conv1d(1->C,k,s) + GroupNorm(C,C) + GELU     HF:hubert/modeling_hubert.py:154-175
+//   mer_posconv_pack     group-major zero-padded copy for the grouped positional conv     HF:...:45-92
+//   mer_vit_patchify     NCHW pixels -> [patch, c*P*P] rows (Conv2d stride==kernel as a GEMM)
+//   mer_split16          fp32 -> 16-bit hi/lo planes
+//   mer_sum_pool         last-4 hidden-state sum + per-clip temporal mean
+//                        (extract_audio_huggingface.py:98-108, extract_text_huggingface.py:226-249)
+// All HBM-bound; each element is read once with the widest load the layout allows.
+#include "common.h"
+
+namespace mer {
+
+// ---------------------------------------------------------------------------------------------
+// conv0: y[b,c,t] = sum_j w[c,j] * x[b, t*stride + j].  Pass 1 accumulates per-(b,c) sum / sum of
+// squares over t in fp64 (GroupNorm with num_groups == C is a per-channel norm over time);
+// pass 2 recomputes y (10 FMAs — cheaper than a 2 x 33 MB/clip round trip through HBM),
+// normalises, applies GELU and writes channels-last 16-bit planes [B, T0, C].
+// ---------------------------------------------------------------------------------------------
+constexpr int C0_TCH = 256;   // output frames per workgroup
+constexpr int C0_KMAX = 16;
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int T0, const float* w, int C, int k,
+                                                    int stride, const float* gamma, const float* beta, float eps,
+                                                    double* stats, T* ohi, T* olo) {
+  __shared__ float xs[C0_TCH * 8 + C0_KMAX];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * C0_TCH;
+  const int nt = (T0 - t0) < C0_TCH ? (T0 - t0) : C0_TCH;
+  const int nin = (nt - 1) * stride + k;
+  const float* xb = wav + (long long)b * L + (long long)t0 * stride;
+  for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wr[C0_KMAX];
+#pragma unroll
+    for (int j = 0; j < C0_KMAX; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
+    if (!APPLY) {
+      float s = 0.f, q = 0.f;
+      for (int t = 0; t < nt; ++t) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_KMAX; ++j)
+          if (j < k) y = fmaf(wr[j], xs[t * stride + j], y);
+        s += y;
+        q = fmaf(y, y, q);
+      }
+      atomicAdd(&stats[((long long)b * C + c) * 2 + 0], (double)s);
+      atomicAdd(&stats[((long long)b * C + c) * 2 + 1], (double)q);
+    } else {
+      const double mean_d = stats[((long long)b * C + c) * 2 + 0] / (double)T0;
+      const double var_d = stats[((long long)b * C + c) * 2 + 1] / (double)T0 - mean_d * mean_d;
+      const float rstd = 1.0f / sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + eps);
+      const float ga = gamma[c] * rstd;
+      const float be = beta[c] - (float)mean_d * ga;
+      for (int t = 0; t < nt; ++t) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_KMAX; ++j)
+          if (j < k) y = fmaf(wr[j], xs[t * stride + j], y);
+        const float z = act_apply(fmaf(y, ga, be), MER_ACT_GELU);
+        T hh, ll;
+        split16<T>(z, hh, ll);
+        const long long o = ((long long)b * T0 + t0 + t) * C + c;
+        ohi[o] = hh;
+        if (olo) olo[o] = ll;
+      }
+    }
+  }
+}
+
+// x [B,T,D] fp32 -> out [B,G,T+K,Dg]; 4 channels per thread.
+template <typename T>
+__global__ void posconv_pack_kernel(const float* x, int B, int Tn, int D, int G, int K, T* ohi, T* olo) {
+  const int Dg = D / G, TPad = Tn + K, half = K / 2;
+  const long long total4 = (long long)B * G * TPad * Dg / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int c = (int)(e % Dg);
+    const long long r = e / Dg;
+    const int tp = (int)(r % TPad);
+    const long long bg = r / TPad;
+    const int g = (int)(bg % G), b = (int)(bg / G);
+    const int t = tp - half;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < Tn) v = *reinterpret_cast<const f32x4*>(x + ((long long)b * Tn + t) * D + g * Dg + c);
+    typename T16<T>::v4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      T hh, ll;
+      split16<T>(v[j], hh, ll);
+      h[j] = hh;
+      l[j] = ll;
+    }
+    *reinterpret_cast<typename T16<T>::v4*>(ohi + e) = h;
+    if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + e) = l;
+  }
+}
+
+// pixels [N,C,H,W] -> rows [N*gh*gw, C*P*P]; 4 pixels (along j) per thread.
+template <typename T>
+__global__ void patchify_kernel(const float* px, int N, int C, int H, int W, int P, T* ohi, T* olo) {
+  const int gh = H / P, gw = W / P, cols = C * P * P;
+  const long long total4 = (long long)N * gh * gw * cols / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int col = (int)(e % cols);
+    const long long row = e / cols;
+    const int c = col / (P * P), ii = (col % (P * P)) / P, j = col % P;
+    const int pp = (int)(row % (gh * gw));
+    const long long n = row / (gh * gw);
+    const int py = pp / gw, pxx = pp % gw;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(px + ((n * C + c) * H + (py * P + ii)) * (long long)W + pxx * P + j);
+    typename T16<T>::v4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      T hh, ll;
+      split16<T>(v[q], hh, ll);
+      h[q] = hh;
+      l[q] = ll;
+    }
+    *reinterpret_cast<typename T16<T>::v4*>(ohi + e) = h;
+    if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + e) = l;
+  }
+}
+
+template <typename T>
+__global__ void split16_kernel(const float* x, T* hi, T* lo, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    T hh, ll;
+    split16<T>(x[i], hh, ll);
+    hi[i] = hh;
+    if (lo) lo[i] = ll;
+  }
+}
+
+__global__ void sum4_kernel(const float* h0, const float* h1, const float* h2, const float* h3, long long n4, float* out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 s = reinterpret_cast<const f32x4*>(h0)[i];
+    if (h1) s = s + reinterpret_cast<const f32x4*>(h1)[i];
+    if (h2) s = s + reinterpret_cast<const f32x4*>(h2)[i];
+    if (h3) s = s + reinterpret_cast<const f32x4*>(h3)[i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+// grid (nseg, ceil(D/64)); block 256 = 4 waves; wave w sums rows w, w+4, ... of the segment for
+// 64 consecutive columns (coalesced 256-B row slices), partials combined through LDS.
+__global__ __launch_bounds__(256) void seg_mean_kernel(const float* h0, const float* h1, const float* h2,
+                                                       const float* h3, int D, const int* seg_start,
+                                                       const int* seg_len, float* out) {
+  __shared__ float part[4][64];
+  const int seg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + lane;
+  const int r0 = seg_start[seg], n = seg_len[seg];
+  float acc = 0.f;
+  if (col < D) {
+    for (int r = wave; r < n; r += 4) {
+      const long long o = (long long)(r0 + r) * D + col;
+      float s = h0[o];
+      if (h1) s += h1[o];
+      if (h2) s += h2[o];
+      if (h3) s += h3[o];
+      acc += s;
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < D) {
+    const float tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    out[(long long)seg * D + col] = n > 0 ? tot / (float)n : 0.f;
+  }
+}
+
+static inline unsigned grid_for(long long n, int block) {
+  long long g = cdiv(n, block);
+  return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace mer
+
+extern "C" int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* w, int C, int k, int stride,
+                                   const float* gamma, const float* beta, float eps, double* stats, void* out_hi,
+                                   void* out_lo, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(wav && w && gamma && beta && stats && out_hi, MER_EINVAL, "mer_hubert_conv0_gn: null pointer");
+  MER_REQUIRE(k >= 1 && k <= C0_KMAX && stride >= 1 && stride <= 8, MER_EUNSUPPORTED,
+              "mer_hubert_conv0_gn: kernel %d / stride %d unsupported", k, stride);
+  MER_REQUIRE(L >= k, MER_ESHAPE, "mer_hubert_conv0_gn: L=%d < k=%d", L, k);
+  const int T0 = (L - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st);
+  MER_REQUIRE(e == hipSuccess, MER_ELAUNCH, "mer_hubert_conv0_gn: memset failed: %s", hipGetErrorString(e));
+  dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
+  if (dtype == MER_DT_F16) {
+    hipLaunchKernelGGL((conv0_kernel<f16, false>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
+                       (f16*)nullptr, (f16*)nullptr);
+    hipLaunchKernelGGL((conv0_kernel<f16, true>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
+                       (f16*)out_hi, (f16*)out_lo);
+  } else {
+    hipLaunchKernelGGL((conv0_kernel<bf16, false>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
+                       (bf16*)nullptr, (bf16*)nullptr);
+    hipLaunchKernelGGL((conv0_kernel<bf16, true>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
+                       (bf16*)out_hi, (bf16*)out_lo);
+  }
+  return check_launch("hubert_conv0_gn");
+}
+
+extern "C" int mer_posconv_pack(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo, int dtype,
+                                mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && out_hi && B > 0 && T > 0, MER_EINVAL, "mer_posconv_pack: bad args");
+  MER_REQUIRE(D % G == 0 && (D / G) % 8 == 0, MER_ESHAPE, "mer_posconv_pack: D/G must be a multiple of 8");
+  const long long n4 = (long long)B * G * (T + K) * (D / G) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16)
+    hipLaunchKernelGGL((posconv_pack_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, x, B, T, D, G, K, (f16*)out_hi, (f16*)out_lo);
+  else
+    hipLaunchKernelGGL((posconv_pack_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, x, B, T, D, G, K, (bf16*)out_hi, (bf16*)out_lo);
+  return check_launch("posconv_pack");
+}
+
+extern "C" int mer_vit_patchify(const float* pixels, int N, int C, int H, int W, int P, void* out_hi, void* out_lo,
+                                int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(pixels && out_hi && N > 0, MER_EINVAL, "mer_vit_patchify: bad args");
+  MER_REQUIRE(H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0, MER_ESHAPE, "mer_vit_patchify: H=%d W=%d P=%d unsupported", H, W, P);
+  const long long n4 = (long long)N * C * H * W / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16)
+    hipLaunchKernelGGL((patchify_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, (f16*)out_hi, (f16*)out_lo);
+  else
+    hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, (bf16*)out_hi, (bf16*)out_lo);
+  return check_launch("vit_patchify");
+}
+
+extern "C" int mer_split16(const float* x, void* hi, void* lo, long long n, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && hi && n > 0, MER_EINVAL, "mer_split16: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16)
+    hipLaunchKernelGGL((split16_kernel<f16>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, (f16*)hi, (f16*)lo, n);
+  else
+    hipLaunchKernelGGL((split16_kernel<bf16>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, (bf16*)hi, (bf16*)lo, n);
+  return check_launch("split16");
+}
+
+extern "C" int mer_sum_pool(const float* h0, const float* h1, const float* h2, const float* h3, long long M, int D,
+                            float* out_frames, const int* seg_start, const int* seg_len, int nseg, float* out_pool,
+                            mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(h0 && M > 0 && D > 0, MER_EINVAL, "mer_sum_pool: bad args");
+  MER_REQUIRE(D % 4 == 0, MER_ESHAPE, "mer_sum_pool: D %% 4 != 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (out_frames) {
+    const long long n4 = M * D / 4;
+    hipLaunchKernelGGL(sum4_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, st, h0, h1, h2, h3, n4, out_frames);
+    int rc = check_launch("sum4");
+    if (rc) return rc;
+  }
+  if (out_pool) {
+    MER_REQUIRE(seg_start && seg_len && nseg > 0, MER_EINVAL, "mer_sum_pool: segments missing");
+    hipLaunchKernelGGL(seg_mean_kernel, dim3(nseg, (unsigned)cdiv(D, 64)), dim3(256), 0, st, h0, h1, h2, h3, D, seg_start, seg_len, out_pool);
+    return check_launch("seg_mean");
+  }
+  return MER_OK;
+}

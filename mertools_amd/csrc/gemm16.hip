@@ -1,0 +1,327 @@
+// gemm16.hip — C = epilogue(A * W^T) on the gfx950 16x16x32 f16/bf16 MFMA, fp32 accumulate.
+//
+// This is the kernel >90 % of the encoder FLOPs go through (QKV / out-proj / FFN GEMMs of
+// HF:hubert/modeling_hubert.py:262-368, HF:clip/modeling_clip.py:280-350,
+// HF:roberta/modeling_roberta.py:186-399, the strided Conv1d stack :106-175 as implicit
+// im2col, the ViT patch embedding and the grouped positional conv).
+//
+// Structure (one workgroup = WM x WN waves, wave tile (BM/WM) x (BN/WN), 16x16 MFMA tiles):
+//   * A and W k-slabs are staged global -> VGPR -> LDS, double-buffered, one barrier per slab;
+//     global loads for slab t+1 are issued before the MFMAs of slab t and written to the other
+//     LDS buffer after them.
+//   * LDS rows are BK 16-bit elements; the 16-byte chunk index is XOR-swizzled with
+//     (row / rows_per_256B) so that the ds_read_b128 fragment reads (16 lanes = 16 different rows,
+//     same k-chunk) hit 16 distinct 16-byte bank slots.
+//   * "3-pass" mode keeps hi and lo planes of both operands in LDS and issues
+//     acc += a_hi*w_hi + a_hi*w_lo + a_lo*w_hi  (fp32-grade result from 16-bit MFMAs).
+//   * epilogue: the wave's accumulator tile goes through LDS once so that bias / activation /
+//     residual / fp32 + 16-bit stores all run on 4 consecutive columns per lane with full-line
+//     coalesced global accesses.
+//   * workgroup -> tile mapping is XCD-aware (blocks b, b+8, b+16.. share an XCD / L2 and get
+//     neighbouring tiles; bijective for any grid size).
+#include "common.h"
+
+namespace mer {
+
+struct Gemm16Params {
+  int M, N, K;
+  const void* a_hi; const void* a_lo; long long lda; int a_rpb; long long a_bstride;
+  const void* w_hi; const void* w_lo; long long ldw;
+  const float* bias; int act;
+  const float* residual; long long ldr;
+  float* c32; long long ldc32;
+  void* c16_hi; void* c16_lo; long long ldc16;
+  int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
+  int tiles_m, tiles_n;
+  int vec_ok;  // N % 4 == 0 and all output/residual strides+offsets 4-element aligned
+};
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP>
+__global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
+  typedef typename T16<T>::v8 v8;
+  constexpr int NT = WM * WN * 64;
+  constexpr int C = BK / 8;            // 16-byte chunks per LDS row
+  constexpr int RB = BK * 2;           // LDS row bytes
+  constexpr int R = 256 / RB;          // rows per 256-byte bank row
+  constexpr int SM = BM / WM, SN = BN / WN;
+  constexpr int TM = SM / 16, TN = SN / 16;
+  constexpr int KS = BK / 32;          // MFMA k-steps per slab
+  constexpr int CA = BM * C / NT;      // 16-byte chunks per thread per A plane
+  constexpr int CW = BN * C / NT;
+  constexpr int ROWS_PER_IT = NT / C;
+  constexpr int A_PLANE = BM * RB, W_PLANE = BN * RB;
+  constexpr int STAGE = AP * A_PLANE + WP * W_PLANE;
+  constexpr int CLD = SN + 4;          // padded fp32 row of the per-wave C staging tile
+  constexpr int CSTAGE = WM * WN * SM * CLD * 4;
+  constexpr int SMEM = (2 * STAGE > CSTAGE) ? 2 * STAGE : CSTAGE;
+  static_assert(NT % C == 0 && (BM * C) % NT == 0 && (BN * C) % NT == 0, "bad tile/thread split");
+
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- XCD-aware, bijective block -> tile map ----
+  const int nblk = p.tiles_m * p.tiles_n;
+  int tile_m, tile_n;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    tile_n = swz % p.tiles_n;
+    tile_m = swz / p.tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- batch offsets ----
+  const int z = blockIdx.y;
+  const int zo = z / p.nb_inner, zi = z % p.nb_inner;
+  const long long a_boff = (long long)zo * p.a_so + (long long)zi * p.a_si;
+  const long long w_boff = (long long)zi * p.w_si;
+  const long long c_boff = (long long)zo * p.c_so + (long long)zi * p.c_si;
+
+  const T* a_pl[2] = {(const T*)p.a_hi + a_boff, AP == 2 ? (const T*)p.a_lo + a_boff : nullptr};
+  const T* w_pl[2] = {(const T*)p.w_hi + w_boff, WP == 2 ? (const T*)p.w_lo + w_boff : nullptr};
+
+  // ---- per-thread global load coordinates ----
+  const int ld_ch = tid % C;
+  const int ld_row0 = tid / C;
+  long long a_off[CA], w_off[CW];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    int m = m0 + ld_row0 + i * ROWS_PER_IT;
+    m = m < p.M ? m : p.M - 1;
+    a_off[i] = (p.a_rpb > 0) ? (long long)(m / p.a_rpb) * p.a_bstride + (long long)(m % p.a_rpb) * p.lda
+                             : (long long)m * p.lda;
+  }
+#pragma unroll
+  for (int i = 0; i < CW; ++i) {
+    int n = n0 + ld_row0 + i * ROWS_PER_IT;
+    n = n < p.N ? n : p.N - 1;
+    w_off[i] = (long long)n * p.ldw;
+  }
+
+  u32x4 ra[AP][CA], rw[WP][CW];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto gload = [&](int k0) {
+    const int k = k0 + ld_ch * 8;
+    const bool kin = k < p.K;
+#pragma unroll
+    for (int pl = 0; pl < AP; ++pl)
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        ra[pl][i] = kin ? *reinterpret_cast<const u32x4*>(a_pl[pl] + a_off[i] + k) : zero4;
+#pragma unroll
+    for (int pl = 0; pl < WP; ++pl)
+#pragma unroll
+      for (int i = 0; i < CW; ++i)
+        rw[pl][i] = kin ? *reinterpret_cast<const u32x4*>(w_pl[pl] + w_off[i] + k) : zero4;
+  };
+  auto lds_store = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int pl = 0; pl < AP; ++pl)
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int row = ld_row0 + i * ROWS_PER_IT;
+        const int off = row * RB + ((ld_ch ^ ((row / R) & (C - 1))) << 4);
+        *reinterpret_cast<u32x4*>(base + pl * A_PLANE + off) = ra[pl][i];
+      }
+#pragma unroll
+    for (int pl = 0; pl < WP; ++pl)
+#pragma unroll
+      for (int i = 0; i < CW; ++i) {
+        const int row = ld_row0 + i * ROWS_PER_IT;
+        const int off = row * RB + ((ld_ch ^ ((row / R) & (C - 1))) << 4);
+        *reinterpret_cast<u32x4*>(base + AP * A_PLANE + pl * W_PLANE + off) = rw[pl][i];
+      }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lds_store(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const char* base = smem + cur * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v8 af[AP][TM], wf[WP][TN];
+      const int chunk = ks * 4 + lg;
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) {
+        const int row = wm * SM + mt * 16 + li;
+        const int off = row * RB + ((chunk ^ ((row / R) & (C - 1))) << 4);
+#pragma unroll
+        for (int pl = 0; pl < AP; ++pl) af[pl][mt] = *reinterpret_cast<const v8*>(base + pl * A_PLANE + off);
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int row = wn * SN + nt * 16 + li;
+        const int off = row * RB + ((chunk ^ ((row / R) & (C - 1))) << 4);
+#pragma unroll
+        for (int pl = 0; pl < WP; ++pl)
+          wf[pl][nt] = *reinterpret_cast<const v8*>(base + AP * A_PLANE + pl * W_PLANE + off);
+      }
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          if (AP == 2) acc[mt][nt] = T16<T>::mfma(af[AP - 1][mt], wf[0][nt], acc[mt][nt]);
+          if (WP == 2) acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[WP - 1][nt], acc[mt][nt]);
+          acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[0][nt], acc[mt][nt]);
+        }
+    }
+    if (kt + 1 < nk) lds_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> per-wave LDS tile -> 4 consecutive columns per lane ----
+  float* ct = reinterpret_cast<float*>(smem) + wave * SM * CLD;
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ct[(mt * 16 + lg * 4 + r) * CLD + nt * 16 + li] = acc[mt][nt][r];
+  __syncthreads();
+
+  constexpr int V4_PER_ROW = SN / 4;
+  constexpr int ROWS_IT = 64 / V4_PER_ROW;
+  const int c4 = lane % V4_PER_ROW;
+  const int rsub = lane / V4_PER_ROW;
+  const int col = n0 + wn * SN + c4 * 4;
+  if (col >= p.N) return;
+  const float* bias = p.bias ? p.bias + (long long)zi * p.bias_si : nullptr;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col + j < p.N) bv[j] = bias[col + j];
+  }
+  const float* res = p.residual ? p.residual + c_boff : nullptr;
+  float* c32 = p.c32 ? p.c32 + c_boff : nullptr;
+  T* c16h = p.c16_hi ? (T*)p.c16_hi + c_boff : nullptr;
+  T* c16l = p.c16_lo ? (T*)p.c16_lo + c_boff : nullptr;
+  const bool vec = p.vec_ok && (col + 4 <= p.N);
+
+#pragma unroll 4
+  for (int it = 0; it < SM / ROWS_IT; ++it) {
+    const int lr = it * ROWS_IT + rsub;
+    const int row = m0 + wm * SM + lr;
+    if (row >= p.M) continue;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c4 * 4);
+    float v[4] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+    if (vec) {
+      if (res) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (c32) *reinterpret_cast<f32x4*>(c32 + (long long)row * p.ldc32 + col) = f32x4{v[0], v[1], v[2], v[3]};
+      if (c16h) {
+        typename T16<T>::v4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          T hh, ll;
+          split16<T>(v[j], hh, ll);
+          h[j] = hh;
+          l[j] = ll;
+        }
+        *reinterpret_cast<typename T16<T>::v4*>(c16h + (long long)row * p.ldc16 + col) = h;
+        if (c16l) *reinterpret_cast<typename T16<T>::v4*>(c16l + (long long)row * p.ldc16 + col) = l;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (col + j >= p.N) break;
+        float x = v[j];
+        if (res) x += res[(long long)row * p.ldr + col + j];
+        if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
+        if (c16h) {
+          T hh, ll;
+          split16<T>(x, hh, ll);
+          c16h[(long long)row * p.ldc16 + col + j] = hh;
+          if (c16l) c16l[(long long)row * p.ldc16 + col + j] = ll;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP>
+static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
+  Gemm16Params p = p0;
+  p.tiles_m = (int)cdiv(p.M, BM);
+  p.tiles_n = (int)cdiv(p.N, BN);
+  dim3 grid(p.tiles_m * p.tiles_n, nbatch, 1), block(WM * WN * 64, 1, 1);
+  hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP>), grid, block, 0, st, p);
+  return check_launch("gemm16");
+}
+
+template <typename T>
+static int dispatch(const Gemm16Params& p, int nbatch, int passes, int tile, hipStream_t st) {
+  if (tile == 2) {
+    if (passes == 3) return launch<T, 128, 64, 32, 2, 2, 2, 2>(p, nbatch, st);
+    return launch<T, 128, 64, 64, 2, 2, 1, 1>(p, nbatch, st);
+  }
+  if (passes == 3) return launch<T, 128, 128, 32, 2, 2, 2, 2>(p, nbatch, st);
+  return launch<T, 128, 128, 64, 2, 2, 1, 1>(p, nbatch, st);
+}
+
+}  // namespace mer
+
+extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(a != nullptr, MER_EINVAL, "mer_gemm16: null args");
+  MER_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, MER_ESHAPE, "mer_gemm16: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+  MER_REQUIRE(a->a_hi && a->w_hi, MER_EINVAL, "mer_gemm16: a_hi / w_hi must be non-null");
+  MER_REQUIRE(a->passes == 1 || a->passes == 3, MER_EINVAL, "mer_gemm16: passes must be 1 or 3 (got %d)", a->passes);
+  MER_REQUIRE(a->passes == 1 || (a->a_lo && a->w_lo), MER_EINVAL, "mer_gemm16: passes=3 needs a_lo and w_lo");
+  MER_REQUIRE(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0, MER_ESHAPE,
+              "mer_gemm16: K, lda, ldw must be multiples of 8 (K=%d lda=%lld ldw=%lld)", a->K, a->lda, a->ldw);
+  MER_REQUIRE(a->a_so % 8 == 0 && a->a_si % 8 == 0 && a->w_si % 8 == 0 && a->a_batch_stride % 8 == 0, MER_ESHAPE,
+              "mer_gemm16: batch strides of A / W must be multiples of 8 elements");
+  MER_REQUIRE(a->dtype == MER_DT_F16 || a->dtype == MER_DT_BF16, MER_EINVAL, "mer_gemm16: bad dtype %d", a->dtype);
+  MER_REQUIRE(a->c32 || a->c16_hi, MER_EINVAL, "mer_gemm16: no output given");
+  MER_REQUIRE(!a->c16_lo || a->c16_hi, MER_EINVAL, "mer_gemm16: c16_lo without c16_hi");
+  const int nbatch = a->nbatch > 0 ? a->nbatch : 1;
+  Gemm16Params p;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
+  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw;
+  p.bias = a->bias; p.act = a->act;
+  p.residual = a->residual; p.ldr = a->ldr;
+  p.c32 = a->c32; p.ldc32 = a->ldc32;
+  p.c16_hi = a->c16_hi; p.c16_lo = a->c16_lo; p.ldc16 = a->ldc16;
+  p.nb_inner = a->nb_inner > 0 ? a->nb_inner : 1;
+  p.a_so = a->a_so; p.a_si = a->a_si; p.w_si = a->w_si; p.bias_si = a->bias_si; p.c_so = a->c_so; p.c_si = a->c_si;
+  p.tiles_m = p.tiles_n = 0;
+  bool vec = (a->N % 4 == 0) && (a->c_so % 4 == 0) && (a->c_si % 4 == 0);
+  if (a->residual) vec = vec && (a->ldr % 4 == 0) && (((uintptr_t)a->residual & 15) == 0);
+  if (a->c32) vec = vec && (a->ldc32 % 4 == 0) && (((uintptr_t)a->c32 & 15) == 0);
+  if (a->c16_hi) vec = vec && (a->ldc16 % 4 == 0) && (((uintptr_t)a->c16_hi & 7) == 0);
+  if (a->c16_lo) vec = vec && (((uintptr_t)a->c16_lo & 7) == 0);
+  p.vec_ok = vec ? 1 : 0;
+  MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo) & 15) == 0, MER_EINVAL,
+              "mer_gemm16: operand planes must be 16-byte aligned");
+  int tile = a->tile;
+  if (tile == 0) tile = (a->N <= 64) ? 2 : 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, a->passes, tile, st);
+  return dispatch<bf16>(p, nbatch, a->passes, tile, st);
+}

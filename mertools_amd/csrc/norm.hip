@@ -1,0 +1,256 @@
+// norm.hip — row-wise LayerNorm family (one wave64 per row, whole row in registers).
+//   mer_layernorm     torch.nn.LayerNorm (+ optional activation) -> fp32 and/or 16-bit planes
+//   mer_vit_assemble  CLS/patch/position assembly (+ pre-LN)   HF:clip/modeling_clip.py:138-217
+//   mer_bert_embed    word+position+type embeddings + LN        HF:roberta/modeling_roberta.py:56-155
+// All three are HBM-bound streaming kernels: each row is read once with 16-byte loads, reduced
+// with two wave-level passes (mean, then centred variance, as torch does), and written once.
+#include "common.h"
+
+namespace mer {
+
+template <typename T, int NV>
+struct RowLN {
+  // v[j] holds columns (lane + 64*j)*4 .. +3 of the row; entries past D/4 are zero.
+  static __device__ __forceinline__ void run(f32x4 (&v)[NV], int lane, int nv4, int D, const float* gamma,
+                                             const float* beta, float eps, int act, float* o32, T* ohi, T* olo) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (lane + 64 * j < nv4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[j][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = lane + 64 * j;
+      if (idx < nv4) {
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
+        if (beta) b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = act_apply((v[j][e] - mean) * rstd * g[e] + b[e], act);
+        if (o32) *reinterpret_cast<f32x4*>(o32 + idx * 4) = y;
+        if (ohi) {
+          typename T16<T>::v4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            T hh, ll;
+            split16<T>(y[e], hh, ll);
+            h[e] = hh;
+            l[e] = ll;
+          }
+          *reinterpret_cast<typename T16<T>::v4*>(ohi + idx * 4) = h;
+          if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + idx * 4) = l;
+        }
+      }
+    }
+  }
+  static __device__ __forceinline__ void store_plain(f32x4 (&v)[NV], int lane, int nv4, float* o32, T* ohi, T* olo) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = lane + 64 * j;
+      if (idx < nv4) {
+        if (o32) *reinterpret_cast<f32x4*>(o32 + idx * 4) = v[j];
+        if (ohi) {
+          typename T16<T>::v4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            T hh, ll;
+            split16<T>(v[j][e], hh, ll);
+            h[e] = hh;
+            l[e] = ll;
+          }
+          *reinterpret_cast<typename T16<T>::v4*>(ohi + idx * 4) = h;
+          if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + idx * 4) = l;
+        }
+      }
+    }
+  }
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long long ldx, const float* gamma,
+                                                        const float* beta, float eps, int M, int D, int act,
+                                                        float* out32, long long ld32, T* ohi, T* olo, long long ld16) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63, nv4 = D >> 2;
+  const float* xr = x + (long long)row * ldx;
+  f32x4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = lane + 64 * j;
+    v[j] = idx < nv4 ? *reinterpret_cast<const f32x4*>(xr + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  RowLN<T, NV>::run(v, lane, nv4, D, gamma, beta, eps, act, out32 ? out32 + (long long)row * ld32 : nullptr,
+                    ohi ? ohi + (long long)row * ld16 : nullptr, olo ? olo + (long long)row * ld16 : nullptr);
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* patch, const float* cls, const float* pos,
+                                                           const float* gamma, const float* beta, float eps, int N,
+                                                           int P, int D, float* out32, T* ohi, T* olo) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)N * (P + 1)) return;
+  const int lane = threadIdx.x & 63, nv4 = D >> 2;
+  const int n = (int)(row / (P + 1)), t = (int)(row % (P + 1));
+  const float* src = t == 0 ? cls : patch + ((long long)n * P + (t - 1)) * D;
+  const float* pr = pos + (long long)t * D;
+  f32x4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = lane + 64 * j;
+    if (idx < nv4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + idx * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(pr + idx * 4);
+      v[j] = a + b;
+    } else {
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float* o32 = out32 ? out32 + row * D : nullptr;
+  T* oh = ohi ? ohi + row * D : nullptr;
+  T* ol = olo ? olo + row * D : nullptr;
+  if (gamma)
+    RowLN<T, NV>::run(v, lane, nv4, D, gamma, beta, eps, MER_ACT_NONE, o32, oh, ol);
+  else
+    RowLN<T, NV>::store_plain(v, lane, nv4, o32, oh, ol);
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* ids, const int64_t* tt, int B, int Tn, int D,
+                                                         const float* word, const float* pos, const float* type,
+                                                         int pos_mode, int pad_id, const float* gamma,
+                                                         const float* beta, float eps, float* out32, T* ohi, T* olo) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * Tn) return;
+  const int lane = threadIdx.x & 63, nv4 = D >> 2;
+  const int b = (int)(row / Tn), t = (int)(row % Tn);
+  const long long id = ids[row];
+  long long p;
+  if (pos_mode == 0) {
+    p = t;
+  } else {
+    // RoBERTa create_position_ids_from_input_ids: cumsum(mask) * mask + padding_idx
+    int cnt = 0;
+    for (int u = lane; u <= t; u += 64) cnt += (ids[(long long)b * Tn + u] != pad_id) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    p = (id != pad_id) ? (long long)pad_id + cnt : (long long)pad_id;
+  }
+  const long long ty = tt ? tt[row] : 0;
+  const float* wr = word + id * D;
+  const float* pr = pos + p * D;
+  const float* tr = type ? type + ty * D : nullptr;
+  f32x4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = lane + 64 * j;
+    if (idx < nv4) {
+      // HF: inputs_embeds + token_type_embeddings, then + position_embeddings
+      f32x4 a = *reinterpret_cast<const f32x4*>(wr + idx * 4);
+      if (tr) a = a + *reinterpret_cast<const f32x4*>(tr + idx * 4);
+      a = a + *reinterpret_cast<const f32x4*>(pr + idx * 4);
+      v[j] = a;
+    } else {
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  RowLN<T, NV>::run(v, lane, nv4, D, gamma, beta, eps, MER_ACT_NONE, out32 ? out32 + row * D : nullptr,
+                    ohi ? ohi + row * D : nullptr, olo ? olo + row * D : nullptr);
+}
+
+static int pick_nv(int D) {
+  const int need = (D / 4 + 63) / 64;
+  if (need <= 2) return 2;
+  if (need <= 3) return 3;
+  if (need <= 4) return 4;
+  if (need <= 8) return 8;
+  return 0;
+}
+
+}  // namespace mer
+
+#define MER_NV_SWITCH(NVVAR, ...)                        \
+  switch (NVVAR) {                                       \
+    case 2: { constexpr int NV = 2; __VA_ARGS__; } break;  \
+    case 3: { constexpr int NV = 3; __VA_ARGS__; } break;  \
+    case 4: { constexpr int NV = 4; __VA_ARGS__; } break;  \
+    default: { constexpr int NV = 8; __VA_ARGS__; } break; \
+  }
+
+extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, const float* beta, float eps, int M,
+                             int D, int act, float* out32, long long ld32, void* out16_hi, void* out16_lo,
+                             long long ld16, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && M > 0 && D > 0, MER_EINVAL, "mer_layernorm: bad args");
+  MER_REQUIRE(D % 4 == 0 && ldx % 4 == 0, MER_ESHAPE, "mer_layernorm: D and ldx must be multiples of 4 (D=%d)", D);
+  MER_REQUIRE(!out32 || ld32 % 4 == 0, MER_ESHAPE, "mer_layernorm: ld32 %% 4 != 0");
+  MER_REQUIRE(!out16_hi || ld16 % 4 == 0, MER_ESHAPE, "mer_layernorm: ld16 %% 4 != 0");
+  const int nv = pick_nv(D);
+  MER_REQUIRE(nv != 0, MER_EUNSUPPORTED, "mer_layernorm: D=%d > 2048 unsupported", D);
+  dim3 grid((unsigned)cdiv(M, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) {
+    MER_NV_SWITCH(nv, layernorm_kernel<f16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
+                                          act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16));
+  } else {
+    MER_NV_SWITCH(nv, layernorm_kernel<bf16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
+                                          act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16));
+  }
+  return check_launch("layernorm");
+}
+
+extern "C" int mer_vit_assemble(const float* patch, const float* cls, const float* pos, const float* gamma,
+                                const float* beta, float eps, int N, int P, int D, float* out32, void* out16_hi,
+                                void* out16_lo, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(patch && cls && pos && N > 0 && P > 0, MER_EINVAL, "mer_vit_assemble: bad args");
+  MER_REQUIRE(D % 4 == 0, MER_ESHAPE, "mer_vit_assemble: D %% 4 != 0");
+  const int nv = pick_nv(D);
+  MER_REQUIRE(nv != 0, MER_EUNSUPPORTED, "mer_vit_assemble: D=%d unsupported", D);
+  dim3 grid((unsigned)cdiv((long long)N * (P + 1), 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) {
+    MER_NV_SWITCH(nv, vit_assemble_kernel<f16, NV><<<grid, block, 0, st>>>(patch, cls, pos, gamma, beta,
+                                          eps, N, P, D, out32, (f16*)out16_hi, (f16*)out16_lo));
+  } else {
+    MER_NV_SWITCH(nv, vit_assemble_kernel<bf16, NV><<<grid, block, 0, st>>>(patch, cls, pos, gamma, beta,
+                                          eps, N, P, D, out32, (bf16*)out16_hi, (bf16*)out16_lo));
+  }
+  return check_launch("vit_assemble");
+}
+
+extern "C" int mer_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int T, int D, const float* word,
+                              const float* pos, const float* type, int pos_mode, int pad_id, const float* gamma,
+                              const float* beta, float eps, float* out32, void* out16_hi, void* out16_lo, int dtype,
+                              mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(ids && word && pos && B > 0 && T > 0, MER_EINVAL, "mer_bert_embed: bad args");
+  MER_REQUIRE(D % 4 == 0, MER_ESHAPE, "mer_bert_embed: D %% 4 != 0");
+  const int nv = pick_nv(D);
+  MER_REQUIRE(nv != 0, MER_EUNSUPPORTED, "mer_bert_embed: D=%d unsupported", D);
+  dim3 grid((unsigned)cdiv((long long)B * T, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) {
+    MER_NV_SWITCH(nv, bert_embed_kernel<f16, NV><<<grid, block, 0, st>>>(ids, token_type, B, T, D, word,
+                                          pos, type, pos_mode, pad_id, gamma, beta, eps, out32, (f16*)out16_hi,
+                                          (f16*)out16_lo));
+  } else {
+    MER_NV_SWITCH(nv, bert_embed_kernel<bf16, NV><<<grid, block, 0, st>>>(ids, token_type, B, T, D, word,
+                                          pos, type, pos_mode, pad_id, gamma, beta, eps, out32, (bf16*)out16_hi,
+                                          (bf16*)out16_lo));
+  }
+  return check_launch("bert_embed");
+}
