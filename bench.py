@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — clips/sec of the tri-modal (A+V+T) feature-extraction hot path on N MI355X.
+
+One "step" = one batch of B synthetic clips through all three encoders on the HIP path:
+  audio  5 s @16 kHz -> HuBERT-base -> last-4 sum -> utterance mean            [B,80000] -> [B,768]
+  visual 8 frames x 224^2 -> CLIP-ViT-B/16 get_image_features -> frame mean    [8B,3,224,224] -> [B,512]
+  text   64 tokens -> RoBERTa-base -> last-4 sum -> strip specials -> mean     [B,64] -> [B,768]
+(BASELINE.json metric; config 4's extraction leg, which is configs 2+3+text on one GPU.)
+Inputs are resident in HBM before the timed region.  N>1: one process per GPU (torchrun), clips
+shard across ranks with no data-path collective (weak scaling); the timed region is bracketed by
+barrier + synchronize and the max over ranks is reported.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (gemm16: fp16 MFMA GEMM) — algorithmic 2*M*N*K FLOPs of its launches
+                divided by their HIP-event durations (measured in a second, instrumented pass over
+                the same steps), against the 2.5 PFLOP/s dense fp16 MFMA peak.
+  cpu_baseline  the CPU oracle (oracle/, kind "port") timed on the host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_CLIP = {"hubert-base": 71.67, "clip-vit-b16-8f": 281.0, "roberta-base-64": 11.02}
+PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
+    ap.add_argument("--audio-precision", default="mixed", choices=["f16", "mixed", "x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_clips=2):
+    """The oracle's fp32 CPU forward (same architectures, same synthetic inputs), batch of `sample_clips`."""
+    from oracle import encoders_ref as R
+    from mertools_amd import synthetic as W
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    hc, cc, bc = W.hubert_config("base"), W.clip_config("base16"), W.bert_config("roberta-base")
+    hsd, csd, bsd = W.hubert_state_dict(hc, 0), W.clip_state_dict(cc, 0), W.bert_state_dict(bc, 0)
+    wav, px, ids = W.synth_audio(sample_clips), W.synth_frames(sample_clips * 8), W.synth_tokens(sample_clips)
+
+    def run():
+        with torch.no_grad():
+            a = torch.stack(R.hubert_hidden_states(hsd, vars(hc), wav))[[-4, -3, -2, -1]].sum(0).mean(1)
+            v = R.clip_image_features(csd, dict(vars(cc.vision_config), projection_dim=cc.projection_dim), px)
+            v = v.view(sample_clips, 8, -1).mean(1)
+            t = torch.stack(R.bert_hidden_states(bsd, dict(vars(bc), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
+        return a, v, t
+
+    run()  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        run()
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 4:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_clips * reps / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x batch of {sample_clips} tri-modal clips (HuBERT-base 5 s + CLIP-B/16 8 frames + RoBERTa-base 64 tok), "
+                      f"oracle fp32 torch-CPU forward, {cores} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from mertools_amd import _lib, synthetic as W
+    from mertools_amd.encoders import HipBertModel, HipCLIPModel, HipHubertModel
+
+    B = args.batch
+    mods = set(args.modalities)
+    models, inputs = {}, {}
+    # every rank: same weights (replicated), its own shard of synthetic clips (seed offset by rank)
+    if "a" in mods:
+        hc = W.hubert_config("base")
+        models["a"] = HipHubertModel(W.hubert_state_dict(hc, 0), hc, device=dev, precision=args.audio_precision)
+        inputs["a"] = W.synth_audio(B, seed=1234 + rank).to(dev)
+    if "v" in mods:
+        cc = W.clip_config("base16")
+        models["v"] = HipCLIPModel(W.clip_state_dict(cc, 0), cc, device=dev, precision="f16")
+        inputs["v"] = W.synth_frames(B * 8, seed=1235 + rank).to(dev)
+    if "t" in mods:
+        bc = W.bert_config("roberta-base")
+        models["t"] = HipBertModel(W.bert_state_dict(bc, 0), bc, device=dev, precision="f16")
+        inputs["t"] = W.synth_tokens(B, seed=1236 + rank).to(dev)
+    frames_per_clip = [8] * B
+    lengths = [64] * B
+
+    def step():
+        out = []
+        if "a" in mods:
+            out.append(models["a"].extract_utterance(inputs["a"]))
+        if "v" in mods:
+            out.append(models["v"].extract_utterance(inputs["v"], frames_per_clip))
+        if "t" in mods:
+            out.append(models["t"].extract_utterance(inputs["t"], lengths, 1, -1))
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    for o in out:
+        assert torch.isfinite(o).all(), "non-finite features"
+
+    clips = B * world * args.steps
+    gflop_clip = (GFLOP_PER_CLIP["hubert-base"] if "a" in mods else 0) + (GFLOP_PER_CLIP["clip-vit-b16-8f"] if "v" in mods else 0) + \
+                 (GFLOP_PER_CLIP["roberta-base-64"] if "t" in mods else 0)
+
+    roofline = None
+    if not args.no_roofline:
+        lib = _lib.lib()
+        lib.mer_prof_enable(1)
+        for _ in range(max(1, min(args.steps, 3))):
+            step()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.mer_prof_report(buf, len(buf))
+        lib.mer_prof_enable(0)
+        recs = {r["name"]: r for r in json.loads(buf.value.decode())}
+        tot_ms = sum(r["ms"] for r in recs.values())
+        dom = max(recs.values(), key=lambda r: r["ms"])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2), "launches": dom["calls"],
+                    "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
+                    "other_kernels": {k: {"ms_share": round(v["ms"] / tot_ms, 4),
+                                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                          "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                      for k, v in recs.items() if k != dom["name"]},
+                    "whole_step_tflops": round(gflop_clip * B * world * args.steps / dt / 1e3, 2)}
+
+    if rank == 0:
+        res = {
+            "metric": "clips/sec (A+V+T feature-extract, 5s/8-frame/64-tok)" if mods == set("avt") else f"clips/sec ({''.join(sorted(mods))} only)",
+            "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "tri-modal base extract: HuBERT-base 5s@16kHz + CLIP-ViT-B/16 8x224^2 + RoBERTa-base 64 tok "
+                                   "(BASELINE.json configs[3] extraction leg = configs[1]+[2]+text on each GPU)",
+                       "clips_per_gpu_per_step": B, "modalities": "".join(sorted(mods)), "audio_precision": args.audio_precision,
+                       "weights": "random-init (seed 0), HF architectures", "parallelism": f"clip-sharded x{world}, no collective",
+                       "gflop_per_clip": gflop_clip},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

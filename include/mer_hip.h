@@ -42,6 +42,12 @@ const char* mer_last_error(void);
 /* Hardware the library was built for ("gfx950"). */
 const char* mer_target_arch(void);
 
+/* Per-launch timing for the roofline report: while enabled, instrumented launches are bracketed
+ * by hipEvents on their own stream.  mer_prof_report synchronises the device, writes a JSON array
+ * [{"name","calls","ms","flops","bytes"}] aggregated per kernel and clears the records. */
+int mer_prof_enable(int on);
+int mer_prof_report(char* buf, int buflen);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Op level                                                                                    */
 /* ------------------------------------------------------------------------------------------ */

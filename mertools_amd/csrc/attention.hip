@@ -156,6 +156,7 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
                        int B, int Tn, int H, float scale, const int* kv_len, hipStream_t st) {
   const float sl2 = scale * 1.4426950408889634f;
   dim3 grid((unsigned)cdiv(Tn, 64), H, B), block(256);
+  ProfScope prof("attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
 #define MER_ATTN_CASE(N)                                                                                       \
   hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
                      (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len)

@@ -91,6 +91,15 @@ int check_launch(const char* what);
     }                                       \
   } while (0)
 
+// Optional per-launch timing (bench.py's roofline leg): when enabled, every instrumented launch is
+// bracketed by hipEvents on the launch stream; mer_prof_report() resolves them after a sync.
+struct ProfScope {
+  void* rec;
+  hipStream_t st;
+  ProfScope(const char* name, double flops, double bytes, hipStream_t stream);
+  ~ProfScope();
+};
+
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 }  // namespace mer

@@ -192,6 +192,7 @@ extern "C" int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* 
   hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st);
   MER_REQUIRE(e == hipSuccess, MER_ELAUNCH, "mer_hubert_conv0_gn: memset failed: %s", hipGetErrorString(e));
   dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
+  ProfScope prof("hubert_conv0_gn", 2.0 * 2 * (double)B * T0 * C * k, (double)B * L * 4 * 2 + (double)B * T0 * C * (out_lo ? 4 : 2), st);
   if (dtype == MER_DT_F16) {
     hipLaunchKernelGGL((conv0_kernel<f16, false>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
                        (f16*)nullptr, (f16*)nullptr);

@@ -269,6 +269,13 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   p.tiles_m = (int)cdiv(p.M, BM);
   p.tiles_n = (int)cdiv(p.N, BN);
   dim3 grid(p.tiles_m * p.tiles_n, nbatch, 1), block(WM * WN * 64, 1, 1);
+  // algorithmic work of this launch: 2*M*N*K flops (one pass, whatever AP/WP execute), A + W read once,
+  // outputs (+ residual) touched once
+  const double mn = (double)p.M * p.N * nbatch;
+  ProfScope prof(AP == 2 ? "gemm16_x3" : "gemm16", 2.0 * mn * p.K,
+                 2.0 * AP * nbatch * (double)p.M * p.K + 2.0 * WP * (double)p.N * p.K * (nbatch / p.nb_inner > 0 ? p.nb_inner : 1) +
+                     mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.residual ? 4 : 0)),
+                 st);
   hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP>), grid, block, 0, st, p);
   return check_launch("gemm16");
 }

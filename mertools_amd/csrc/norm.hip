@@ -202,6 +202,7 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
   MER_REQUIRE(nv != 0, MER_EUNSUPPORTED, "mer_layernorm: D=%d > 2048 unsupported", D);
   dim3 grid((unsigned)cdiv(M, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  ProfScope prof("layernorm", 0.0, (double)M * D * (4 + (out32 ? 4 : 0) + (out16_hi ? 2 : 0) + (out16_lo ? 2 : 0)), st);
   if (dtype == MER_DT_F16) {
     MER_NV_SWITCH(nv, layernorm_kernel<f16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
                                           act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16));

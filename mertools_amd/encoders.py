@@ -1,0 +1,438 @@
+"""Drop-in encoder objects for the three HuggingFace call sites of the MERTools extractors.
+
+    HipHubertModel(input_values, output_hidden_states=True).hidden_states
+        -> MERBench/feature_extraction/audio/extract_audio_huggingface.py:97
+    HipCLIPModel.get_image_features(pixel_values)
+        -> MERBench/feature_extraction/visual/extract_vision_huggingface.py:121
+    HipBertModel(input_ids=..., attention_mask=..., output_hidden_states=True).hidden_states
+        -> MERBench/feature_extraction/text/extract_text_huggingface.py:225
+
+Each object is built from a HuggingFace state_dict (the checkpoint format the reference loads with
+AutoModel.from_pretrained), converts the weights once into the layouts the HIP kernels want
+(16-bit hi/lo planes, fused QKV, im2col-ordered conv weights, folded weight-norm) and afterwards
+only passes device pointers to libmer_hip.so.  torch provides device memory and the stream; there
+is no torch compute on the forward path and no CPU fallback.
+
+precision:
+    "f16"    every GEMM one fp16 MFMA pass (fp32 accumulate)
+    "mixed"  conv stack / projection / positional conv in 3-pass split fp16 (fp32-grade), the
+             transformer blocks in one pass — default for HuBERT, whose un-normalised conv stack
+             otherwise accounts for most of the fp16 error
+    "x3"     every GEMM 3-pass
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (BertConfig, BertWeights, HubertConfig, HubertWeights, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_MAX_CONV,
+                   TfConfig, TfLayer, VitConfig, VitWeights, W16)
+from .ops import dt_code, split16_host, stream
+
+
+class EncoderOutput:
+    """Minimal stand-in for transformers' BaseModelOutput at the reference call sites."""
+
+    def __init__(self, last_hidden_state=None, hidden_states=None, pooler_output=None):
+        self.last_hidden_state = last_hidden_state
+        self.hidden_states = hidden_states
+        self.pooler_output = pooler_output
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state, self.hidden_states)[i]
+
+
+def _sd_of(model_or_sd):
+    sd = model_or_sd.state_dict() if hasattr(model_or_sd, "state_dict") else model_or_sd
+    return {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()}
+
+
+class _Holder:
+    """Owns the device copies of the weights and hands out raw pointers."""
+
+    def __init__(self, device, dtype):
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.keep = []
+
+    def f32(self, t):
+        if t is None:
+            return None
+        d = t.detach().to(torch.float32).contiguous().to(self.device)
+        self.keep.append(d)
+        return d.data_ptr()
+
+    def w16(self, t, lo):
+        hi, lo_t = split16_host(t.contiguous(), self.dtype, lo)
+        hi = hi.contiguous().to(self.device)
+        self.keep.append(hi)
+        w = W16()
+        w.hi = hi.data_ptr()
+        w.lo = None
+        if lo:
+            lo_t = lo_t.contiguous().to(self.device)
+            self.keep.append(lo_t)
+            w.lo = lo_t.data_ptr()
+        return w
+
+
+def _tf_layer(hold, lo, wq, bq, wk, bk, wv, bv, wo, bo, ln1, w1, b1, w2, b2, ln2):
+    D = wq.shape[0]
+    z = torch.zeros(D)
+    L = TfLayer()
+    L.wqkv = hold.w16(torch.cat([wq, wk, wv], 0), lo)
+    L.bqkv = hold.f32(torch.cat([bq if bq is not None else z, bk if bk is not None else z, bv if bv is not None else z], 0))
+    L.wo = hold.w16(wo, lo)
+    L.bo = hold.f32(bo)
+    L.ln1_g, L.ln1_b = hold.f32(ln1[0]), hold.f32(ln1[1])
+    L.w1 = hold.w16(w1, lo)
+    L.b1 = hold.f32(b1)
+    L.w2 = hold.w16(w2, lo)
+    L.b2 = hold.f32(b2)
+    L.ln2_g, L.ln2_b = hold.f32(ln2[0]), hold.f32(ln2[1])
+    return L
+
+
+def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes):
+    c = TfConfig()
+    c.hidden, c.heads, c.ffn, c.layers, c.pre_ln = hidden, heads, ffn, layers, int(pre_ln)
+    c.act, c.ln_eps, c.dtype, c.passes = act, eps, dt_code(dtype), passes
+    return c
+
+
+_PREC = {"f16": (1, 1), "fast": (1, 1), "mixed": (3, 1), "x3": (3, 3)}
+
+
+class _HipModule:
+    """Shared plumbing: handle lifetime, cached workspace, nn.Module-ish no-ops the scripts call."""
+
+    _destroy = None
+
+    def __init__(self):
+        self._handle = C.c_void_p()
+        self._ws = None
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    def _seg(self, seg_start, seg_len):
+        if seg_start is None:
+            return None, None, 0
+        ss = torch.as_tensor(seg_start, dtype=torch.int32).to(self.device)
+        sl = torch.as_tensor(seg_len, dtype=torch.int32).to(self.device)
+        return ss, sl, ss.numel()
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def half(self):
+        raise _lib.MerError("precision is chosen at construction (precision=...), .half() is not supported")
+
+    def __del__(self):
+        try:
+            if self._handle and self._destroy:
+                getattr(_lib.lib(), self._destroy)(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+# =================================================================================================
+class HipHubertModel(_HipModule):
+    _destroy = "mer_hubert_destroy"
+
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mixed"):
+        super().__init__()
+        sd = _sd_of(state_dict)
+        self.config = config
+        self.device = torch.device(device)
+        self.precision = precision
+        conv_passes, tf_passes = _PREC[precision]
+        hold = self._hold = _Holder(device, dtype)
+        n_conv = len(config.conv_kernel)
+        assert n_conv <= MER_MAX_CONV
+        Cc = config.conv_dim[0]
+        assert all(c == Cc for c in config.conv_dim), "conv_dim must be uniform"
+        D = config.hidden_size
+        cfg = HubertConfig()
+        cfg.tf = _tf_config(D, config.num_attention_heads, config.intermediate_size, config.num_hidden_layers,
+                            config.do_stable_layer_norm, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+        cfg.n_conv, cfg.conv_dim = n_conv, Cc
+        for i in range(n_conv):
+            cfg.conv_kernel[i], cfg.conv_stride[i] = config.conv_kernel[i], config.conv_stride[i]
+        cfg.feat_norm_group = 1 if config.feat_extract_norm == "group" else 0
+        cfg.conv_bias = int(config.conv_bias)
+        cfg.feat_proj_layer_norm = int(getattr(config, "feat_proj_layer_norm", True))
+        cfg.pos_k, cfg.pos_groups = config.num_conv_pos_embeddings, config.num_conv_pos_embedding_groups
+        cfg.stable_layer_norm = int(config.do_stable_layer_norm)
+        cfg.conv_passes = conv_passes
+        clo = conv_passes == 3
+        w = HubertWeights()
+        fe = "feature_extractor.conv_layers."
+        w.conv0_w = hold.f32(sd[fe + "0.conv.weight"].reshape(Cc, -1))
+        for i in range(n_conv):
+            if fe + f"{i}.layer_norm.weight" in sd:
+                w.conv_norm_g[i] = hold.f32(sd[fe + f"{i}.layer_norm.weight"])
+                w.conv_norm_b[i] = hold.f32(sd[fe + f"{i}.layer_norm.bias"])
+            if config.conv_bias:
+                w.conv_b[i] = hold.f32(sd[fe + f"{i}.conv.bias"])
+            if i >= 1:  # [Cout, Cin, k] -> [Cout, k*Cin] (column kk*Cin + ci == one contiguous im2col row)
+                wt = sd[fe + f"{i}.conv.weight"]
+                w.conv_w[i] = hold.w16(wt.permute(0, 2, 1).reshape(Cc, -1), clo)
+        if cfg.feat_proj_layer_norm:
+            w.fp_ln_g, w.fp_ln_b = hold.f32(sd["feature_projection.layer_norm.weight"]), hold.f32(sd["feature_projection.layer_norm.bias"])
+        w.fp_w = hold.w16(sd["feature_projection.projection.weight"], clo)
+        w.fp_b = hold.f32(sd["feature_projection.projection.bias"])
+        # positional conv: fold weight-norm (dim=2), then [D, Dg, K] -> [G, Dg, K*Dg] with column kk*Dg + ci
+        p = "encoder.pos_conv_embed.conv."
+        if p + "weight" in sd:
+            pw = sd[p + "weight"]
+        else:
+            if p + "parametrizations.weight.original0" in sd:
+                g, v = sd[p + "parametrizations.weight.original0"], sd[p + "parametrizations.weight.original1"]
+            else:
+                g, v = sd[p + "weight_g"], sd[p + "weight_v"]
+            pw = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        G, K = cfg.pos_groups, cfg.pos_k
+        Dg = D // G
+        w.pos_w = hold.w16(pw.reshape(G, Dg, Dg, K).permute(0, 1, 3, 2).reshape(G * Dg, K * Dg), clo)
+        w.pos_b = hold.f32(sd[p + "bias"])
+        w.enc_ln_g, w.enc_ln_b = hold.f32(sd["encoder.layer_norm.weight"]), hold.f32(sd["encoder.layer_norm.bias"])
+        tlo = tf_passes == 3
+        layers = (TfLayer * config.num_hidden_layers)()
+        for l in range(config.num_hidden_layers):
+            q = f"encoder.layers.{l}."
+            a = q + "attention."
+            layers[l] = _tf_layer(
+                hold, tlo, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"], sd[a + "k_proj.weight"], sd[a + "k_proj.bias"],
+                sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"],
+                (sd[q + "layer_norm.weight"], sd[q + "layer_norm.bias"]),
+                sd[q + "feed_forward.intermediate_dense.weight"], sd[q + "feed_forward.intermediate_dense.bias"],
+                sd[q + "feed_forward.output_dense.weight"], sd[q + "feed_forward.output_dense.bias"],
+                (sd[q + "final_layer_norm.weight"], sd[q + "final_layer_norm.bias"]))
+        w.layers = C.cast(layers, C.POINTER(TfLayer))
+        self._layers = layers
+        _lib.check(_lib.lib().mer_hubert_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_hubert_create")
+        self._cfg = cfg
+
+    @classmethod
+    def from_hf(cls, hf_model, **kw):
+        return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def out_frames(self, L):
+        return _lib.lib().mer_hubert_out_frames(self._handle, int(L))
+
+    def forward_raw(self, input_values, *, hidden_states=False, frames=False, seg_start=None, seg_len=None):
+        x = input_values
+        if not x.is_cuda:
+            x = x.to(self.device)
+        x = x.to(torch.float32).contiguous()
+        B, L = x.shape
+        T, D, nl = self.out_frames(L), self.config.hidden_size, self.config.num_hidden_layers
+        hs = torch.empty((nl + 1, B, T, D), dtype=torch.float32, device=self.device) if hidden_states else None
+        fr = torch.empty((B * T, D), dtype=torch.float32, device=self.device) if frames else None
+        ss, sl, nseg = self._seg(seg_start, seg_len)
+        pooled = torch.empty((nseg, D), dtype=torch.float32, device=self.device) if nseg else None
+        nbytes = _lib.lib().mer_hubert_workspace_bytes(self._handle, B, L, int(hidden_states))
+        wp, wn = self._workspace(nbytes)
+        _lib.check(_lib.lib().mer_hubert_forward(
+            self._handle, x.data_ptr(), B, L, wp, wn, hs.data_ptr() if hs is not None else None,
+            fr.data_ptr() if fr is not None else None, ss.data_ptr() if nseg else None, sl.data_ptr() if nseg else None, nseg,
+            pooled.data_ptr() if nseg else None, stream()), "mer_hubert_forward")
+        return hs, fr, pooled
+
+    def __call__(self, input_values, attention_mask=None, output_hidden_states=False, **_):
+        if attention_mask is not None:
+            raise _lib.MerError("the reference passes no attention_mask for audio (extract_audio_huggingface.py:97)")
+        hs, _, _ = self.forward_raw(input_values, hidden_states=True)
+        return EncoderOutput(last_hidden_state=hs[-1], hidden_states=tuple(hs[i] for i in range(hs.shape[0])) if output_hidden_states else None)
+
+    def extract_utterance(self, input_values, clip_chunks=None):
+        """Fused path: last-4 sum + mean over all frames of each clip -> [nclip, D].
+        clip_chunks[i] = number of consecutive batch rows belonging to clip i (default 1 each)."""
+        B, L = input_values.shape
+        T = self.out_frames(L)
+        clip_chunks = clip_chunks or [1] * B
+        starts, lens, r = [], [], 0
+        for n in clip_chunks:
+            starts.append(r * T)
+            lens.append(n * T)
+            r += n
+        _, _, pooled = self.forward_raw(input_values, seg_start=starts, seg_len=lens)
+        return pooled
+
+
+# =================================================================================================
+class HipCLIPModel(_HipModule):
+    _destroy = "mer_vit_destroy"
+
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="f16"):
+        super().__init__()
+        sd = _sd_of(state_dict)
+        self.config = config
+        vc = config.vision_config
+        self.device = torch.device(device)
+        _, tf_passes = _PREC[precision]
+        if precision == "mixed":
+            tf_passes = 1
+        lo = tf_passes == 3
+        hold = self._hold = _Holder(device, dtype)
+        act = MER_ACT_QUICK_GELU if vc.hidden_act == "quick_gelu" else MER_ACT_GELU
+        cfg = VitConfig()
+        cfg.tf = _tf_config(vc.hidden_size, vc.num_attention_heads, vc.intermediate_size, vc.num_hidden_layers, True, act,
+                            vc.layer_norm_eps, dtype, tf_passes)
+        cfg.image_size, cfg.patch_size, cfg.channels, cfg.proj_dim = vc.image_size, vc.patch_size, vc.num_channels, config.projection_dim
+        v = "vision_model."
+        w = VitWeights()
+        w.patch_w = hold.w16(sd[v + "embeddings.patch_embedding.weight"].reshape(vc.hidden_size, -1), lo)
+        w.cls = hold.f32(sd[v + "embeddings.class_embedding"])
+        w.pos = hold.f32(sd[v + "embeddings.position_embedding.weight"])
+        w.pre_ln_g, w.pre_ln_b = hold.f32(sd[v + "pre_layrnorm.weight"]), hold.f32(sd[v + "pre_layrnorm.bias"])
+        w.post_ln_g, w.post_ln_b = hold.f32(sd[v + "post_layernorm.weight"]), hold.f32(sd[v + "post_layernorm.bias"])
+        w.proj_w = hold.w16(sd["visual_projection.weight"], lo)
+        layers = (TfLayer * vc.num_hidden_layers)()
+        for l in range(vc.num_hidden_layers):
+            q = f"{v}encoder.layers.{l}."
+            a = q + "self_attn."
+            layers[l] = _tf_layer(
+                hold, lo, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"], sd[a + "k_proj.weight"], sd[a + "k_proj.bias"],
+                sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"],
+                (sd[q + "layer_norm1.weight"], sd[q + "layer_norm1.bias"]), sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"],
+                sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"], (sd[q + "layer_norm2.weight"], sd[q + "layer_norm2.bias"]))
+        w.layers = C.cast(layers, C.POINTER(TfLayer))
+        self._layers = layers
+        _lib.check(_lib.lib().mer_vit_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_vit_create")
+        self._cfg = cfg
+
+    @classmethod
+    def from_hf(cls, hf_model, **kw):
+        return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def forward_raw(self, pixel_values, *, features=True, seg_start=None, seg_len=None):
+        x = pixel_values
+        if not x.is_cuda:
+            x = x.to(self.device)
+        x = x.to(torch.float32).contiguous()
+        N = x.shape[0]
+        P = self.config.projection_dim
+        assert x.shape[1:] == (self._cfg.channels, self._cfg.image_size, self._cfg.image_size), x.shape
+        feats = torch.empty((N, P), dtype=torch.float32, device=self.device) if features else None
+        ss, sl, nseg = self._seg(seg_start, seg_len)
+        pooled = torch.empty((nseg, P), dtype=torch.float32, device=self.device) if nseg else None
+        wp, wn = self._workspace(_lib.lib().mer_vit_workspace_bytes(self._handle, N))
+        _lib.check(_lib.lib().mer_vit_forward(
+            self._handle, x.data_ptr(), N, wp, wn, feats.data_ptr() if features else None,
+            ss.data_ptr() if nseg else None, sl.data_ptr() if nseg else None, nseg, pooled.data_ptr() if nseg else None,
+            stream()), "mer_vit_forward")
+        return feats, pooled
+
+    def get_image_features(self, pixel_values=None, **_):
+        """transformers-4.28 semantics: returns the projected embeddings tensor [N, projection_dim]."""
+        return self.forward_raw(pixel_values)[0]
+
+    def extract_utterance(self, pixel_values, frames_per_clip):
+        """Fused path: per-frame features + mean over each clip's frames -> [nclip, projection_dim]."""
+        starts, lens, r = [], [], 0
+        for n in frames_per_clip:
+            starts.append(r)
+            lens.append(n)
+            r += n
+        return self.forward_raw(pixel_values, features=False, seg_start=starts, seg_len=lens)[1]
+
+
+# =================================================================================================
+class HipBertModel(_HipModule):
+    """BERT / RoBERTa family (post-LN encoder-only text models)."""
+    _destroy = "mer_bert_destroy"
+
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="f16"):
+        super().__init__()
+        sd = _sd_of(state_dict)
+        self.config = config
+        self.device = torch.device(device)
+        _, tf_passes = _PREC[precision]
+        lo = tf_passes == 3
+        hold = self._hold = _Holder(device, dtype)
+        if config.hidden_act != "gelu":
+            raise _lib.MerError(f"hidden_act={config.hidden_act} unsupported")
+        roberta = config.model_type in ("roberta", "xlm-roberta")
+        cfg = BertConfig()
+        cfg.tf = _tf_config(config.hidden_size, config.num_attention_heads, config.intermediate_size, config.num_hidden_layers,
+                            False, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+        cfg.vocab, cfg.max_pos, cfg.type_vocab = config.vocab_size, config.max_position_embeddings, config.type_vocab_size
+        cfg.pad_id = config.pad_token_id if config.pad_token_id is not None else 0
+        cfg.pos_mode = 1 if roberta else 0
+        cfg.emb_ln_eps = config.layer_norm_eps
+        w = BertWeights()
+        w.word = hold.f32(sd["embeddings.word_embeddings.weight"])
+        w.pos = hold.f32(sd["embeddings.position_embeddings.weight"])
+        w.type = hold.f32(sd["embeddings.token_type_embeddings.weight"])
+        w.emb_ln_g, w.emb_ln_b = hold.f32(sd["embeddings.LayerNorm.weight"]), hold.f32(sd["embeddings.LayerNorm.bias"])
+        layers = (TfLayer * config.num_hidden_layers)()
+        for l in range(config.num_hidden_layers):
+            q = f"encoder.layer.{l}."
+            a = q + "attention.self."
+            layers[l] = _tf_layer(
+                hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"],
+                sd[a + "value.weight"], sd[a + "value.bias"], sd[q + "attention.output.dense.weight"],
+                sd[q + "attention.output.dense.bias"],
+                (sd[q + "attention.output.LayerNorm.weight"], sd[q + "attention.output.LayerNorm.bias"]),
+                sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"],
+                sd[q + "output.dense.bias"], (sd[q + "output.LayerNorm.weight"], sd[q + "output.LayerNorm.bias"]))
+        w.layers = C.cast(layers, C.POINTER(TfLayer))
+        self._layers = layers
+        _lib.check(_lib.lib().mer_bert_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_bert_create")
+        self._cfg = cfg
+
+    @classmethod
+    def from_hf(cls, hf_model, **kw):
+        return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def forward_raw(self, input_ids, *, lengths=None, token_type_ids=None, hidden_states=False, frames=False, seg_start=None,
+                    seg_len=None):
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        B, T = ids.shape
+        D, nl = self.config.hidden_size, self.config.num_hidden_layers
+        tt = token_type_ids.to(self.device, torch.int64).contiguous() if token_type_ids is not None else None
+        ln = torch.as_tensor(lengths, dtype=torch.int32).to(self.device) if lengths is not None else None
+        hs = torch.empty((nl + 1, B, T, D), dtype=torch.float32, device=self.device) if hidden_states else None
+        fr = torch.empty((B * T, D), dtype=torch.float32, device=self.device) if frames else None
+        ss, sl, nseg = self._seg(seg_start, seg_len)
+        pooled = torch.empty((nseg, D), dtype=torch.float32, device=self.device) if nseg else None
+        wp, wn = self._workspace(_lib.lib().mer_bert_workspace_bytes(self._handle, B, T, int(hidden_states)))
+        _lib.check(_lib.lib().mer_bert_forward(
+            self._handle, ids.data_ptr(), tt.data_ptr() if tt is not None else None, ln.data_ptr() if ln is not None else None,
+            B, T, wp, wn, hs.data_ptr() if hs is not None else None, fr.data_ptr() if fr is not None else None,
+            ss.data_ptr() if nseg else None, sl.data_ptr() if nseg else None, nseg, pooled.data_ptr() if nseg else None,
+            stream()), "mer_bert_forward")
+        return hs, fr, pooled
+
+    def __call__(self, input_ids=None, attention_mask=None, token_type_ids=None, output_hidden_states=False, **_):
+        lengths = None
+        if attention_mask is not None:
+            m = attention_mask.to("cpu")
+            lengths = m.sum(dim=1).to(torch.int32)
+            T = m.shape[1]
+            if not bool((m == (torch.arange(T)[None] < lengths[:, None]).to(m.dtype)).all()):
+                raise _lib.MerError("attention_mask must be a right-padded prefix mask")
+        hs, _, _ = self.forward_raw(input_ids, lengths=lengths, token_type_ids=token_type_ids, hidden_states=True)
+        return EncoderOutput(last_hidden_state=hs[-1], hidden_states=tuple(hs[i] for i in range(hs.shape[0])) if output_hidden_states else None)
+
+    def extract_utterance(self, input_ids, lengths, start, end):
+        """Fused path: last-4 sum, drop `start` leading / `-end` trailing special tokens
+        (extract_text_huggingface.py:228-231), mean over the rest -> [B, D]."""
+        B, T = input_ids.shape
+        lengths = [int(x) for x in lengths]
+        starts = [b * T + start for b in range(B)]
+        lens = [max(0, (lengths[b] + (end if end is not None else 0)) - start) for b in range(B)]
+        return self.forward_raw(input_ids, lengths=lengths, seg_start=starts, seg_len=lens)[2]

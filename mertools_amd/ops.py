@@ -1,0 +1,182 @@
+"""Torch-tensor front ends for the op-level C ABI (include/mer_hip.h).
+
+torch is used for device memory and the current stream only; every computation below is one
+HIP kernel of libmer_hip.so.  These wrappers exist for the parity tests and for composing the
+encoders; they validate devices/dtypes and otherwise pass raw pointers through.
+"""
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, MER_DT_F16, MER_DT_BF16, MER_ACT_NONE, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_ACT_RELU  # noqa: F401
+
+ACT = {None: MER_ACT_NONE, "none": MER_ACT_NONE, "gelu": MER_ACT_GELU, "quick_gelu": MER_ACT_QUICK_GELU, "relu": MER_ACT_RELU}
+_TORCH16 = {MER_DT_F16: torch.float16, MER_DT_BF16: torch.bfloat16}
+_DT = {"f16": MER_DT_F16, "bf16": MER_DT_BF16, MER_DT_F16: MER_DT_F16, MER_DT_BF16: MER_DT_BF16,
+       torch.float16: MER_DT_F16, torch.bfloat16: MER_DT_BF16}
+
+
+def dt_code(dtype):
+    return _DT[dtype]
+
+
+def torch16(dtype):
+    return _TORCH16[dt_code(dtype)]
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MerError("mertools_amd ops need CUDA/HIP device tensors (there is no CPU path)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def split16(x, dtype="f16", lo=True):
+    """fp32 tensor -> (hi, lo) 16-bit planes computed on the GPU."""
+    x = x.contiguous()
+    t16 = torch16(dtype)
+    hi = torch.empty(x.shape, dtype=t16, device=x.device)
+    lo_t = torch.empty(x.shape, dtype=t16, device=x.device) if lo else None
+    _lib.check(_lib.lib().mer_split16(_p(x), _p(hi), _p(lo_t), x.numel(), dt_code(dtype), stream()), "mer_split16")
+    return hi, lo_t
+
+
+def split16_host(x, dtype="f16", lo=True):
+    """Same split on a CPU tensor (weight preparation at load time)."""
+    t16 = torch16(dtype)
+    x = x.detach().to(torch.float32)
+    hi = x.to(t16)
+    lo_t = (x - hi.to(torch.float32)).to(t16) if lo else None
+    return hi, lo_t
+
+
+def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
+           out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0):
+    """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
+    dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
+    N, K = w_hi.shape
+    if M is None:
+        M = a_hi.shape[0]
+    g = GemmArgs()
+    g.M, g.N, g.K, g.dtype = M, N, K, dtype
+    g.a_hi, g.a_lo = _p(a_hi), _p(a_lo)
+    g.lda = lda if lda is not None else a_hi.stride(0)
+    g.a_rows_per_batch, g.a_batch_stride = a_rows_per_batch, a_batch_stride
+    g.w_hi, g.w_lo, g.ldw = _p(w_hi), _p(w_lo), w_hi.stride(0)
+    g.bias, g.act = _p(bias), ACT[act]
+    g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
+    dev = a_hi.device
+    c32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out32 else None
+    c16h = torch.empty((M, N), dtype=torch16(dtype), device=dev) if out16 else None
+    c16l = torch.empty((M, N), dtype=torch16(dtype), device=dev) if (out16 and out16_lo) else None
+    g.c32, g.ldc32 = _p(c32), N
+    g.c16_hi, g.c16_lo, g.ldc16 = _p(c16h), _p(c16l), N
+    g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, passes, tile
+    _lib.check(_lib.lib().mer_gemm16(g, stream()), "mer_gemm16")
+    return c32, c16h, c16l
+
+
+def gemm16_raw(args: GemmArgs):
+    _lib.check(_lib.lib().mer_gemm16(args, stream()), "mer_gemm16")
+
+
+def layernorm(x, gamma, beta, eps, *, act=None, out32=True, out16=False, out16_lo=False, dtype="f16", M=None, D=None, ldx=None):
+    D = D if D is not None else x.shape[-1]
+    M = M if M is not None else x.numel() // D
+    ldx = ldx if ldx is not None else D
+    dev = x.device
+    o32 = torch.empty((M, D), dtype=torch.float32, device=dev) if out32 else None
+    oh = torch.empty((M, D), dtype=torch16(dtype), device=dev) if out16 else None
+    ol = torch.empty((M, D), dtype=torch16(dtype), device=dev) if (out16 and out16_lo) else None
+    _lib.check(_lib.lib().mer_layernorm(_p(x), ldx, _p(gamma), _p(beta), eps, M, D, ACT[act], _p(o32), D, _p(oh), _p(ol), D,
+                                        dt_code(dtype), stream()), "mer_layernorm")
+    return o32, oh, ol
+
+
+def attention(qkv, B, T, H, scale, *, kv_len=None, out_lo=False):
+    """qkv: 16-bit [B*T, 3*H*64] (q | k | v column blocks) -> ctx 16-bit [B*T, H*64]."""
+    D = H * 64
+    assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous()
+    oh = torch.empty((B * T, D), dtype=qkv.dtype, device=qkv.device)
+    ol = torch.empty_like(oh) if out_lo else None
+    es = qkv.element_size()
+    _lib.check(_lib.lib().mer_attention(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, 3 * D,
+                                        _p(oh), _p(ol), D, B, T, H, float(scale), _p(kv_len), dt_code(qkv.dtype), stream()),
+               "mer_attention")
+    return oh, ol
+
+
+def hubert_conv0_gn(wav, w, gamma, beta, eps=1e-5, *, stride=5, dtype="f16", lo=False):
+    B, L = wav.shape
+    Cc, k = w.shape
+    T0 = (L - k) // stride + 1
+    stats = torch.empty((B, Cc, 2), dtype=torch.float64, device=wav.device)
+    oh = torch.empty((B, T0, Cc), dtype=torch16(dtype), device=wav.device)
+    ol = torch.empty_like(oh) if lo else None
+    _lib.check(_lib.lib().mer_hubert_conv0_gn(_p(wav), B, L, _p(w), Cc, k, stride, _p(gamma), _p(beta), eps, _p(stats),
+                                              _p(oh), _p(ol), dt_code(dtype), stream()), "mer_hubert_conv0_gn")
+    return oh, ol
+
+
+def posconv_pack(x, G, K, *, dtype="f16", lo=False):
+    B, T, D = x.shape
+    oh = torch.empty((B, G, T + K, D // G), dtype=torch16(dtype), device=x.device)
+    ol = torch.empty_like(oh) if lo else None
+    _lib.check(_lib.lib().mer_posconv_pack(_p(x), B, T, D, G, K, _p(oh), _p(ol), dt_code(dtype), stream()), "mer_posconv_pack")
+    return oh, ol
+
+
+def vit_patchify(px, P, *, dtype="f16", lo=False):
+    N, Cc, H, W = px.shape
+    oh = torch.empty((N * (H // P) * (W // P), Cc * P * P), dtype=torch16(dtype), device=px.device)
+    ol = torch.empty_like(oh) if lo else None
+    _lib.check(_lib.lib().mer_vit_patchify(_p(px), N, Cc, H, W, P, _p(oh), _p(ol), dt_code(dtype), stream()), "mer_vit_patchify")
+    return oh, ol
+
+
+def vit_assemble(patch, cls, pos, gamma, beta, eps, N, P, D):
+    out = torch.empty((N * (P + 1), D), dtype=torch.float32, device=patch.device)
+    _lib.check(_lib.lib().mer_vit_assemble(_p(patch), _p(cls), _p(pos), _p(gamma), _p(beta), eps, N, P, D, _p(out), None, None,
+                                           MER_DT_F16, stream()), "mer_vit_assemble")
+    return out
+
+
+def bert_embed(ids, token_type, word, pos, type_emb, pos_mode, pad_id, gamma, beta, eps, *, dtype="f16"):
+    B, T = ids.shape
+    D = word.shape[1]
+    o32 = torch.empty((B * T, D), dtype=torch.float32, device=ids.device)
+    oh = torch.empty((B * T, D), dtype=torch16(dtype), device=ids.device)
+    _lib.check(_lib.lib().mer_bert_embed(_p(ids), _p(token_type), B, T, D, _p(word), _p(pos), _p(type_emb), pos_mode, pad_id,
+                                         _p(gamma), _p(beta), eps, _p(o32), _p(oh), None, dt_code(dtype), stream()),
+               "mer_bert_embed")
+    return o32, oh
+
+
+def sum_pool(hs, seg_start=None, seg_len=None, *, frames=False):
+    """hs: list of 1..4 fp32 [M,D] tensors. Returns (frames [M,D] or None, pooled [nseg,D] or None)."""
+    M, D = hs[0].shape
+    h = list(hs) + [None] * (4 - len(hs))
+    fr = torch.empty((M, D), dtype=torch.float32, device=hs[0].device) if frames else None
+    pooled = None
+    nseg = 0
+    if seg_start is not None:
+        nseg = seg_start.numel()
+        pooled = torch.empty((nseg, D), dtype=torch.float32, device=hs[0].device)
+    _lib.check(_lib.lib().mer_sum_pool(_p(h[0]), _p(h[1]), _p(h[2]), _p(h[3]), M, D, _p(fr), _p(seg_start), _p(seg_len), nseg,
+                                       _p(pooled), stream()), "mer_sum_pool")
+    return fr, pooled
+
+
+def gemm32(a, w, bias=None, act=None, *, trans_a=False, trans_w=False, out=None, accumulate=False):
+    """Exact-fp32 C = act(A @ W^T + bias).  a: [M,K] (or [K,M] if trans_a); w: [N,K] (or [K,N] if trans_w)."""
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N = w.shape[1] if trans_w else w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().mer_gemm32(_p(a), a.stride(0), int(trans_a), _p(w), w.stride(0), int(trans_w), _p(bias), ACT[act],
+                                     _p(out), out.stride(0), int(accumulate), M, N, K, stream()), "mer_gemm32")
+    return out

@@ -1,0 +1,156 @@
+"""Synthetic checkpoints (HF state_dict key names) and the seeded synthetic inputs of SURVEY.md §8(d).
+
+Used by bench.py, the parity tests and smoke().  There is no network and no pretrained weight on
+disk, so throughput and parity are measured on random weights of the exact
+architectures.  Unlike the HF default init
+(all biases 0, LayerNorm gamma 1 / beta 0) every bias and affine parameter here is non-trivial, so
+a kernel that drops a bias or swaps gamma/beta cannot pass.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _lin(g, out_f, in_f, std=None):
+    std = std if std is not None else 1.0 / math.sqrt(in_f)
+    return torch.randn(out_f, in_f, generator=g) * std, torch.randn(out_f, generator=g) * 0.05
+
+
+def _ln(g, d):
+    return 1.0 + 0.1 * torch.randn(d, generator=g), 0.05 * torch.randn(d, generator=g)
+
+
+def hubert_config(size="base", **over):
+    base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                conv_dim=(512,) * 7, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2),
+                feat_extract_norm="group", conv_bias=False, feat_proj_layer_norm=True, num_conv_pos_embeddings=128,
+                num_conv_pos_embedding_groups=16, do_stable_layer_norm=False, layer_norm_eps=1e-5, model_type="hubert")
+    if size == "tiny":
+        base.update(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
+                    num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    base.update(over)
+    return SimpleNamespace(**base)
+
+
+def hubert_state_dict(cfg, seed=0):
+    g = _g(seed)
+    sd = {}
+    C = cfg.conv_dim[0]
+    for i, k in enumerate(cfg.conv_kernel):
+        cin = 1 if i == 0 else C
+        sd[f"feature_extractor.conv_layers.{i}.conv.weight"] = torch.randn(C, cin, k, generator=g) * math.sqrt(2.0 / (cin * k))
+        if cfg.conv_bias:
+            sd[f"feature_extractor.conv_layers.{i}.conv.bias"] = torch.randn(C, generator=g) * 0.05
+        if (cfg.feat_extract_norm == "group" and i == 0) or cfg.feat_extract_norm == "layer":
+            w, b = _ln(g, C)
+            sd[f"feature_extractor.conv_layers.{i}.layer_norm.weight"], sd[f"feature_extractor.conv_layers.{i}.layer_norm.bias"] = w, b
+    D = cfg.hidden_size
+    if cfg.feat_proj_layer_norm:
+        sd["feature_projection.layer_norm.weight"], sd["feature_projection.layer_norm.bias"] = _ln(g, C)
+    sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"] = _lin(g, D, C)
+    K, G = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = torch.randn(D, D // G, K, generator=g) * math.sqrt(1.0 / (K * D // G))
+    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = 0.5 + torch.rand(1, 1, K, generator=g)
+    sd["encoder.pos_conv_embed.conv.bias"] = torch.randn(D, generator=g) * 0.05
+    sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"] = _ln(g, D)
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"attention.{n}.weight"], sd[p + f"attention.{n}.bias"] = _lin(g, D, D)
+        sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"] = _ln(g, D)
+        sd[p + "feed_forward.intermediate_dense.weight"], sd[p + "feed_forward.intermediate_dense.bias"] = _lin(g, cfg.intermediate_size, D)
+        sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"] = _lin(g, D, cfg.intermediate_size)
+        sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = _ln(g, D)
+    return sd
+
+
+def clip_config(size="base16", **over):
+    v = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, patch_size=16,
+             image_size=224, num_channels=3, layer_norm_eps=1e-5, hidden_act="quick_gelu")
+    proj = 512
+    if size == "tiny":
+        v.update(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=64)
+        proj = 64
+    v.update({k: val for k, val in over.items() if k != "projection_dim"})
+    return SimpleNamespace(vision_config=SimpleNamespace(**v), projection_dim=over.get("projection_dim", proj), model_type="clip")
+
+
+def clip_state_dict(cfg, seed=0):
+    g = _g(seed)
+    vc = cfg.vision_config
+    D, P = vc.hidden_size, vc.patch_size
+    n = (vc.image_size // P) ** 2
+    v = "vision_model."
+    sd = {v + "embeddings.class_embedding": torch.randn(D, generator=g) * 0.5,
+          v + "embeddings.patch_embedding.weight": torch.randn(D, vc.num_channels, P, P, generator=g) * math.sqrt(1.0 / (vc.num_channels * P * P)),
+          v + "embeddings.position_embedding.weight": torch.randn(n + 1, D, generator=g) * 0.3}
+    sd[v + "pre_layrnorm.weight"], sd[v + "pre_layrnorm.bias"] = _ln(g, D)
+    sd[v + "post_layernorm.weight"], sd[v + "post_layernorm.bias"] = _ln(g, D)
+    sd["visual_projection.weight"] = torch.randn(cfg.projection_dim, D, generator=g) / math.sqrt(D)
+    for l in range(vc.num_hidden_layers):
+        p = f"{v}encoder.layers.{l}."
+        for nme in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{nme}.weight"], sd[p + f"self_attn.{nme}.bias"] = _lin(g, D, D)
+        sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"] = _ln(g, D)
+        sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"] = _ln(g, D)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = _lin(g, vc.intermediate_size, D)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = _lin(g, D, vc.intermediate_size, std=0.5 / math.sqrt(vc.intermediate_size))
+    return sd
+
+
+def bert_config(size="roberta-base", **over):
+    base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=50265,
+                max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5, hidden_act="gelu",
+                model_type="roberta")
+    if size == "bert-base":
+        base.update(vocab_size=21128, max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
+                    model_type="bert")
+    if size == "tiny":
+        base.update(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=300,
+                    max_position_embeddings=70)
+    base.update(over)
+    return SimpleNamespace(**base)
+
+
+def bert_state_dict(cfg, seed=0):
+    g = _g(seed)
+    D = cfg.hidden_size
+    sd = {"embeddings.word_embeddings.weight": torch.randn(cfg.vocab_size, D, generator=g) * 0.5,
+          "embeddings.position_embeddings.weight": torch.randn(cfg.max_position_embeddings, D, generator=g) * 0.3,
+          "embeddings.token_type_embeddings.weight": torch.randn(cfg.type_vocab_size, D, generator=g) * 0.3}
+    sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"] = _ln(g, D)
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        for nme in ("query", "key", "value"):
+            sd[p + f"attention.self.{nme}.weight"], sd[p + f"attention.self.{nme}.bias"] = _lin(g, D, D)
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = _lin(g, D, D)
+        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"] = _ln(g, D)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = _lin(g, cfg.intermediate_size, D)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = _lin(g, D, cfg.intermediate_size)
+        sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"] = _ln(g, D)
+    return sd
+
+
+# ---- the seeded synthetic inputs of SURVEY.md §8(d) ----
+def synth_audio(B, L=80000, seed=1234):
+    wav = 0.1 * torch.randn(B, L, generator=_g(seed))
+    return (wav - wav.mean(1, keepdim=True)) / torch.sqrt(wav.var(1, unbiased=False, keepdim=True) + 1e-7)
+
+
+def synth_frames(N, S=224, seed=1235):
+    px = torch.randint(0, 256, (N, S, S, 3), generator=_g(seed), dtype=torch.uint8).float() / 255.0
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073])
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711])
+    return ((px - mean) / std).permute(0, 3, 1, 2).contiguous()
+
+
+def synth_tokens(B, T=64, vocab=50000, seed=1236, bos=0, eos=2):
+    ids = torch.randint(3, vocab, (B, T), generator=_g(seed))
+    ids[:, 0] = bos
+    ids[:, -1] = eos
+    return ids

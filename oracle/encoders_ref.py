@@ -1,0 +1,212 @@
+"""CPU fp32 restatement of the three encoder forwards on the MERTools feature-extraction path.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker; the product (mertools_amd) never imports this package.
+
+Where the arithmetic lives: the reference calls HuggingFace `transformers` (pinned 4.28.0,
+MERBench/environment.yml:44; un-vendored) at
+  * MERBench/feature_extraction/audio/extract_audio_huggingface.py:63,97   (HubertModel / Wav2Vec2Model)
+  * MERBench/feature_extraction/visual/extract_vision_huggingface.py:85,121 (CLIPModel.get_image_features)
+  * MERBench/feature_extraction/text/extract_text_huggingface.py:189,225   (RobertaModel / BertModel)
+This file restates the published forward of those classes from a plain state_dict (HF key names)
+with torch CPU ops only; `HF:` citations point into transformers/models/ of the installed
+5.15.0 package, which tests/test_oracle_pin.py runs side by side with this file (same weights,
+same inputs) to pin the restatement.  Parity status: pinned against the live HF classes and the
+committed golden vectors (tests/golden/); the reference itself ships no golden vectors for this
+path.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _ln(x, sd, prefix, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def _gelu(x):
+    return F.gelu(x)  # exact erf form (HF ACT2FN["gelu"])
+
+
+def _quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)  # HF QuickGELUActivation
+
+
+def _mhsa(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, key_mask=None):
+    """softmax((x Wq^T + bq)(x Wk^T + bk)^T / sqrt(d)) (x Wv^T + bv) Wo^T + bo  — HF eager_attention_forward
+    (HF:hubert/modeling_hubert.py:236-259; same in clip/roberta).  key_mask: bool [B,T], True = keep."""
+    B, T, D = x.shape
+    d = D // heads
+    q = F.linear(x, wq, bq).view(B, T, heads, d).transpose(1, 2)
+    k = F.linear(x, wk, bk).view(B, T, heads, d).transpose(1, 2)
+    v = F.linear(x, wv, bv).view(B, T, heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(2, 3)) * (d ** -0.5)
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, v).transpose(1, 2).reshape(B, T, D)
+    return F.linear(o, wo, bo)
+
+
+# ------------------------------------------------------------------------------------------------
+# HuBERT / wav2vec2  (HF:hubert/modeling_hubert.py)
+# ------------------------------------------------------------------------------------------------
+def pos_conv_weight(sd):
+    """Fold the weight-norm parametrisation of encoder.pos_conv_embed.conv (dim=2)
+    (HF:hubert/modeling_hubert.py:56-80): w = g * v / ||v||_{dims 0,1}."""
+    p = "encoder.pos_conv_embed.conv."
+    if p + "weight" in sd:
+        return sd[p + "weight"]
+    if p + "parametrizations.weight.original0" in sd:
+        g, v = sd[p + "parametrizations.weight.original0"], sd[p + "parametrizations.weight.original1"]
+    else:
+        g, v = sd[p + "weight_g"], sd[p + "weight_v"]
+    norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return v * (g / norm)
+
+
+def hubert_hidden_states(sd, cfg, wav):
+    """`model(input_values, output_hidden_states=True).hidden_states`
+    (extract_audio_huggingface.py:97).  wav: [B, L] fp32.  Returns list of layers+1 tensors [B,T,D]."""
+    eps = cfg.get("layer_norm_eps", 1e-5)
+    n_conv = len(cfg["conv_kernel"])
+    x = wav[:, None, :]
+    # feature encoder: HF:...:106-213
+    for i in range(n_conv):
+        p = f"feature_extractor.conv_layers.{i}."
+        x = F.conv1d(x, sd[p + "conv.weight"], sd.get(p + "conv.bias"), stride=cfg["conv_stride"][i])
+        if cfg["feat_extract_norm"] == "group" and i == 0:
+            x = F.group_norm(x, x.shape[1], sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], 1e-5)
+        elif cfg["feat_extract_norm"] == "layer":
+            x = F.layer_norm(x.transpose(1, 2), (x.shape[1],), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], 1e-5).transpose(1, 2)
+        x = _gelu(x)
+    x = x.transpose(1, 2)  # [B,T,C]
+    # feature projection: HF:...:216-231
+    if cfg.get("feat_proj_layer_norm", True):
+        x = _ln(x, sd, "feature_projection.layer_norm", eps)
+    x = F.linear(x, sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"])
+    # positional conv embedding: HF:...:45-103
+    K = cfg["num_conv_pos_embeddings"]
+    pc = F.conv1d(x.transpose(1, 2), pos_conv_weight(sd), sd["encoder.pos_conv_embed.conv.bias"], padding=K // 2,
+                  groups=cfg["num_conv_pos_embedding_groups"])
+    if K % 2 == 0:
+        pc = pc[:, :, :-1]
+    x = x + _gelu(pc).transpose(1, 2)
+    stable = cfg.get("do_stable_layer_norm", False)
+    if not stable:
+        x = _ln(x, sd, "encoder.layer_norm", eps)  # HF:...:439-441
+    hs = []
+    H = cfg["num_attention_heads"]
+    for l in range(cfg["num_hidden_layers"]):
+        hs.append(x)
+        p = f"encoder.layers.{l}."
+        a = p + "attention."
+
+        def attn(inp):
+            return _mhsa(inp, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"], sd[a + "k_proj.weight"], sd[a + "k_proj.bias"],
+                         sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], H)
+
+        def ffn(inp):
+            h1 = _gelu(F.linear(inp, sd[p + "feed_forward.intermediate_dense.weight"], sd[p + "feed_forward.intermediate_dense.bias"]))
+            return F.linear(h1, sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"])
+
+        if stable:  # HF:...:504-547 (pre-LN)
+            x = x + attn(_ln(x, sd, p + "layer_norm", eps))
+            x = x + ffn(_ln(x, sd, p + "final_layer_norm", eps))
+        else:       # HF:...:371-404 (post-LN)
+            x = _ln(x + attn(x), sd, p + "layer_norm", eps)
+            x = _ln(x + ffn(x), sd, p + "final_layer_norm", eps)
+    if stable:
+        x = _ln(x, sd, "encoder.layer_norm", eps)  # HF:...:612
+    hs.append(x)
+    return hs
+
+
+def hubert_cfg_from_hf(c):
+    return dict(conv_kernel=list(c.conv_kernel), conv_stride=list(c.conv_stride), conv_dim=list(c.conv_dim),
+                feat_extract_norm=c.feat_extract_norm, feat_proj_layer_norm=getattr(c, "feat_proj_layer_norm", True),
+                num_conv_pos_embeddings=c.num_conv_pos_embeddings, num_conv_pos_embedding_groups=c.num_conv_pos_embedding_groups,
+                do_stable_layer_norm=c.do_stable_layer_norm, num_attention_heads=c.num_attention_heads,
+                num_hidden_layers=c.num_hidden_layers, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                layer_norm_eps=c.layer_norm_eps, conv_bias=c.conv_bias)
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP vision tower + projection  (HF:clip/modeling_clip.py)
+# ------------------------------------------------------------------------------------------------
+def clip_image_features(sd, cfg, pixel_values):
+    """`model.get_image_features(pixel_values)` with transformers-4.28 semantics (a tensor)
+    (extract_vision_huggingface.py:121).  pixel_values [N,3,S,S] -> [N, projection_dim]."""
+    eps = cfg.get("layer_norm_eps", 1e-5)
+    v = "vision_model."
+    P = cfg["patch_size"]
+    x = F.conv2d(pixel_values, sd[v + "embeddings.patch_embedding.weight"], None, stride=P)  # HF:...:138-217
+    N, D = x.shape[0], x.shape[1]
+    x = x.flatten(2).transpose(1, 2)
+    cls = sd[v + "embeddings.class_embedding"].expand(N, 1, D)
+    x = torch.cat([cls, x], dim=1) + sd[v + "embeddings.position_embedding.weight"][None]
+    x = _ln(x, sd, v + "pre_layrnorm", eps)
+    H = cfg["num_attention_heads"]
+    act = _quick_gelu if cfg.get("hidden_act", "quick_gelu") == "quick_gelu" else _gelu
+    for l in range(cfg["num_hidden_layers"]):  # HF:...:353-384 (pre-LN)
+        p = f"{v}encoder.layers.{l}."
+        a = p + "self_attn."
+        h = _ln(x, sd, p + "layer_norm1", eps)
+        x = x + _mhsa(h, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"], sd[a + "k_proj.weight"], sd[a + "k_proj.bias"],
+                      sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], H)
+        h = _ln(x, sd, p + "layer_norm2", eps)
+        h = act(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+        x = x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    pooled = _ln(x[:, 0], sd, v + "post_layernorm", eps)  # HF:...:719-748
+    return F.linear(pooled, sd["visual_projection.weight"])
+
+
+def clip_cfg_from_hf(c):
+    vc = c.vision_config
+    return dict(patch_size=vc.patch_size, image_size=vc.image_size, hidden_size=vc.hidden_size,
+                intermediate_size=vc.intermediate_size, num_hidden_layers=vc.num_hidden_layers,
+                num_attention_heads=vc.num_attention_heads, layer_norm_eps=vc.layer_norm_eps, hidden_act=vc.hidden_act,
+                projection_dim=c.projection_dim, num_channels=vc.num_channels)
+
+
+# ------------------------------------------------------------------------------------------------
+# BERT / RoBERTa  (HF:roberta/modeling_roberta.py, HF:bert/modeling_bert.py)
+# ------------------------------------------------------------------------------------------------
+def bert_hidden_states(sd, cfg, input_ids, attention_mask=None, token_type_ids=None):
+    """`model(**inputs, output_hidden_states=True).hidden_states` (extract_text_huggingface.py:225)."""
+    eps = cfg.get("layer_norm_eps", 1e-12)
+    B, T = input_ids.shape
+    if cfg.get("roberta", False):  # HF:roberta/modeling_roberta.py:56-155 create_position_ids_from_input_ids
+        pad = cfg["pad_token_id"]
+        m = (input_ids != pad).long()
+        pos_ids = torch.cumsum(m, dim=1) * m + pad
+    else:
+        pos_ids = torch.arange(T)[None].expand(B, T)
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_ids)
+    x = sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.token_type_embeddings.weight"][token_type_ids]
+    x = x + sd["embeddings.position_embeddings.weight"][pos_ids]
+    x = _ln(x, sd, "embeddings.LayerNorm", eps)
+    key_mask = attention_mask.bool() if attention_mask is not None else None
+    H = cfg["num_attention_heads"]
+    hs = [x]
+    for l in range(cfg["num_hidden_layers"]):  # HF:roberta/modeling_roberta.py:186-464 (post-LN)
+        p = f"encoder.layer.{l}."
+        a = p + "attention.self."
+        att = _mhsa(x, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"],
+                    sd[a + "value.weight"], sd[a + "value.bias"], sd[p + "attention.output.dense.weight"],
+                    sd[p + "attention.output.dense.bias"], H, key_mask)
+        x = _ln(x + att, sd, p + "attention.output.LayerNorm", eps)
+        h = _gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        x = _ln(x + F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]), sd, p + "output.LayerNorm", eps)
+        hs.append(x)
+    return hs
+
+
+def bert_cfg_from_hf(c):
+    return dict(roberta=(c.model_type in ("roberta", "xlm-roberta")), pad_token_id=c.pad_token_id,
+                num_attention_heads=c.num_attention_heads, num_hidden_layers=c.num_hidden_layers,
+                hidden_size=c.hidden_size, intermediate_size=c.intermediate_size, layer_norm_eps=c.layer_norm_eps,
+                vocab_size=c.vocab_size, max_position_embeddings=c.max_position_embeddings,
+                type_vocab_size=c.type_vocab_size, hidden_act=c.hidden_act)

@@ -1,0 +1,153 @@
+"""Encoder-level parity (GPU): the HIP path through the C-ABI against the CPU oracle, same seeded
+weights and inputs.  Tolerance: north_star's 1e-3 relative on the saved feature (max-norm relative:
+max|x-ref| / max|ref|); the fp32-grade "x3" mode is held to 5e-5."""
+import pytest
+import torch
+
+from oracle import encoders_ref as R
+from oracle import weights as W
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _hf_like_cfg(cfg):
+    return cfg
+
+
+@pytest.mark.parametrize("precision,tol", [("x3", 5e-5), ("mixed", TOL), ("f16", 2e-3)])
+def test_hubert_tiny_hidden_states(dev, precision, tol):
+    from mertools_amd.encoders import HipHubertModel
+    cfg = W.hubert_config("tiny")
+    sd = W.hubert_state_dict(cfg, 1)
+    wav = W.synth_audio(3, 8000, seed=5)
+    ref = R.hubert_hidden_states(sd, vars(cfg), wav)
+    m = HipHubertModel(sd, cfg, device=dev, precision=precision)
+    out = m(wav.to(dev), output_hidden_states=True)
+    torch.cuda.synchronize()
+    assert len(out.hidden_states) == cfg.num_hidden_layers + 1
+    for i, (o, r) in enumerate(zip(out.hidden_states, ref)):
+        assert_close(o.cpu(), r, tol, f"hubert-tiny[{precision}] hidden_states[{i}]")
+    # fused last-4 sum + utterance mean == the reference post-processing (extract_audio_huggingface.py:98-108)
+    feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
+    pooled = m.extract_utterance(wav.to(dev))
+    torch.cuda.synchronize()
+    assert_close(pooled.cpu(), feat.mean(1), tol, f"hubert-tiny[{precision}] UTT feature")
+
+
+def test_hubert_tiny_chunked_clip(dev):
+    """>10 s clips become several batch rows whose frames are pooled together (extract_audio_huggingface.py:40-50,104-108)."""
+    from mertools_amd.encoders import HipHubertModel
+    cfg = W.hubert_config("tiny")
+    sd = W.hubert_state_dict(cfg, 2)
+    wav = W.synth_audio(5, 4000, seed=6)
+    ref = torch.stack(R.hubert_hidden_states(sd, vars(cfg), wav))[[-4, -3, -2, -1]].sum(0)  # [5,T,D]
+    m = HipHubertModel(sd, cfg, device=dev, precision="x3")
+    pooled = m.extract_utterance(wav.to(dev), clip_chunks=[2, 3])
+    torch.cuda.synchronize()
+    exp = torch.stack([ref[0:2].reshape(-1, ref.shape[-1]).mean(0), ref[2:5].reshape(-1, ref.shape[-1]).mean(0)])
+    assert_close(pooled.cpu(), exp, 5e-5, "chunked clip pooling")
+
+
+@pytest.mark.parametrize("precision,tol", [("x3", 5e-5), ("f16", TOL)])
+def test_clip_tiny_image_features(dev, precision, tol):
+    from mertools_amd.encoders import HipCLIPModel
+    cfg = W.clip_config("tiny")
+    sd = W.clip_state_dict(cfg, 3)
+    px = W.synth_frames(5, 64, seed=7)
+    ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
+    m = HipCLIPModel(sd, cfg, device=dev, precision=precision)
+    out = m.get_image_features(px.to(dev))
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, tol, f"clip-tiny[{precision}] image features")
+    pooled = m.extract_utterance(px.to(dev), [2, 3])
+    torch.cuda.synchronize()
+    assert_close(pooled.cpu(), torch.stack([ref[:2].mean(0), ref[2:].mean(0)]), tol, "clip-tiny frame mean")
+
+
+@pytest.mark.parametrize("precision,tol", [("x3", 5e-5), ("f16", TOL)])
+@pytest.mark.parametrize("kind", ["tiny", "tiny-bert"])
+def test_bert_tiny_hidden_states(dev, precision, tol, kind):
+    from mertools_amd.encoders import HipBertModel
+    if kind == "tiny":
+        cfg = W.bert_config("tiny")
+    else:
+        cfg = W.bert_config("tiny", model_type="bert", pad_token_id=0, type_vocab_size=2, layer_norm_eps=1e-12)
+    sd = W.bert_state_dict(cfg, 4)
+    pad = cfg.pad_token_id
+    ids = W.synth_tokens(4, 24, vocab=300, seed=8, bos=3, eos=4)
+    lens = [24, 9, 17, 24]
+    for b, n in enumerate(lens):
+        ids[b, n:] = pad
+    mask = (torch.arange(24)[None] < torch.tensor(lens)[:, None]).long()
+    rcfg = dict(vars(cfg), roberta=(cfg.model_type == "roberta"))
+    ref = R.bert_hidden_states(sd, rcfg, ids, mask)
+    m = HipBertModel(sd, cfg, device=dev, precision=precision)
+    out = m(input_ids=ids.to(dev), attention_mask=mask, output_hidden_states=True)
+    torch.cuda.synchronize()
+    for i, (o, r) in enumerate(zip(out.hidden_states, ref)):
+        for b, n in enumerate(lens):  # padded positions are unspecified in both implementations
+            assert_close(o[b, :n].cpu(), r[b, :n], tol, f"bert-{kind}[{precision}] hs[{i}] row {b}")
+    # fused: last-4 sum, strip [start:end] = [1:-1], mean (extract_text_huggingface.py:226-249)
+    feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
+    exp = torch.stack([feat[b, 1:n - 1].mean(0) for b, n in enumerate(lens)])
+    pooled = m.extract_utterance(ids.to(dev), lens, 1, -1)
+    torch.cuda.synchronize()
+    assert_close(pooled.cpu(), exp, tol, f"bert-{kind}[{precision}] UTT feature")
+
+
+# ---- full-size architectures (BASELINE.json configs 2/3 and the text leg), small batch so the CPU oracle takes seconds ----
+def test_hubert_base_5s(dev):
+    from mertools_amd.encoders import HipHubertModel
+    cfg = W.hubert_config("base")
+    sd = W.hubert_state_dict(cfg, 0)
+    wav = W.synth_audio(2, 80000)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    hs = R.hubert_hidden_states(sd, vars(cfg), wav)
+    feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
+    m = HipHubertModel(sd, cfg, device=dev, precision="mixed")
+    assert m.out_frames(80000) == 249
+    hsd, fr, pooled = m.forward_raw(wav.to(dev), hidden_states=True, frames=True, seg_start=[0, 249], seg_len=[249, 249])
+    torch.cuda.synchronize()
+    e0 = assert_close(hsd[0].cpu(), hs[0], TOL, "hubert-base hidden_states[0] (conv stack + pos conv)")
+    eL = assert_close(hsd[-1].cpu(), hs[-1], TOL, "hubert-base hidden_states[12]")
+    ef = assert_close(fr.cpu().view(2, 249, 768), feat, TOL, "hubert-base FRAME feature")
+    eu = assert_close(pooled.cpu(), feat.mean(1), TOL, "hubert-base UTT feature")
+    print(f"hubert-base mixed: hs0 {e0:.2e} hs12 {eL:.2e} frame {ef:.2e} utt {eu:.2e}")
+    m16 = HipHubertModel(sd, cfg, device=dev, precision="f16")
+    p16 = m16.extract_utterance(wav.to(dev))
+    torch.cuda.synchronize()
+    e16 = assert_close(p16.cpu(), feat.mean(1), TOL, "hubert-base UTT feature, all-f16")
+    print(f"hubert-base f16: utt {e16:.2e}")
+
+
+def test_clip_base16_8frames(dev):
+    from mertools_amd.encoders import HipCLIPModel
+    cfg = W.clip_config("base16")
+    sd = W.clip_state_dict(cfg, 0)
+    px = W.synth_frames(8)
+    ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
+    m = HipCLIPModel(sd, cfg, device=dev, precision="f16")
+    out = m.get_image_features(px.to(dev))
+    pooled = m.extract_utterance(px.to(dev), [8])
+    torch.cuda.synchronize()
+    e = assert_close(out.cpu(), ref, TOL, "clip-B/16 frame features")
+    eu = assert_close(pooled.cpu(), ref.mean(0, keepdim=True), TOL, "clip-B/16 UTT feature")
+    print(f"clip-B/16 f16: frames {e:.2e} utt {eu:.2e}")
+
+
+def test_roberta_base_64tok(dev):
+    from mertools_amd.encoders import HipBertModel
+    cfg = W.bert_config("roberta-base")
+    sd = W.bert_state_dict(cfg, 0)
+    ids = W.synth_tokens(4, 64)
+    ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids))
+    feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
+    m = HipBertModel(sd, cfg, device=dev, precision="f16")
+    hs, fr, pooled = m.forward_raw(ids.to(dev), lengths=[64] * 4, hidden_states=True, frames=True,
+                                   seg_start=[b * 64 + 1 for b in range(4)], seg_len=[62] * 4)
+    torch.cuda.synchronize()
+    e = assert_close(fr.cpu().view(4, 64, 768), feat, TOL, "roberta-base FRAME feature")
+    eu = assert_close(pooled.cpu(), feat[:, 1:-1].mean(1), TOL, "roberta-base UTT feature")
+    print(f"roberta-base f16: frame {e:.2e} utt {eu:.2e}")

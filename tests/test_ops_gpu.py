@@ -1,0 +1,267 @@
+"""Op-level parity (GPU): every HIP kernel against a plain torch fp32/fp64 CPU reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from mertools_amd import ops
+    return ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _act_ref(x, act):
+    if act == "gelu":
+        return F.gelu(x)
+    if act == "quick_gelu":
+        return x * torch.sigmoid(1.702 * x)
+    if act == "relu":
+        return F.relu(x)
+    return x
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 1), (300, 200, 136, 1), (257, 48, 72, 2), (1000, 768, 768, 0),
+                                        (64, 2304, 768, 1), (130, 64, 3072, 2)])
+def test_gemm16_single_pass(dev, dtype, M, N, K, tile):
+    ops = _ops()
+    t16 = ops.torch16(dtype)
+    a = _rand((M, K), 1).to(t16)
+    w = (_rand((N, K), 2) * 0.05).to(t16)
+    bias = _rand((N,), 3)
+    res = _rand((M, N), 4)
+    ref = a.double() @ w.double().T + bias.double()
+    ref = _act_ref(ref, "gelu") + res.double()
+    c32, c16, _ = ops.gemm16(a.to(dev), w.to(dev), bias=bias.to(dev), act="gelu", residual=res.to(dev), out32=True, out16=True,
+                             dtype=dtype, tile=tile)
+    torch.cuda.synchronize()
+    assert_close(c32.cpu(), ref.float(), 2e-5, f"gemm16 {dtype} c32")
+    assert_close(c16.float().cpu(), ref.float(), 1e-2 if dtype == "bf16" else 1.5e-3, f"gemm16 {dtype} c16")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 136), (1000, 768, 768), (257, 48, 6144)])
+def test_gemm16_three_pass_is_fp32_grade(dev, M, N, K):
+    ops = _ops()
+    a = _rand((M, K), 5)
+    w = _rand((N, K), 6) * 0.05
+    ah, al = ops.split16(a.to(dev), "f16")
+    wh, wl = ops.split16_host(w, "f16")
+    ref = a.double() @ w.double().T
+    c32, c16h, c16l = ops.gemm16(ah, wh.to(dev), a_lo=al, w_lo=wl.to(dev), out32=True, out16=True, out16_lo=True, passes=3,
+                                 dtype="f16", tile=2 if N <= 64 else 1)
+    torch.cuda.synchronize()
+    assert_close(c32.cpu(), ref.float(), 2e-5, "gemm16 x3 c32")
+    # hi+lo planes of the output reproduce the fp32 result to ~2^-21
+    assert_close((c16h.float() + c16l.float()).cpu(), ref.float(), 1e-5, "gemm16 x3 hi+lo out")
+    # and a single pass on the same data is visibly worse (guards against silently running 3 passes everywhere)
+    c1, _, _ = ops.gemm16(ah, wh.to(dev), out32=True, passes=1, dtype="f16")
+    e1 = (c1.cpu().double() - ref).abs().max() / ref.abs().max()
+    assert e1 > 5e-5
+
+
+def test_gemm16_implicit_conv1d(dev):
+    """Strided Conv1d over channels-last input as a row-mapped GEMM (HuBERT conv layers 1..6)."""
+    ops = _ops()
+    B, Tin, C, k, s, Cout = 3, 41, 64, 3, 2, 96
+    x = _rand((B, Tin, C), 7).half()
+    w = (_rand((Cout, C, k), 8) * 0.1).half()
+    Tout = (Tin - k) // s + 1
+    ref = F.conv1d(x.float().transpose(1, 2).double(), w.double(), stride=s).transpose(1, 2).reshape(B * Tout, Cout)
+    w2 = w.permute(0, 2, 1).reshape(Cout, k * C).contiguous()
+    c32, _, _ = ops.gemm16(x.to(dev).reshape(B * Tin, C), w2.to(dev), out32=True, dtype="f16", M=B * Tout, lda=s * C,
+                           a_rows_per_batch=Tout, a_batch_stride=Tin * C)
+    torch.cuda.synchronize()
+    assert_close(c32.cpu(), ref.float(), 2e-5, "implicit conv1d")
+
+
+def test_gemm16_batched_posconv(dev):
+    """Grouped positional conv = pack + batched implicit GEMM with residual epilogue."""
+    from mertools_amd._lib import GemmArgs
+    ops = _ops()
+    B, T, D, G, K = 2, 37, 96, 4, 16
+    Dg = D // G
+    x = _rand((B, T, D), 9)
+    w = _rand((D, Dg, K), 10) * 0.05
+    bias = _rand((D,), 11)
+    pc = F.conv1d(x.transpose(1, 2).double(), w.double(), bias.double(), padding=K // 2, groups=G)[:, :, :-1]
+    ref = (x.double() + F.gelu(pc).transpose(1, 2)).float()
+    xd = x.to(dev)
+    ph, pl = ops.posconv_pack(xd, G, K, dtype="f16", lo=True)
+    # the pack itself
+    xp = torch.zeros(B, G, T + K, Dg)
+    xp[:, :, K // 2:K // 2 + T] = x.view(B, T, G, Dg).permute(0, 2, 1, 3)
+    torch.cuda.synchronize()
+    assert_close((ph.float() + pl.float()).cpu(), xp, 1e-6, "posconv_pack")
+    wg = w.view(G, Dg, Dg, K).permute(0, 1, 3, 2).reshape(G * Dg, K * Dg).contiguous()
+    wh, wl = ops.split16_host(wg, "f16")
+    wh, wl = wh.to(dev), wl.to(dev)
+    bd = bias.to(dev)
+    out = torch.empty((B, T, D), device=dev)
+    g = GemmArgs()
+    g.M, g.N, g.K, g.dtype = T, Dg, K * Dg, 0
+    g.a_hi, g.a_lo, g.lda = ph.data_ptr(), pl.data_ptr(), Dg
+    g.w_hi, g.w_lo, g.ldw = wh.data_ptr(), wl.data_ptr(), K * Dg
+    g.bias, g.act = bd.data_ptr(), 1
+    g.residual, g.ldr = xd.data_ptr(), D
+    g.c32, g.ldc32 = out.data_ptr(), D
+    g.nbatch, g.nb_inner = B * G, G
+    g.a_so, g.a_si = G * (T + K) * Dg, (T + K) * Dg
+    g.w_si, g.bias_si = Dg * K * Dg, Dg
+    g.c_so, g.c_si = T * D, Dg
+    g.passes, g.tile = 3, 0
+    ops.gemm16_raw(g)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, 2e-5, "batched posconv gemm")
+
+
+@pytest.mark.parametrize("D", [512, 768, 1024, 48 * 4])
+def test_layernorm(dev, D):
+    ops = _ops()
+    M = 77
+    x = _rand((M, D), 12, 3.0) + 0.5
+    g, b = _rand((D,), 13) * 0.1 + 1.0, _rand((D,), 14) * 0.1
+    ref = F.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-5)
+    o32, oh, ol = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-5, out32=True, out16=True, out16_lo=True)
+    torch.cuda.synchronize()
+    assert_close(o32.cpu(), ref.float(), 2e-6, "layernorm fp32")
+    assert_close((oh.float() + ol.float()).cpu(), ref.float(), 2e-6, "layernorm planes")
+    o32g, _, _ = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-5, act="gelu")
+    torch.cuda.synchronize()
+    assert_close(o32g.cpu(), F.gelu(ref).float(), 2e-6, "layernorm+gelu")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (2, 50, 3), (1, 197, 12), (2, 249, 4), (1, 257, 2), (1, 499, 2)])
+def test_attention(dev, dtype, B, T, H):
+    ops = _ops()
+    t16 = ops.torch16(dtype)
+    D = H * 64
+    qkv = _rand((B * T, 3 * D), 15).to(t16)
+    q, k, v = [t.float().view(B, T, H, 64).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    p = torch.softmax(q @ k.transpose(2, 3) / 8.0, dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * T, D).float()
+    oh, ol = ops.attention(qkv.to(dev), B, T, H, 0.125, out_lo=True)
+    torch.cuda.synchronize()
+    # P is rounded to 16 bits before P@V: that bounds the error, not the fp32 softmax
+    assert_close((oh.float() + ol.float()).cpu(), ref, 6e-3 if dtype == "bf16" else 8e-4, f"attention {dtype}")
+
+
+def test_attention_kv_len_mask(dev):
+    ops = _ops()
+    B, T, H = 3, 64, 2
+    D = H * 64
+    lens = torch.tensor([64, 17, 40], dtype=torch.int32)
+    qkv = _rand((B * T, 3 * D), 16).half()
+    q, k, v = [t.float().view(B, T, H, 64).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    s = q @ k.transpose(2, 3) / 8.0
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, D).float()
+    oh, _ = ops.attention(qkv.to(dev), B, T, H, 0.125, kv_len=lens.to(dev))
+    torch.cuda.synchronize()
+    out = oh.float().cpu().view(B, T, D)
+    for b in range(B):
+        assert_close(out[b, :lens[b]], ref[b, :lens[b]], 1.5e-3, f"masked attention row {b}")
+
+
+def test_hubert_conv0_groupnorm_gelu(dev):
+    ops = _ops()
+    B, L, C, k, s = 2, 4000, 512, 10, 5
+    wav = _rand((B, L), 17)
+    w = _rand((C, k), 18) * 0.3
+    g, b = _rand((C,), 19) * 0.1 + 1.0, _rand((C,), 20) * 0.1
+    y = F.conv1d(wav[:, None].double(), w[:, None].double(), stride=s)
+    ref = F.gelu(F.group_norm(y, C, g.double(), b.double(), 1e-5)).transpose(1, 2).float()
+    oh, ol = ops.hubert_conv0_gn(wav.to(dev), w.to(dev), g.to(dev), b.to(dev), 1e-5, stride=s, lo=True)
+    torch.cuda.synchronize()
+    assert_close((oh.float() + ol.float()).cpu(), ref, 5e-6, "conv0+GN+GELU")
+
+
+def test_vit_patchify_and_assemble(dev):
+    ops = _ops()
+    N, P, S, D = 3, 16, 64, 128
+    px = _rand((N, 3, S, S), 21)
+    ph, pl = ops.vit_patchify(px.to(dev), P, lo=True)
+    g = S // P
+    ref = px.view(N, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(N * g * g, 3 * P * P)
+    torch.cuda.synchronize()
+    assert_close((ph.float() + pl.float()).cpu(), ref, 1e-6, "patchify")
+    npatch = g * g
+    patch = _rand((N * npatch, D), 22)
+    cls, pos = _rand((D,), 23), _rand((npatch + 1, D), 24)
+    gam, bet = _rand((D,), 25) * 0.1 + 1, _rand((D,), 26) * 0.1
+    tok = torch.cat([cls.expand(N, 1, D), patch.view(N, npatch, D)], 1) + pos[None]
+    out = ops.vit_assemble(patch.to(dev), cls.to(dev), pos.to(dev), gam.to(dev), bet.to(dev), 1e-5, N, npatch, D)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), F.layer_norm(tok.double(), (D,), gam.double(), bet.double(), 1e-5).float().view(-1, D), 2e-6, "assemble+LN")
+    out2 = ops.vit_assemble(patch.to(dev), cls.to(dev), pos.to(dev), None, None, 1e-5, N, npatch, D)
+    torch.cuda.synchronize()
+    assert_close(out2.cpu(), tok.view(-1, D), 1e-7, "assemble")
+
+
+@pytest.mark.parametrize("pos_mode", [0, 1])
+def test_bert_embed(dev, pos_mode):
+    ops = _ops()
+    B, T, D, V = 3, 20, 256, 100
+    g = torch.Generator().manual_seed(27)
+    ids = torch.randint(3, V, (B, T), generator=g)
+    pad = 1
+    ids[1, 12:] = pad
+    ids[2, 5:] = pad
+    tt = torch.zeros_like(ids)
+    word, pos, typ = _rand((V, D), 28), _rand((T + 4, D), 29), _rand((2, D), 30)
+    gam, bet = _rand((D,), 31) * 0.1 + 1, _rand((D,), 32) * 0.1
+    if pos_mode == 1:
+        m = (ids != pad).long()
+        pid = torch.cumsum(m, 1) * m + pad
+    else:
+        pid = torch.arange(T)[None].expand(B, T)
+    ref = F.layer_norm((word[ids] + typ[tt] + pos[pid]).double(), (D,), gam.double(), bet.double(), 1e-12).float().view(-1, D)
+    o32, oh = ops.bert_embed(ids.to(dev), None, word.to(dev), pos.to(dev), typ.to(dev), pos_mode, pad, gam.to(dev), bet.to(dev), 1e-12)
+    torch.cuda.synchronize()
+    assert_close(o32.cpu(), ref, 2e-6, "bert_embed")
+    assert_close(oh.float().cpu(), ref, 1e-3, "bert_embed f16")
+
+
+def test_sum_pool(dev):
+    ops = _ops()
+    M, D = 90, 768
+    hs = [_rand((M, D), 40 + i) for i in range(4)]
+    ref_fr = ((hs[0] + hs[1]) + hs[2]) + hs[3]
+    starts = torch.tensor([0, 30, 31, 89], dtype=torch.int32)
+    lens = torch.tensor([30, 1, 58, 1], dtype=torch.int32)
+    fr, pooled = ops.sum_pool([h.to(dev) for h in hs], starts.to(dev), lens.to(dev), frames=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fr.cpu(), ref_fr), "last-4 sum must be bit-exact (same add order as torch.stack(...).sum(0))"
+    ref_pool = torch.stack([ref_fr[s:s + n].double().mean(0) for s, n in zip(starts.tolist(), lens.tolist())]).float()
+    assert_close(pooled.cpu(), ref_pool, 1e-6, "segment mean")
+    fr1, _ = ops.sum_pool([hs[0].to(dev)], frames=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fr1.cpu(), hs[0])
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 128, 768), (33, 6, 130), (7, 3, 5)])
+def test_gemm32_exact_fp32(dev, M, N, K):
+    ops = _ops()
+    a, w, b = _rand((M, K), 50), _rand((N, K), 51) * 0.1, _rand((N,), 52)
+    ref = F.relu(a.double() @ w.double().T + b.double()).float()
+    out = ops.gemm32(a.to(dev), w.to(dev), b.to(dev), "relu")
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, 2e-6, "gemm32")
+    # transposed operand forms used by the backward pass
+    out_t = ops.gemm32(a.T.contiguous().to(dev), w.T.contiguous().to(dev), None, None, trans_a=True, trans_w=True)
+    torch.cuda.synchronize()
+    assert_close(out_t.cpu(), (a.double() @ w.double().T).float(), 2e-6, "gemm32 transposed")
+    acc = ops.gemm32(a.to(dev), w.to(dev), None, None, out=out_t.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    assert_close(acc.cpu(), (2 * (a.double() @ w.double().T)).float(), 2e-6, "gemm32 accumulate")
