@@ -77,7 +77,7 @@ typedef struct {
   void* c16_hi; void* c16_lo; long long ldc16;
   int nbatch, nb_inner;
   long long a_so, a_si, w_si, bias_si, c_so, c_si;
-  int passes;   /* 1 = hi*hi only; 3 = hi*hi + hi*lo + lo*hi (needs a_lo and w_lo) */
+  int passes;   /* 1 = a_hi*w_hi; 2 = + a_hi*w_lo (needs w_lo); 3 = + a_lo*w_hi (needs a_lo too) */
   int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N) */
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
@@ -177,7 +177,7 @@ typedef struct {
   int act;        /* MER_ACT_GELU | MER_ACT_QUICK_GELU */
   float ln_eps;
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
-  int passes;     /* GEMM passes inside the blocks: 1 or 3 */
+  int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split) or 3 (both split) */
 } mer_tf_config;
 
 /* ---- HuBERT / wav2vec2 audio encoder --------------------------------------------------------
@@ -193,7 +193,7 @@ typedef struct {
   int feat_proj_layer_norm;
   int pos_k, pos_groups;
   int stable_layer_norm;    /* 1: HubertEncoderStableLayerNorm (large) */
-  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1 or 3 */
+  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1, 2 or 3 */
 } mer_hubert_config;
 
 typedef struct {

@@ -146,6 +146,10 @@ def lib():
             raise MerError(
                 f"{LIB_PATH} not found: build it with `python -m mertools_amd.build` "
                 "(hipcc --offload-arch=gfx950). mertools_amd has no CPU fallback.")
+        # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  It must be in the process first
+        # so that libmer_hip.so binds to the runtime that owns torch's device memory and streams;
+        # loading ours first leaves two HIP runtimes and ours sees "no ROCm-capable device".
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(h, name, None)

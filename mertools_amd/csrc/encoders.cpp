@@ -119,7 +119,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.hidden > 0 && c.heads > 0 && c.hidden % c.heads == 0, MER_EINVAL, "%s: bad hidden/heads", who);
   MER_REQUIRE(c.hidden / c.heads == 64, MER_EUNSUPPORTED, "%s: head_dim %d != 64 unsupported", who, c.hidden / c.heads);
   MER_REQUIRE(c.hidden % 8 == 0 && c.ffn % 8 == 0, MER_ESHAPE, "%s: hidden/ffn must be multiples of 8", who);
-  MER_REQUIRE(c.passes == 1 || c.passes == 3, MER_EINVAL, "%s: passes must be 1 or 3", who);
+  MER_REQUIRE(c.passes >= 1 && c.passes <= 3, MER_EINVAL, "%s: passes must be 1, 2 or 3", who);
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
   MER_REQUIRE(c.dtype == MER_DT_F16 || c.dtype == MER_DT_BF16, MER_EINVAL, "%s: bad dtype", who);
   return MER_OK;
@@ -156,7 +156,7 @@ extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_
   MER_REQUIRE(cfg->conv_dim % 8 == 0, MER_ESHAPE, "mer_hubert_create: conv_dim %% 8 != 0");
   MER_REQUIRE(cfg->feat_norm_group == 1, MER_EUNSUPPORTED,
               "mer_hubert_create: feat_extract_norm='layer' (HuBERT-large front end) is not built yet");
-  MER_REQUIRE(cfg->conv_passes == 1 || cfg->conv_passes == 3, MER_EINVAL, "mer_hubert_create: conv_passes must be 1 or 3");
+  MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 3, MER_EINVAL, "mer_hubert_create: conv_passes must be 1, 2 or 3");
   MER_REQUIRE(cfg->tf.hidden % cfg->pos_groups == 0 && (cfg->tf.hidden / cfg->pos_groups) % 8 == 0, MER_ESHAPE,
               "mer_hubert_create: hidden/pos_groups must be a multiple of 8");
   MER_REQUIRE(w->layers && w->conv0_w && w->fp_w.hi && w->pos_w.hi, MER_EINVAL, "mer_hubert_create: missing weights");

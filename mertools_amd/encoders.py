@@ -13,12 +13,14 @@ AutoModel.from_pretrained), converts the weights once into the layouts the HIP k
 only passes device pointers to libmer_hip.so.  torch provides device memory and the stream; there
 is no torch compute on the forward path and no CPU fallback.
 
-precision:
-    "f16"    every GEMM one fp16 MFMA pass (fp32 accumulate)
-    "mixed"  conv stack / projection / positional conv in 3-pass split fp16 (fp32-grade), the
-             transformer blocks in one pass — default for HuBERT, whose un-normalised conv stack
-             otherwise accounts for most of the fp16 error
-    "x3"     every GEMM 3-pass
+precision (see DESIGN.md §numerics for the measured parity of each):
+    "fast"      every GEMM one fp16 MFMA pass (fp32 accumulate): ~1e-3 on the saved features
+    "balanced"  weights carried as hi+lo fp16 planes, two MFMA passes (a*w_hi + a*w_lo): removes the
+                weight-rounding error, the part that is coherent across tokens and survives the
+                utterance mean — default
+    "accurate"  both operands split, three passes: fp32-grade GEMMs (attention still rounds q/k/v/P to
+                fp16), ~1e-4
+    "mixed" / "balanced3"  HuBERT only: conv stack 3-pass with 1- / 2-pass transformer blocks
 """
 import ctypes as C
 
@@ -100,7 +102,9 @@ def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes):
     return c
 
 
-_PREC = {"f16": (1, 1), "fast": (1, 1), "mixed": (3, 1), "x3": (3, 3)}
+# precision preset -> (GEMM passes in the HuBERT conv stack, GEMM passes in the transformer blocks)
+_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2),
+         "accurate": (3, 3), "x3": (3, 3)}
 
 
 class _HipModule:
@@ -151,7 +155,7 @@ class _HipModule:
 class HipHubertModel(_HipModule):
     _destroy = "mer_hubert_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mixed"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -176,7 +180,7 @@ class HipHubertModel(_HipModule):
         cfg.pos_k, cfg.pos_groups = config.num_conv_pos_embeddings, config.num_conv_pos_embedding_groups
         cfg.stable_layer_norm = int(config.do_stable_layer_norm)
         cfg.conv_passes = conv_passes
-        clo = conv_passes == 3
+        clo = conv_passes >= 2
         w = HubertWeights()
         fe = "feature_extractor.conv_layers."
         w.conv0_w = hold.f32(sd[fe + "0.conv.weight"].reshape(Cc, -1))
@@ -208,7 +212,7 @@ class HipHubertModel(_HipModule):
         w.pos_w = hold.w16(pw.reshape(G, Dg, Dg, K).permute(0, 1, 3, 2).reshape(G * Dg, K * Dg), clo)
         w.pos_b = hold.f32(sd[p + "bias"])
         w.enc_ln_g, w.enc_ln_b = hold.f32(sd["encoder.layer_norm.weight"]), hold.f32(sd["encoder.layer_norm.bias"])
-        tlo = tf_passes == 3
+        tlo = tf_passes >= 2
         layers = (TfLayer * config.num_hidden_layers)()
         for l in range(config.num_hidden_layers):
             q = f"encoder.layers.{l}."
@@ -276,16 +280,14 @@ class HipHubertModel(_HipModule):
 class HipCLIPModel(_HipModule):
     _destroy = "mer_vit_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="f16"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
         vc = config.vision_config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        if precision == "mixed":
-            tf_passes = 1
-        lo = tf_passes == 3
+        lo = tf_passes >= 2
         hold = self._hold = _Holder(device, dtype)
         act = MER_ACT_QUICK_GELU if vc.hidden_act == "quick_gelu" else MER_ACT_GELU
         cfg = VitConfig()
@@ -355,13 +357,13 @@ class HipBertModel(_HipModule):
     """BERT / RoBERTa family (post-LN encoder-only text models)."""
     _destroy = "mer_bert_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="f16"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo = tf_passes == 3
+        lo = tf_passes >= 2
         hold = self._hold = _Holder(device, dtype)
         if config.hidden_act != "gelu":
             raise _lib.MerError(f"hidden_act={config.hidden_act} unsupported")

@@ -31,7 +31,7 @@ def hubert_config(size="base", **over):
                 feat_extract_norm="group", conv_bias=False, feat_proj_layer_norm=True, num_conv_pos_embeddings=128,
                 num_conv_pos_embedding_groups=16, do_stable_layer_norm=False, layer_norm_eps=1e-5, model_type="hubert")
     if size == "tiny":
-        base.update(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
+        base.update(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
                     num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
     base.update(over)
     return SimpleNamespace(**base)
@@ -111,7 +111,7 @@ def bert_config(size="roberta-base", **over):
         base.update(vocab_size=21128, max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
                     model_type="bert")
     if size == "tiny":
-        base.update(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=300,
+        base.update(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, vocab_size=300,
                     max_position_embeddings=70)
     base.update(over)
     return SimpleNamespace(**base)
