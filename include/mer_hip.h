@@ -45,6 +45,8 @@ const char* mer_target_arch(void);
 /* Per-launch timing for the roofline report: while enabled, instrumented launches are bracketed
  * by hipEvents on their own stream.  mer_prof_report synchronises the device, writes a JSON array
  * [{"name","calls","ms","flops","bytes"}] aggregated per kernel and clears the records. */
+/* Tuning knobs (A/B testing): "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged. */
+int mer_set_option(const char* name, int value);
 int mer_prof_enable(int on);
 int mer_prof_report(char* buf, int buflen);
 

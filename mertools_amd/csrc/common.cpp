@@ -33,13 +33,13 @@ ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s
   if (!g_prof_on.load(std::memory_order_relaxed)) return;
   ProfRec* r = new ProfRec{name, flops, bytes, nullptr, nullptr};
   if (hipEventCreate(&r->e0) != hipSuccess || hipEventCreate(&r->e1) != hipSuccess) { delete r; return; }
-  hipEventRecord(r->e0, st);
+  (void)hipEventRecord(r->e0, st);
   rec = r;
 }
 ProfScope::~ProfScope() {
   if (!rec) return;
   ProfRec* r = (ProfRec*)rec;
-  hipEventRecord(r->e1, st);
+  (void)hipEventRecord(r->e1, st);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(r);
 }
@@ -55,18 +55,18 @@ extern "C" int mer_prof_enable(int on) {
 extern "C" int mer_prof_report(char* buf, int buflen) {
   using namespace mer;
   if (!buf || buflen < 4) return MER_EINVAL;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lk(g_prof_mu);
   struct Agg { const char* name; long long calls; double ms, flops, bytes; };
   std::vector<Agg> aggs;
   for (ProfRec* r : g_prof) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, r->e0, r->e1);
+    (void)hipEventElapsedTime(&ms, r->e0, r->e1);
     Agg* a = nullptr;
     for (auto& x : aggs) if (strcmp(x.name, r->name) == 0) { a = &x; break; }
     if (!a) { aggs.push_back(Agg{r->name, 0, 0, 0, 0}); a = &aggs.back(); }
     a->calls++; a->ms += ms; a->flops += r->flops; a->bytes += r->bytes;
-    hipEventDestroy(r->e0); hipEventDestroy(r->e1);
+    (void)hipEventDestroy(r->e0); (void)hipEventDestroy(r->e1);
     delete r;
   }
   g_prof.clear();

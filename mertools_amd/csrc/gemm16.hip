@@ -23,6 +23,7 @@
 //   * workgroup -> tile mapping is XCD-aware (blocks b, b+8, b+16.. share an XCD / L2 and get
 //     neighbouring tiles; bijective for any grid size).
 #include "common.h"
+#include <string.h>
 
 namespace mer {
 
@@ -39,7 +40,10 @@ struct Gemm16Params {
   int vec_ok;  // N % 4 == 0 and all output/residual strides+offsets 4-element aligned
 };
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
   constexpr int NT = WM * WN * 64;
@@ -144,6 +148,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       }
   };
 
+  // GLDS path: global -> LDS DMA (global_load_lds_dwordx4), no VGPR round trip and no ds_write.
+  // One wave-instruction fills 1 KiB of LDS linearly (lane l -> base + 16*l), i.e. 64/C whole tile
+  // rows; the XOR swizzle therefore moves to the SOURCE side: the lane that owns physical chunk c'
+  // of row r fetches logical chunk c' ^ f(r).  The LDS image is identical to lds_store()'s.
+  long long a_src[CA], w_src[CW];
+  if (GLDS) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int row = ld_row0 + i * ROWS_PER_IT;
+      a_src[i] = a_off[i] + ((ld_ch ^ ((row / R) & (C - 1))) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+      const int row = ld_row0 + i * ROWS_PER_IT;
+      w_src[i] = w_off[i] + ((ld_ch ^ ((row / R) & (C - 1))) << 3);
+    }
+  }
+  const int wave_row0 = (tid >> 6) * (64 / C);  // first tile row of this wave's 1 KiB piece
+  auto glds_issue = [&](int k0, int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int pl = 0; pl < AP; ++pl)
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0),
+                                         (lds_void_t*)(base + pl * A_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
+#pragma unroll
+    for (int pl = 0; pl < WP; ++pl)
+#pragma unroll
+      for (int i = 0; i < CW; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(w_pl[pl] + w_src[i] + k0),
+                                         (lds_void_t*)(base + AP * A_PLANE + pl * W_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
+  };
+
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -151,13 +189,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  gload(0);
-  lds_store(0);
+  if (GLDS) {
+    glds_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    gload(0);
+    lds_store(0);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk) {
+      if (GLDS) glds_issue((kt + 1) * BK, cur ^ 1);
+      else gload((kt + 1) * BK);
+    }
     const char* base = smem + cur * STAGE;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -187,7 +233,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[0][nt], acc[mt][nt]);
         }
     }
-    if (kt + 1 < nk) lds_store(cur ^ 1);
+    if (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (kt + 1 < nk) {
+      lds_store(cur ^ 1);
+    }
     __syncthreads();
   }
 
@@ -266,6 +316,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   }
 }
 
+int g_gemm_glds = 1;  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
+
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP>
 static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   Gemm16Params p = p0;
@@ -279,7 +331,10 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
                  2.0 * AP * nbatch * (double)p.M * p.K + 2.0 * WP * (double)p.N * p.K * (nbatch / p.nb_inner > 0 ? p.nb_inner : 1) +
                      mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.residual ? 4 : 0)),
                  st);
-  hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP>), grid, block, 0, st, p);
+  if (g_gemm_glds && p.K % BK == 0)
+    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, false>), grid, block, 0, st, p);
   return check_launch("gemm16");
 }
 
@@ -296,6 +351,12 @@ static int dispatch(const Gemm16Params& p, int nbatch, int passes, int tile, hip
 }
 
 }  // namespace mer
+
+extern "C" int mer_set_option(const char* name, int value) {
+  if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
+  mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
+  return MER_EINVAL;
+}
 
 extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   using namespace mer;
