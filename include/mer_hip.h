@@ -45,6 +45,8 @@ const char* mer_target_arch(void);
 /* Per-launch timing for the roofline report: while enabled, instrumented launches are bracketed
  * by hipEvents on their own stream.  mer_prof_report synchronises the device, writes a JSON array
  * [{"name","calls","ms","flops","bytes"}] aggregated per kernel and clears the records. */
+/* sizeof() of a struct of this header by name ("mer_gemm16_args", ...) so bindings can verify layouts. */
+int mer_abi_sizeof(const char* name);
 /* Tuning knobs (A/B testing): "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged. */
 int mer_set_option(const char* name, int value);
 int mer_prof_enable(int on);
@@ -155,6 +157,30 @@ int mer_bert_embed(const int64_t* ids, const int64_t* token_type, int B, int T, 
 int mer_sum_pool(const float* h0, const float* h1, const float* h2, const float* h3, long long M, int D,
                  float* out_frames, const int* seg_start, const int* seg_len, int nseg, float* out_pool,
                  mer_stream_t stream);
+
+/* ---- fusion classifier pieces (MERBench/toolkit/models/attention.py:36-57, modules/encoder.py:30-41,
+ *      utils/loss.py:5-28, main-release.py:50-66).  Linear layers run on mer_gemm32; these are the
+ *      element-wise / tiny-reduction kernels around them, forward and backward. ------------------- */
+int mer_relu_bwd(const float* dy, const float* y, float* dz, long long n, mer_stream_t stream);          /* dz = y>0 ? dy : 0 */
+int mer_colsum(const float* x, int M, int N, long long ldx, float* out, int accumulate, mer_stream_t stream); /* bias grad */
+int mer_dropout(const float* x, const uint8_t* keep, float scale, float* out, long long n, mer_stream_t stream);
+/* fused[b,j] = sum_e h[b,e*H+j]*att[b,e]  (h = cat of the E modality encoders' outputs, att NOT softmaxed) */
+int mer_fuse_fwd(const float* h, const float* att, float* out, int B, int H, int E, mer_stream_t stream);
+int mer_fuse_bwd(const float* dout, const float* h, const float* att, float* dh, float* datt, int B, int H, int E,
+                 mer_stream_t stream);
+/* CELoss = NLL(log_softmax(logits,1), target, 'sum')/B; probs [B,C] and row_scratch [B] are device scratch
+ * kept for the backward; loss is a device scalar. */
+int mer_ce_loss(const float* logits, const int64_t* target, int B, int C, float* probs, float* row_scratch, float* loss,
+                mer_stream_t stream);
+int mer_ce_loss_bwd(const float* probs, const int64_t* target, const float* gout, float* dlogits, int B, int C,
+                    mer_stream_t stream);
+/* MSELoss = sum((pred-target)^2)/B on [B] vectors */
+int mer_mse_loss(const float* pred, const float* target, int B, float* row_scratch, float* loss, mer_stream_t stream);
+int mer_mse_loss_bwd(const float* pred, const float* target, const float* gout, float* dpred, int B, mer_stream_t stream);
+/* torch.optim.Adam step on one flat tensor (L2 weight decay added to the gradient; clip_value > 0 applies
+ * clip_grad_value_ first); step counts from 1. */
+int mer_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float clip_value, mer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Encoder level                                                                               */

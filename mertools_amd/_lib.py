@@ -97,6 +97,7 @@ _PROTOS = {
     "mer_version": (C.c_char_p, []),
     "mer_last_error": (C.c_char_p, []),
     "mer_target_arch": (C.c_char_p, []),
+    "mer_abi_sizeof": (c_int, [C.c_char_p]),
     "mer_set_option": (c_int, [C.c_char_p, c_int]),
     "mer_prof_enable": (c_int, [c_int]),
     "mer_prof_report": (c_int, [C.c_char_p, c_int]),
@@ -118,6 +119,17 @@ _PROTOS = {
                                c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mer_sum_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_int,
                              c_void_p, c_void_p]),
+    "mer_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    "mer_colsum": (c_int, [c_void_p, c_int, c_int, c_ll, c_void_p, c_int, c_void_p]),
+    "mer_dropout": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_ll, c_void_p]),
+    "mer_fuse_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mer_fuse_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mer_ce_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mer_ce_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mer_mse_loss": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mer_mse_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mer_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float,
+                              c_int, c_float, c_void_p]),
     "mer_hubert_create": (c_int, [C.POINTER(HubertConfig), C.POINTER(HubertWeights), C.POINTER(c_void_p)]),
     "mer_hubert_destroy": (None, [c_void_p]),
     "mer_hubert_out_frames": (c_int, [c_void_p, c_int]),

@@ -453,3 +453,21 @@ extern "C" int mer_bert_forward(const mer_bert* h, const int64_t* ids, const int
   MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, T, hs, p.tf, lengths));
   return last4_pool(st, hs, c.tf.layers, M, D, frames, seg_start, seg_len, nseg, pooled);
 }
+
+// ABI self-description: lets a binding check its struct layouts against the library it loaded.
+extern "C" int mer_abi_sizeof(const char* name) {
+  if (!name) return MER_EINVAL;
+#define MER_SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T)
+  MER_SZ(mer_gemm16_args);
+  MER_SZ(mer_w16);
+  MER_SZ(mer_tf_layer);
+  MER_SZ(mer_tf_config);
+  MER_SZ(mer_hubert_config);
+  MER_SZ(mer_hubert_weights);
+  MER_SZ(mer_vit_config);
+  MER_SZ(mer_vit_weights);
+  MER_SZ(mer_bert_config);
+  MER_SZ(mer_bert_weights);
+#undef MER_SZ
+  return MER_EINVAL;
+}

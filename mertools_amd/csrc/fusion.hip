@@ -1,0 +1,180 @@
+// fusion.hip — the small fp32 kernels of the Attention / MLP fusion classifier and its training step.
+// (MERBench/toolkit/models/attention.py:36-57, modules/encoder.py:30-41, utils/loss.py:5-28,
+//  main-release.py:50-66.)  The Linear layers themselves run on mer_gemm32 (exact fp32 MFMA);
+// everything here is element-wise / tiny reductions over a [32, <=768] minibatch: the problem is
+// launch-latency bound, so each kernel does as much of its stage as possible in one launch.
+#include "common.h"
+
+namespace mer {
+
+__global__ void relu_bwd_kernel(const float* dy, const float* y, float* dz, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dz[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// out[n] (+)= sum_m x[m*ldx + n]   (bias gradient); one thread per column, rows in order.
+__global__ void colsum_kernel(const float* x, int M, int N, long long ldx, float* out, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += x[(long long)m * ldx + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+__global__ void dropout_kernel(const float* x, const uint8_t* keep, float scale, float* out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = keep[i] ? x[i] * scale : 0.f;
+}
+
+// fused[b,j] = sum_e h[b, e*H + j] * att[b,e]   (torch.matmul([B,H,3],[B,3,1]) of attention.py:48-50)
+__global__ void fuse_fwd_kernel(const float* h, const float* att, float* out, int B, int H, int E) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H) return;
+  const int b = (int)(i / H), j = (int)(i % H);
+  float s = 0.f;
+  for (int e = 0; e < E; ++e) s = fmaf(h[(long long)b * E * H + e * H + j], att[b * E + e], s);
+  out[i] = s;
+}
+
+// dh[b,e*H+j] = dout[b,j]*att[b,e];  datt[b,e] = sum_j dout[b,j]*h[b,e*H+j].  One wave per (b,e).
+__global__ __launch_bounds__(64) void fuse_bwd_kernel(const float* dout, const float* h, const float* att, float* dh,
+                                                      float* datt, int B, int H, int E) {
+  const int b = blockIdx.x / E, e = blockIdx.x % E, lane = threadIdx.x;
+  const float a = att[b * E + e];
+  float s = 0.f;
+  for (int j = lane; j < H; j += 64) {
+    const float g = dout[(long long)b * H + j];
+    const long long o = (long long)b * E * H + e * H + j;
+    dh[o] = g * a;
+    s = fmaf(g, h[o], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) datt[b * E + e] = s;
+}
+
+// CE of loss.py:5-15: sum_b -log_softmax(pred)[b, target[b]] / B.  One wave per row; writes probs for the
+// backward pass and per-row losses; a second tiny kernel reduces them in row order.
+__global__ __launch_bounds__(64) void ce_rows_kernel(const float* logits, const int64_t* target, float* probs,
+                                                     float* row_loss, int B, int Cn) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float mx = -INFINITY;
+  for (int c = lane; c < Cn; c += 64) mx = fmaxf(mx, logits[(long long)b * Cn + c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < Cn; c += 64) s += expf(logits[(long long)b * Cn + c] - mx);
+  s = wave_sum(s);
+  const float lse = mx + logf(s);
+  for (int c = lane; c < Cn; c += 64) probs[(long long)b * Cn + c] = expf(logits[(long long)b * Cn + c] - lse);
+  if (lane == 0) row_loss[b] = lse - logits[(long long)b * Cn + (int)target[b]];
+}
+__global__ void mse_rows_kernel(const float* pred, const float* target, float* row_loss, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    const float d = pred[b] - target[b];
+    row_loss[b] = d * d;
+  }
+}
+__global__ void mean_rows_kernel(const float* row_loss, int B, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += row_loss[b];
+    out[0] = s / (float)B;
+  }
+}
+// dlogits = gscale * (probs - onehot) / B
+__global__ void ce_bwd_kernel(const float* probs, const int64_t* target, const float* gout, float* dlogits, int B, int Cn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Cn) return;
+  const int b = i / Cn, c = i % Cn;
+  dlogits[i] = gout[0] * (probs[i] - (c == (int)target[b] ? 1.f : 0.f)) / (float)B;
+}
+__global__ void mse_bwd_kernel(const float* pred, const float* target, const float* gout, float* dpred, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) dpred[b] = gout[0] * 2.f * (pred[b] - target[b]) / (float)B;
+}
+
+// torch.optim.Adam (amsgrad=False, maximize=False, L2 weight_decay added to the gradient) — main-release.py:205.
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                            float eps, float wd, float bc1, float bc2_sqrt, float clip) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);  // clip_grad_value_ (main-release.py:64-65)
+    gi = fmaf(wd, p[i], gi);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+
+static inline unsigned g1(long long n) {
+  long long g = cdiv(n, 256);
+  return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace mer
+
+using namespace mer;
+
+extern "C" int mer_relu_bwd(const float* dy, const float* y, float* dz, long long n, mer_stream_t stream) {
+  MER_REQUIRE(dy && y && dz && n > 0, MER_EINVAL, "mer_relu_bwd: bad args");
+  relu_bwd_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(dy, y, dz, n);
+  return check_launch("relu_bwd");
+}
+extern "C" int mer_colsum(const float* x, int M, int N, long long ldx, float* out, int accumulate, mer_stream_t stream) {
+  MER_REQUIRE(x && out && M > 0 && N > 0, MER_EINVAL, "mer_colsum: bad args");
+  colsum_kernel<<<(unsigned)cdiv(N, 64), 64, 0, (hipStream_t)stream>>>(x, M, N, ldx, out, accumulate);
+  return check_launch("colsum");
+}
+extern "C" int mer_dropout(const float* x, const uint8_t* keep, float scale, float* out, long long n, mer_stream_t stream) {
+  MER_REQUIRE(x && keep && out && n > 0, MER_EINVAL, "mer_dropout: bad args");
+  dropout_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(x, keep, scale, out, n);
+  return check_launch("dropout");
+}
+extern "C" int mer_fuse_fwd(const float* h, const float* att, float* out, int B, int H, int E, mer_stream_t stream) {
+  MER_REQUIRE(h && att && out && B > 0 && H > 0 && E > 0, MER_EINVAL, "mer_fuse_fwd: bad args");
+  fuse_fwd_kernel<<<g1((long long)B * H), 256, 0, (hipStream_t)stream>>>(h, att, out, B, H, E);
+  return check_launch("fuse_fwd");
+}
+extern "C" int mer_fuse_bwd(const float* dout, const float* h, const float* att, float* dh, float* datt, int B, int H, int E,
+                            mer_stream_t stream) {
+  MER_REQUIRE(dout && h && att && dh && datt && B > 0, MER_EINVAL, "mer_fuse_bwd: bad args");
+  fuse_bwd_kernel<<<B * E, 64, 0, (hipStream_t)stream>>>(dout, h, att, dh, datt, B, H, E);
+  return check_launch("fuse_bwd");
+}
+extern "C" int mer_ce_loss(const float* logits, const int64_t* target, int B, int C, float* probs, float* row_scratch,
+                           float* loss, mer_stream_t stream) {
+  MER_REQUIRE(logits && target && probs && row_scratch && loss && B > 0 && C > 0, MER_EINVAL, "mer_ce_loss: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  ce_rows_kernel<<<B, 64, 0, st>>>(logits, target, probs, row_scratch, B, C);
+  mean_rows_kernel<<<1, 64, 0, st>>>(row_scratch, B, loss);
+  return check_launch("ce_loss");
+}
+extern "C" int mer_ce_loss_bwd(const float* probs, const int64_t* target, const float* gout, float* dlogits, int B, int C,
+                               mer_stream_t stream) {
+  MER_REQUIRE(probs && target && gout && dlogits && B > 0, MER_EINVAL, "mer_ce_loss_bwd: bad args");
+  ce_bwd_kernel<<<(unsigned)cdiv((long long)B * C, 256), 256, 0, (hipStream_t)stream>>>(probs, target, gout, dlogits, B, C);
+  return check_launch("ce_loss_bwd");
+}
+extern "C" int mer_mse_loss(const float* pred, const float* target, int B, float* row_scratch, float* loss, mer_stream_t stream) {
+  MER_REQUIRE(pred && target && row_scratch && loss && B > 0, MER_EINVAL, "mer_mse_loss: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  mse_rows_kernel<<<(unsigned)cdiv(B, 256), 256, 0, st>>>(pred, target, row_scratch, B);
+  mean_rows_kernel<<<1, 64, 0, st>>>(row_scratch, B, loss);
+  return check_launch("mse_loss");
+}
+extern "C" int mer_mse_loss_bwd(const float* pred, const float* target, const float* gout, float* dpred, int B, mer_stream_t stream) {
+  MER_REQUIRE(pred && target && gout && dpred && B > 0, MER_EINVAL, "mer_mse_loss_bwd: bad args");
+  mse_bwd_kernel<<<(unsigned)cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(pred, target, gout, dpred, B);
+  return check_launch("mse_loss_bwd");
+}
+extern "C" int mer_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float clip_value, mer_stream_t stream) {
+  MER_REQUIRE(p && g && m && v && n > 0 && step >= 1, MER_EINVAL, "mer_adam_step: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  adam_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, clip_value);
+  return check_launch("adam_step");
+}

@@ -1,0 +1,116 @@
+"""Audio feature extraction — mirror of MERBench/feature_extraction/audio/extract_audio_huggingface.py:40-113.
+
+Same `extract(model_name, audio_files, save_dir, feature_level, gpu)` signature and the same
+`<save_dir>/<clip>.npy` outputs (UTT: [D] float32; FRAME: [B*T, D] float32).  What differs is how the work
+reaches the GPU: clips are bucketed by (chunked) length and pushed through the HIP HuBERT/wav2vec2 encoder
+in batches; the last-4-layer sum and the utterance mean run on the GPU, so only [D] (or [T,D]) floats come
+back per clip instead of 13 x [T,D] hidden states.
+"""
+import math
+import os
+import time
+import wave
+
+import numpy as np
+import torch
+
+MAXLEN = 16000 * 10
+
+
+def split_into_batch(input_values, maxlen=MAXLEN):
+    """[1, L] -> [ceil(L/maxlen), maxlen] zero-padded when L > maxlen, else unchanged (reference :40-50)."""
+    if len(input_values[0]) <= maxlen:
+        return input_values
+    bs, wavlen = input_values.shape
+    assert bs == 1
+    tgtlen = math.ceil(wavlen / maxlen) * maxlen
+    batches = torch.zeros((1, tgtlen))
+    batches[:, :wavlen] = input_values
+    return batches.view(-1, maxlen)
+
+
+def wav2vec2_normalize(samples, do_normalize=True):
+    """Wav2Vec2FeatureExtractor.__call__ on one utterance (reference :94; HF:wav2vec2/feature_extraction_wav2vec2.py:78-97,
+    :207-215): zero-mean / unit-variance on the raw array, result as float32 [1, L]."""
+    x = np.asarray(samples, dtype=np.float32)  # HF casts float64 -> float32 first, then normalises in float32
+    if do_normalize:
+        x = (x - x.mean()) / np.sqrt(x.var() + 1e-7)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None]
+
+
+def read_audio(path):
+    """(samples float64 in [-1,1), sample_rate) — soundfile when importable, else stdlib PCM16 WAV."""
+    try:
+        import soundfile as sf
+        return sf.read(path)
+    except ImportError:
+        with wave.open(path, 'rb') as w:
+            assert w.getsampwidth() == 2, 'only PCM16 wav supported without soundfile'
+            raw = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float64) / 32768.0
+            if w.getnchannels() > 1:
+                raw = raw.reshape(-1, w.getnchannels())
+            return raw, w.getframerate()
+
+
+def save_feature(csv_file, feature, feature_level):
+    """np.save rules of reference :103-110."""
+    if feature_level == 'UTTERANCE':
+        feature = np.array(feature).squeeze()
+        if len(feature.shape) != 1:
+            feature = np.mean(feature, axis=0)
+    np.save(csv_file, feature)
+
+
+def load_model(model_name, gpu, precision="balanced"):
+    """AutoModel checkpoint under config.PATH_TO_PRETRAINED_MODELS/transformers/<model_name> -> HIP encoder."""
+    from transformers import AutoModel, Wav2Vec2FeatureExtractor
+    from .. import config
+    from ..encoders import HipHubertModel
+    model_file = os.path.join(config.PATH_TO_PRETRAINED_MODELS, f'transformers/{model_name}')
+    hf = AutoModel.from_pretrained(model_file)
+    fe = Wav2Vec2FeatureExtractor.from_pretrained(model_file)
+    return HipHubertModel.from_hf(hf, device=f'cuda:{max(gpu, 0)}', precision=precision), fe.do_normalize
+
+
+def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
+            reader=read_audio):
+    start_time = time.time()
+    if model is None:
+        model, do_normalize = load_model(model_name, gpu)
+    os.makedirs(save_dir, exist_ok=True)
+    # bucket clips by the shape they have after split_into_batch: equal-length rows batch without any masking
+    # (the reference never masks audio, and GroupNorm runs over the whole row, so padding would change results)
+    buckets = {}
+    for audio_file in audio_files:
+        samples, sr = reader(audio_file)
+        assert sr == 16000, 'currently, we only test on 16k audio'
+        iv = split_into_batch(wav2vec2_normalize(samples, do_normalize))
+        buckets.setdefault(tuple(iv.shape), []).append((os.path.basename(audio_file)[:-4], iv))
+
+    def flush(items):
+        rows = torch.cat([iv for _, iv in items], 0)
+        chunks = [iv.shape[0] for _, iv in items]
+        T = model.out_frames(rows.shape[1])
+        if feature_level == 'UTTERANCE':
+            pooled = model.extract_utterance(rows, clip_chunks=chunks).cpu().numpy()
+            for (vid, _), feat in zip(items, pooled):
+                save_feature(os.path.join(save_dir, f'{vid}.npy'), feat, feature_level)
+        else:
+            _, frames, _ = model.forward_raw(rows, frames=True)
+            frames = frames.cpu().numpy()
+            r = 0
+            for (vid, _), n in zip(items, chunks):
+                save_feature(os.path.join(save_dir, f'{vid}.npy'), frames[r * T:(r + n) * T], feature_level)
+                r += n
+
+    for shape, items in buckets.items():
+        cur, rows = [], 0
+        for it in items:
+            if cur and rows + it[1].shape[0] > batch_rows:
+                flush(cur)
+                cur, rows = [], 0
+            cur.append(it)
+            rows += it[1].shape[0]
+        if cur:
+            flush(cur)
+    print(f'Total time used: {time.time() - start_time:.1f}s.')

@@ -1,0 +1,114 @@
+"""Text feature extraction — mirror of MERBench/feature_extraction/text/extract_text_huggingface.py:90-252 for the
+encoder-only (BERT / RoBERTa family) models.  Special-token probing and .npy rules are the reference's;
+sentences are right-padded into batches with per-row key-length masking on the HIP encoder."""
+import os
+import time
+
+import numpy as np
+import torch
+
+PROBE = '今天天气真好'
+
+
+def find_start_end_pos(tokenizer):
+    """How many leading (0..2) / trailing (0..2) special tokens to strip (reference :90-114; integer path)."""
+    input_ids = tokenizer(PROBE, return_tensors='pt')['input_ids'][0]
+    start, end = None, None
+    for start in range(0, 3, 1):
+        outputs = tokenizer.decode(input_ids[start:]).replace(' ', '')
+        if outputs == PROBE:
+            print(f'start: {start};  end: {end}')
+            return start, None
+        if outputs.startswith(PROBE):
+            break
+    for end in range(-1, -3, -1):
+        outputs = tokenizer.decode(input_ids[start:end]).replace(' ', '')
+        if outputs == PROBE:
+            break
+    assert tokenizer.decode(input_ids[start:end]).replace(' ', '') == PROBE
+    print(f'start: {start};  end: {end}')
+    return start, end
+
+
+def find_batchpos_embdim(tokenizer, model, gpu=-1):
+    """(batch axis, feature dim) via a probe sentence (reference :118-135).  HIP encoders are batch-first."""
+    inputs = tokenizer(PROBE, return_tensors='pt')
+    outputs = model(**inputs, output_hidden_states=True).hidden_states
+    outputs = torch.stack(outputs)[[-1]].sum(dim=0).cpu().numpy()
+    batch_pos = 0 if outputs.shape[0] == 1 else (1 if outputs.shape[1] == 1 else None)
+    assert batch_pos in [0, 1]
+    print(f'batch_pos:{batch_pos}, feature_dim:{outputs.shape[2]}')
+    return batch_pos, outputs.shape[2]
+
+
+def save_embeddings(csv_file, embeddings, feature_level, feature_dim):
+    """np.save rules of reference :235-249 (empty sentence -> float64 zeros)."""
+    embeddings = np.array(embeddings).squeeze()
+    if feature_level == 'FRAME':
+        if len(embeddings) == 0:
+            embeddings = np.zeros((1, feature_dim))
+        elif len(embeddings.shape) == 1:
+            embeddings = embeddings[np.newaxis, :]
+    else:
+        if len(embeddings) == 0:
+            embeddings = np.zeros((feature_dim,))
+        elif len(embeddings.shape) == 2:
+            embeddings = np.mean(embeddings, axis=0)
+    np.save(csv_file, embeddings)
+
+
+def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, punc_case=None, language='chinese',
+                      model_dir=None, model=None, tokenizer=None, batch_size=64):
+    import pandas as pd
+    print('=' * 30 + f' Extracting "{model_name}" ' + '=' * 30)
+    start_time = time.time()
+    if punc_case is None and language == 'chinese' and model_dir is None:
+        save_dir = os.path.join(save_dir, f'{model_name}-{feature_level[:3]}')
+    elif punc_case is not None:
+        save_dir = os.path.join(save_dir, f'{model_name}-punc{punc_case}-{feature_level[:3]}')
+    elif language == 'english':
+        save_dir = os.path.join(save_dir, f'{model_name}-langeng-{feature_level[:3]}')
+    elif model_dir is not None:
+        save_dir = os.path.join(save_dir, f'{"-".join(model_dir.split("/")[-2:])}-{model_name}-{feature_level[:3]}')
+    os.makedirs(save_dir, exist_ok=True)
+    if model is None:
+        from transformers import AutoModel, AutoTokenizer
+        from .. import config
+        from ..encoders import HipBertModel
+        if model_dir is None:
+            model_dir = os.path.join(config.PATH_TO_PRETRAINED_MODELS, f'transformers/{model_name}')
+        model = HipBertModel.from_hf(AutoModel.from_pretrained(model_dir), device=f'cuda:{max(gpu, 0)}')
+        tokenizer = AutoTokenizer.from_pretrained(model_dir, use_fast=False)
+    start, end = find_start_end_pos(tokenizer)
+    batch_pos, feature_dim = find_batchpos_embdim(tokenizer, model, gpu)
+    pad_id = model.config.pad_token_id if model.config.pad_token_id is not None else 0
+    df = pd.read_csv(trans_dir)
+    todo = []
+    for idx, row in df.iterrows():
+        sentence = row['chinese'] if language == 'chinese' else row['english']
+        if pd.isna(sentence) == False and len(sentence) > 0:  # noqa: E712 (reference's test)
+            ids = tokenizer(sentence, return_tensors='pt')['input_ids'][0]
+            todo.append((row['name'], ids))
+        else:
+            save_embeddings(os.path.join(save_dir, f"{row['name']}.npy"), [], feature_level, feature_dim)
+    todo.sort(key=lambda it: len(it[1]))
+    for i in range(0, len(todo), batch_size):
+        chunk = todo[i:i + batch_size]
+        T = max(len(ids) for _, ids in chunk)
+        batch = torch.full((len(chunk), T), pad_id, dtype=torch.int64)
+        lens = []
+        for r, (_, ids) in enumerate(chunk):
+            batch[r, :len(ids)] = ids
+            lens.append(len(ids))
+        if feature_level == 'FRAME':
+            _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
+            frames = frames.cpu().numpy().reshape(len(chunk), T, -1)
+            for r, (name, _) in enumerate(chunk):
+                e = lens[r] + end if end is not None else lens[r]
+                save_embeddings(os.path.join(save_dir, f'{name}.npy'), frames[r, start:e], feature_level, feature_dim)
+        else:
+            pooled = model.extract_utterance(batch, lens, start, end).cpu().numpy()
+            for r, (name, _) in enumerate(chunk):
+                n_tok = (lens[r] + (end if end is not None else 0)) - start
+                save_embeddings(os.path.join(save_dir, f'{name}.npy'), pooled[r] if n_tok > 0 else [], feature_level, feature_dim)
+    print(f'Total {len(df)} files done! Time used ({model_name}): {time.time() - start_time:.1f}s.')

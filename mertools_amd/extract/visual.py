@@ -1,0 +1,106 @@
+"""Visual feature extraction — mirror of MERBench/feature_extraction/visual/extract_vision_huggingface.py:29-189
+(CLIP branch).  Frame sampling / batching / save rules are the reference's; the vision tower runs on the HIP
+encoder, frames of several videos share a batch, and the per-video frame mean is taken on the GPU."""
+import math
+import os
+
+import numpy as np
+import torch
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def func_read_frames(face_dir, vid):
+    npy_path = os.path.join(face_dir, vid, f'{vid}.npy')
+    assert os.path.exists(npy_path), f'Error: {vid} does not have frames.npy!'
+    return np.load(npy_path)
+
+
+def resample_frames_uniform(frames, nframe=16):
+    """Uniform index pick, last index repeated when the video is short (reference :44-56; integer path, bit-exact)."""
+    vlen = len(frames)
+    n_frms_update = min(nframe, vlen)
+    indices = np.arange(0, vlen, vlen / n_frms_update).astype(int).tolist()
+    while len(indices) < nframe:
+        indices.append(indices[-1])
+    indices = indices[:nframe]
+    assert len(indices) == nframe, f'{indices}, {vlen}, {nframe}'
+    return frames[indices]
+
+
+def split_into_batch(inputs, bsize=32):
+    return [inputs[ii * bsize:(ii + 1) * bsize] for ii in range(math.ceil(len(inputs) / bsize))]
+
+
+def clip_preprocess(frames_bgr, size=224):
+    """func_opencv_to_image + CLIPImageProcessor (reference :29-31,116): BGR->RGB, resize shortest edge to `size`
+    (PIL bicubic), centre crop, /255, normalise.  uint8 [N,h,w,3] -> float32 [N,3,size,size]."""
+    from PIL import Image
+    out = np.empty((len(frames_bgr), 3, size, size), dtype=np.float32)
+    mean = np.array(CLIP_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(CLIP_STD, dtype=np.float32)[:, None, None]
+    for i, f in enumerate(frames_bgr):
+        img = Image.fromarray(np.ascontiguousarray(f[:, :, ::-1]))
+        w, h = img.size
+        if (w, h) != (size, size):
+            short, long = (w, h) if w <= h else (h, w)
+            new_short, new_long = size, int(size * long / short)
+            nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+            img = img.resize((nw, nh), resample=Image.BICUBIC)
+            left, top = (nw - size) // 2, (nh - size) // 2
+            img = img.crop((left, top, left + size, top + size))
+        arr = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+        out[i] = (arr - mean) / std
+    return torch.from_numpy(out)
+
+
+def save_embeddings(save_file, embeddings, feature_level, embedding_dim):
+    """np.save rules of reference :171-189 (incl. the zero fallback for videos without frames)."""
+    embeddings = np.array(embeddings).squeeze()
+    if feature_level == 'FRAME':
+        if len(embeddings) == 0:
+            embeddings = np.zeros((1, embedding_dim))
+        elif len(embeddings.shape) == 1:
+            embeddings = embeddings[np.newaxis, :]
+    else:
+        if len(embeddings) == 0:
+            embeddings = np.zeros((embedding_dim,))
+        elif len(embeddings.shape) == 2:
+            embeddings = np.mean(embeddings, axis=0)
+    np.save(save_file, embeddings)
+
+
+def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames):
+    """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video."""
+    os.makedirs(save_dir, exist_ok=True)
+    vids = vids if vids is not None else os.listdir(face_dir)
+    embedding_dim = -1
+    pending, nframes = [], 0
+
+    def flush():
+        nonlocal pending, nframes, embedding_dim
+        if not pending:
+            return
+        px = torch.cat([p for _, p in pending], 0)
+        counts = [p.shape[0] for _, p in pending]
+        feats = model.get_image_features(px).cpu().numpy()  # [sum(frames), P]
+        embedding_dim = max(embedding_dim, feats.shape[-1])
+        r = 0
+        for (vid, _), n in zip(pending, counts):
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), feats[r:r + n], feature_level, embedding_dim)
+            r += n
+        pending, nframes = [], 0
+
+    for vid in vids:
+        frames = reader(face_dir, vid)
+        if len(frames) == 0:
+            flush()
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
+            continue
+        px = clip_preprocess(frames, model.config.vision_config.image_size)
+        if nframes + len(px) > frames_per_batch:
+            flush()
+        pending.append((vid, px))
+        nframes += len(px)
+    flush()

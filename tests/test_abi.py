@@ -1,0 +1,83 @@
+"""The C-ABI library loads (no GPU needed), exports every symbol include/mer_hip.h declares, the ctypes binding
+covers all of them with matching struct layouts, and argument validation fails loudly without touching a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mertools_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from mertools_amd import build
+        build.build()
+    return _lib.lib()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mer_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mer_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from mertools_amd import _lib
+    names = _declared()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in mer_hip.h but not exported: {missing}"
+    unbound = [n for n in names if n not in _lib._PROTOS]
+    assert not unbound, f"declared in mer_hip.h but missing from the ctypes binding: {unbound}"
+    stale = [n for n in _lib._PROTOS if n not in names]
+    assert not stale, f"bound but not declared: {stale}"
+
+
+def test_struct_layouts_match(lib):
+    from mertools_amd import _lib
+    pairs = {"mer_gemm16_args": _lib.GemmArgs, "mer_w16": _lib.W16, "mer_tf_layer": _lib.TfLayer, "mer_tf_config": _lib.TfConfig,
+             "mer_hubert_config": _lib.HubertConfig, "mer_hubert_weights": _lib.HubertWeights, "mer_vit_config": _lib.VitConfig,
+             "mer_vit_weights": _lib.VitWeights, "mer_bert_config": _lib.BertConfig, "mer_bert_weights": _lib.BertWeights}
+    for name, cls in pairs.items():
+        assert lib.mer_abi_sizeof(name.encode()) == ctypes.sizeof(cls), name
+
+
+def test_version_and_target(lib):
+    assert lib.mer_target_arch() == b"gfx950"
+    assert b"mer_hip" in lib.mer_version()
+
+
+def test_bad_arguments_fail_loudly_without_a_gpu(lib):
+    from mertools_amd import _lib
+    g = _lib.GemmArgs()
+    assert lib.mer_gemm16(ctypes.byref(g), None) < 0
+    assert b"bad shape" in lib.mer_last_error()
+    assert lib.mer_attention(None, None, None, 0, None, None, 0, 1, 1, 1, ctypes.c_float(1.0), None, 0, None) < 0
+    assert lib.mer_layernorm(None, 0, None, None, ctypes.c_float(1e-5), 0, 0, 0, None, 0, None, None, 0, 0, None) < 0
+    assert lib.mer_set_option(b"no_such_option", 1) < 0
+    with pytest.raises(_lib.MerError):
+        _lib.check(-1, "x")
+
+
+def test_product_has_no_cpu_path():
+    import torch
+    from mertools_amd import _lib, ops
+    with pytest.raises(_lib.MerError):
+        ops.split16(torch.zeros(8))
+    from mertools_amd.fusion_ops import LinearFn
+    with pytest.raises(_lib.MerError):
+        LinearFn.apply(torch.zeros(2, 4), torch.zeros(3, 4), None, False)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "mertools_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, f"product files import the oracle: {bad}"

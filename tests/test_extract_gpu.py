@@ -1,0 +1,115 @@
+"""End-to-end extractor drivers (GPU): wav / frame .npy / transcription csv on disk -> <clip>.npy features with the
+reference's file layout, compared with the oracle's per-clip (batch-of-one, as the reference loops) result."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders_ref as R
+from oracle import weights as W
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _write_wav(path, x):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes((np.clip(x, -1, 1 - 1 / 32768) * 32768).astype("<i2").tobytes())
+
+
+@pytest.mark.parametrize("level", ["UTTERANCE", "FRAME"])
+def test_audio_extract_files(dev, tmp_path, level):
+    from mertools_amd.encoders import HipHubertModel
+    from mertools_amd.extract import audio
+    cfg = W.hubert_config("tiny")
+    sd = W.hubert_state_dict(cfg, 1)
+    model = HipHubertModel(sd, cfg, device=dev, precision="accurate")
+    rng = np.random.RandomState(0)
+    lens = [6000, 9000, 6000, 25000]  # two equal-length clips batch together; 25000 > maxlen(below) is chunked
+    files = []
+    for i, L in enumerate(lens):
+        p = str(tmp_path / f"clip{i}.wav")
+        _write_wav(p, rng.randn(L) * 0.1)
+        files.append(p)
+    audio.MAXLEN = 10000
+    save_dir = str(tmp_path / f"feat-{level[:3]}")
+    old = audio.split_into_batch.__defaults__
+    audio.split_into_batch.__defaults__ = (10000,)
+    try:
+        audio.extract("hubert-tiny", files, save_dir, level, 0, model=model)
+        for i, p in enumerate(files):
+            samples, sr = audio.read_audio(p)
+            iv = audio.split_into_batch(audio.wav2vec2_normalize(samples))
+            hs = R.hubert_hidden_states(sd, vars(cfg), iv)
+            feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).view(-1, cfg.hidden_size).numpy()
+            ref = feat.mean(0) if level == "UTTERANCE" else feat
+            out = np.load(os.path.join(save_dir, f"clip{i}.npy"))
+            assert out.shape == ref.shape and out.dtype == np.float32, (out.shape, ref.shape)
+            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < 3e-4, i
+    finally:
+        audio.split_into_batch.__defaults__ = old
+
+
+def test_visual_extract_files(dev, tmp_path):
+    from mertools_amd.encoders import HipCLIPModel
+    from mertools_amd.extract import visual
+    cfg = W.clip_config("tiny")
+    sd = W.clip_state_dict(cfg, 3)
+    model = HipCLIPModel(sd, cfg, device=dev, precision="accurate")
+    rng = np.random.RandomState(1)
+    face_dir = tmp_path / "openface_face"
+    counts = {"v0": 5, "v1": 1, "v2": 9}
+    for vid, n in counts.items():
+        (face_dir / vid).mkdir(parents=True)
+        np.save(face_dir / vid / f"{vid}.npy", rng.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8))
+    for level in ["UTTERANCE", "FRAME"]:
+        save_dir = str(tmp_path / f"clip-{level[:3]}")
+        visual.extract(model, str(face_dir), save_dir, level, vids=sorted(counts), frames_per_batch=8)
+        for vid, n in counts.items():
+            frames = np.load(face_dir / vid / f"{vid}.npy")
+            px = visual.clip_preprocess(frames, 64)
+            ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px).numpy()
+            out = np.load(os.path.join(save_dir, f"{vid}.npy"))
+            if level == "UTTERANCE":
+                ref = ref.mean(0) if n > 1 else ref.squeeze()
+                assert out.shape == (cfg.projection_dim,)
+            else:
+                assert out.shape == (n, cfg.projection_dim)
+            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref).view(out.shape))[0] < 3e-4, (vid, level)
+
+
+def test_text_extract_files(dev, tmp_path):
+    tr = pytest.importorskip("transformers")
+    import pandas as pd
+    from mertools_amd.encoders import HipBertModel
+    from mertools_amd.extract import text
+    chars = list("今天气真好你我他是的不很高兴难过")
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + chars
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab), encoding="utf-8")
+    tok = tr.BertTokenizer(str(tmp_path / "vocab.txt"))
+    cfg = W.bert_config("tiny", model_type="bert", pad_token_id=0, type_vocab_size=2, layer_norm_eps=1e-12, vocab_size=len(vocab))
+    sd = W.bert_state_dict(cfg, 4)
+    model = HipBertModel(sd, cfg, device=dev, precision="accurate")
+    rows = [("s0", "今天天气真好"), ("s1", "我很高兴"), ("s2", float("nan")), ("s3", "他不是很难过的你好"), ("s4", "好")]
+    csv = str(tmp_path / "trans.csv")
+    pd.DataFrame([dict(name=n, chinese=s, english="x") for n, s in rows]).to_csv(csv, index=False)
+    for level in ["UTTERANCE", "FRAME"]:
+        text.extract_embedding("bert-tiny", csv, str(tmp_path / "feat"), level, gpu=0, model=model, tokenizer=tok, batch_size=3)
+        save_dir = str(tmp_path / "feat" / f"bert-tiny-{level[:3]}")
+        for name, s in rows:
+            out = np.load(os.path.join(save_dir, f"{name}.npy"))
+            if not isinstance(s, str):
+                assert out.dtype == np.float64 and not out.any() and out.shape == ((cfg.hidden_size,) if level == "UTTERANCE" else (1, cfg.hidden_size))
+                continue
+            ids = tok(s, return_tensors="pt")["input_ids"]
+            hs = R.bert_hidden_states(sd, dict(vars(cfg), roberta=False), ids, torch.ones_like(ids))
+            emb = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)[0, 1:-1].numpy()
+            ref = emb.mean(0) if level == "UTTERANCE" else emb
+            assert out.shape == ref.shape and out.dtype == np.float32, (name, out.shape, ref.shape)
+            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < 3e-4, (name, level)

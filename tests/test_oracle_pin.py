@@ -1,0 +1,104 @@
+"""Pins the CPU oracle (oracle/) before anything trusts it:
+  * against golden vectors produced by the reference's own code / the HF classes it calls (tests/golden/*.npz);
+  * against the live HuggingFace classes when `transformers` is importable (same weights, same inputs)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders_ref as R
+from oracle import fusion_ref as FR
+from oracle import host_ref as HR
+from oracle import weights as W
+from util import rel_err
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _g(name):
+    return np.load(os.path.join(G, name), allow_pickle=True)
+
+
+def test_encoder_oracle_matches_hf_goldens():
+    g = _g("encoders_tiny_hf.npz")
+    cfg = W.hubert_config("tiny")
+    hs = R.hubert_hidden_states(W.hubert_state_dict(cfg, 1), vars(cfg), W.synth_audio(3, 8000, seed=5))
+    assert rel_err(hs[0], torch.from_numpy(g["hubert_hs0"]))[0] < 2e-6
+    assert rel_err(hs[-1], torch.from_numpy(g["hubert_hs_last"]))[0] < 2e-6
+    utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
+    assert rel_err(utt, torch.from_numpy(g["hubert_utt"]))[0] < 2e-6
+    cc = W.clip_config("tiny")
+    feats = R.clip_image_features(W.clip_state_dict(cc, 3), dict(vars(cc.vision_config), projection_dim=cc.projection_dim), W.synth_frames(5, 64, seed=7))
+    assert rel_err(feats, torch.from_numpy(g["clip_feats"]))[0] < 2e-6
+    bc = W.bert_config("tiny")
+    ids = W.synth_tokens(4, 24, vocab=300, seed=8, bos=3, eos=4)
+    hs = R.bert_hidden_states(W.bert_state_dict(bc, 4), dict(vars(bc), roberta=True), ids, torch.ones_like(ids))
+    f = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
+    assert rel_err(f, torch.from_numpy(g["roberta_frame"]))[0] < 2e-6
+    assert rel_err(f[:, 1:-1].mean(1), torch.from_numpy(g["roberta_utt"]))[0] < 2e-6
+
+
+def test_encoder_oracle_matches_live_hf_stable_layer_norm():
+    """HuBERT-large style front end / encoder (LayerNorm convs with bias, pre-LN blocks) against the live HF class."""
+    tr = pytest.importorskip("transformers")
+    cfg = W.hubert_config("tiny", feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)
+    sd = W.hubert_state_dict(cfg, 2)
+    hc = tr.HubertConfig(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
+                         num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, attn_implementation="eager",
+                         feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)
+    m = tr.HubertModel(hc).eval()
+    m.load_state_dict(sd, strict=False)
+    wav = W.synth_audio(2, 6000, seed=9)
+    with torch.no_grad():
+        hs = m(wav, output_hidden_states=True).hidden_states
+    ref = R.hubert_hidden_states(sd, vars(cfg), wav)
+    for a, b in zip(ref, hs):
+        assert rel_err(a, b)[0] < 2e-6
+
+
+def test_fusion_oracle_matches_reference_goldens():
+    g = _g("fusion_attention.npz")
+    sd = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_")}
+    xs = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("x_")}
+    f, e, v = FR.attention_forward(sd, {k: x[0] for k, x in xs.items()})
+    assert rel_err(f, torch.from_numpy(g["out_features"]))[0] < 1e-6
+    assert rel_err(e, torch.from_numpy(g["out_emos_out"]))[0] < 1e-6
+    assert rel_err(v, torch.from_numpy(g["out_vals_out"]))[0] < 1e-6
+    assert g["out_interloss"].dtype == np.int64 and int(g["out_interloss"]) == 0
+    losses, final, grads0 = FR.train_steps(sd, xs, torch.from_numpy(g["emos"]), torch.from_numpy(g["vals"]), len(g["losses"]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-6)
+    for k in sd:
+        assert rel_err(grads0[k], torch.from_numpy(g["grad0_" + k]))[0] < 1e-5, k
+        assert rel_err(final[k], torch.from_numpy(g["final_" + k]))[0] < 1e-5, k
+    gl = _g("losses.npz")
+    assert abs(FR.ce_loss(torch.from_numpy(gl["pred"]), torch.from_numpy(gl["tgt"])).item() - float(gl["ce"])) < 1e-6
+    assert abs(FR.mse_loss(torch.from_numpy(gl["vp"]), torch.from_numpy(gl["vt"])).item() - float(gl["mse"])) < 1e-6
+
+
+def test_host_oracle_matches_reference_goldens_bit_exact():
+    g = _g("index_paths.npz")
+    for k in [k for k in g.files if k.startswith("resample_")]:
+        _, vlen, n = k.split("_")
+        assert HR.resample_indices(int(vlen), int(n)) == g[k].tolist(), k
+    assert HR.visual_batches(70, 32) == g["vsplit_70_32"].tolist()
+    x = np.arange(1, 26, dtype=np.float32)[None]
+    assert np.array_equal(HR.audio_split(x, 10), g["asplit_25_10"])
+    assert np.array_equal(HR.audio_split(x, 30), g["asplit_25_30"])
+    assert np.array_equal(HR.audio_split(x[:, :20], 10), g["asplit_20_10"])
+    for k in [k for k in g.files if k.startswith("mapfeat_in_")]:
+        _, _, L, dst = k.split("_")
+        out = HR.mapping_feature(g[k].copy(), int(dst))
+        ref = g[f"mapfeat_out_{L}_{dst}"]
+        assert out.shape == ref.shape and out.dtype == ref.dtype and np.array_equal(out, ref), k
+    lab = os.path.join(G, "mer2023_label-6way.npz")
+    for split in ["train", "test1", "test2", "test3"]:
+        names, labels = HR.read_names_labels(lab, split)
+        assert len(names) == int(g[f"labels_{split}_n"]) and names[:5] == g[f"labels_{split}_first_names"].tolist()
+        assert [l["emo"] for l in labels] == g[f"labels_{split}_emo"].tolist()
+        assert [float(l["val"]) for l in labels] == g[f"labels_{split}_val"].tolist()
+    random.seed(2023)
+    folds = HR.random_split_indexes(3373, 5)
+    for i, (tr, ev) in enumerate(folds):
+        assert np.array_equal(np.array(tr), g[f"fold{i}_train"]) and np.array_equal(np.array(ev), g[f"fold{i}_eval"])
