@@ -51,7 +51,7 @@ def test_audio_extract_files(dev, tmp_path, level):
             ref = feat.mean(0) if level == "UTTERANCE" else feat
             out = np.load(os.path.join(save_dir, f"clip{i}.npy"))
             assert out.shape == ref.shape and out.dtype == np.float32, (out.shape, ref.shape)
-            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < 3e-4, i
+            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < TOL, i
     finally:
         audio.split_into_batch.__defaults__ = old
 
@@ -81,7 +81,7 @@ def test_visual_extract_files(dev, tmp_path):
                 assert out.shape == (cfg.projection_dim,)
             else:
                 assert out.shape == (n, cfg.projection_dim)
-            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref).view(out.shape))[0] < 3e-4, (vid, level)
+            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref).view(out.shape))[0] < TOL, (vid, level)
 
 
 def test_text_extract_files(dev, tmp_path):
@@ -112,4 +112,4 @@ def test_text_extract_files(dev, tmp_path):
             emb = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)[0, 1:-1].numpy()
             ref = emb.mean(0) if level == "UTTERANCE" else emb
             assert out.shape == ref.shape and out.dtype == np.float32, (name, out.shape, ref.shape)
-            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < 3e-4, (name, level)
+            assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < TOL, (name, level)
