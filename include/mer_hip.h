@@ -82,7 +82,7 @@ typedef struct {
   int nbatch, nb_inner;
   long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int passes;   /* 1 = a_hi*w_hi; 2 = + a_hi*w_lo (needs w_lo); 3 = + a_lo*w_hi (needs a_lo too) */
-  int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N) */
+  int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N); 3 = 256x256 (8 waves, 1 workgroup/CU) */
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 

@@ -43,24 +43,41 @@ struct Gemm16Params {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS>
+// XOR term of the 16-byte chunk index for tile row `row` (C = chunks per LDS row).  Chosen so that every
+// ds_read_b128 lane group of gfx950 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...; 16 lanes = rows li of two
+// neighbouring k-chunks) lands on 16 distinct 16-byte slots of the 256-byte bank row:
+//   C == 8 (128-B rows, 2 rows per bank row): (row >> 1) & 7
+//   C == 4 ( 64-B rows, 4 rows per bank row): (-(row >> 2)) & 3      [(row >> 2) & 3 is still 2-way]
+template <int C>
+__device__ __forceinline__ int swz_of(int row) {
+  return C == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
   constexpr int NT = WM * WN * 64;
   constexpr int C = BK / 8;            // 16-byte chunks per LDS row
   constexpr int RB = BK * 2;           // LDS row bytes
-  constexpr int R = 256 / RB;          // rows per 256-byte bank row
   constexpr int SM = BM / WM, SN = BN / WN;
   constexpr int TM = SM / 16, TN = SN / 16;
   constexpr int KS = BK / 32;          // MFMA k-steps per slab
+  constexpr bool STAGGER = (WM * WN == 8) && KS == 1;   // two-group phase-shifted schedule (8-wave tiles)
   constexpr int CA = BM * C / NT;      // 16-byte chunks per thread per A plane
   constexpr int CW = BN * C / NT;
   constexpr int ROWS_PER_IT = NT / C;
   constexpr int A_PLANE = BM * RB, W_PLANE = BN * RB;
   constexpr int STAGE = AP * A_PLANE + WP * W_PLANE;
   constexpr int CLD = SN + 4;          // padded fp32 row of the per-wave C staging tile
-  constexpr int CSTAGE = WM * WN * SM * CLD * 4;
-  constexpr int SMEM = (2 * STAGE > CSTAGE) ? 2 * STAGE : CSTAGE;
+  constexpr int EROWS = SM > 64 ? 32 : SM;   // rows of the wave tile staged per epilogue chunk
+  constexpr int CSTAGE = WM * WN * EROWS * CLD * 4;
+  constexpr int SMEM = (NS * STAGE > CSTAGE) ? NS * STAGE : CSTAGE;
+  static_assert(NS >= 2 && (GLDS || NS == 2), "register-staged loader is double-buffered only");
   static_assert(NT % C == 0 && (BM * C) % NT == 0 && (BN * C) % NT == 0, "bad tile/thread split");
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
         const int row = ld_row0 + i * ROWS_PER_IT;
-        const int off = row * RB + ((ld_ch ^ ((row / R) & (C - 1))) << 4);
+        const int off = row * RB + ((ld_ch ^ swz_of<C>(row)) << 4);
         *reinterpret_cast<u32x4*>(base + pl * A_PLANE + off) = ra[pl][i];
       }
 #pragma unroll
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
       for (int i = 0; i < CW; ++i) {
         const int row = ld_row0 + i * ROWS_PER_IT;
-        const int off = row * RB + ((ld_ch ^ ((row / R) & (C - 1))) << 4);
+        const int off = row * RB + ((ld_ch ^ swz_of<C>(row)) << 4);
         *reinterpret_cast<u32x4*>(base + AP * A_PLANE + pl * W_PLANE + off) = rw[pl][i];
       }
   };
@@ -157,12 +174,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       const int row = ld_row0 + i * ROWS_PER_IT;
-      a_src[i] = a_off[i] + ((ld_ch ^ ((row / R) & (C - 1))) << 3);
+      a_src[i] = a_off[i] + ((ld_ch ^ swz_of<C>(row)) << 3);
     }
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
       const int row = ld_row0 + i * ROWS_PER_IT;
-      w_src[i] = w_off[i] + ((ld_ch ^ ((row / R) & (C - 1))) << 3);
+      w_src[i] = w_off[i] + ((ld_ch ^ swz_of<C>(row)) << 3);
     }
   }
   const int wave_row0 = (tid >> 6) * (64 / C);  // first tile row of this wave's 1 KiB piece
@@ -189,74 +206,143 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  if (GLDS) {
-    glds_issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    gload(0);
-    lds_store(0);
-  }
-  __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      if (GLDS) glds_issue((kt + 1) * BK, cur ^ 1);
-      else gload((kt + 1) * BK);
+  // fragment registers of one 32-deep k-step (ks) and the two halves of a k-step: LDS -> registers, registers -> MFMA
+  v8 af[AP][TM], wf[WP][TN];
+  auto load_frags = [&](const char* base, int ks) {
+    const int chunk = ks * 4 + lg;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+      const int row = wm * SM + mt * 16 + li;
+      const int off = row * RB + ((chunk ^ swz_of<C>(row)) << 4);
+#pragma unroll
+      for (int pl = 0; pl < AP; ++pl) af[pl][mt] = *reinterpret_cast<const v8*>(base + pl * A_PLANE + off);
     }
-    const char* base = smem + cur * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      v8 af[AP][TM], wf[WP][TN];
-      const int chunk = ks * 4 + lg;
+    for (int nt = 0; nt < TN; ++nt) {
+      const int row = wn * SN + nt * 16 + li;
+      const int off = row * RB + ((chunk ^ swz_of<C>(row)) << 4);
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt) {
-        const int row = wm * SM + mt * 16 + li;
-        const int off = row * RB + ((chunk ^ ((row / R) & (C - 1))) << 4);
-#pragma unroll
-        for (int pl = 0; pl < AP; ++pl) af[pl][mt] = *reinterpret_cast<const v8*>(base + pl * A_PLANE + off);
-      }
-#pragma unroll
-      for (int nt = 0; nt < TN; ++nt) {
-        const int row = wn * SN + nt * 16 + li;
-        const int off = row * RB + ((chunk ^ ((row / R) & (C - 1))) << 4);
-#pragma unroll
-        for (int pl = 0; pl < WP; ++pl)
-          wf[pl][nt] = *reinterpret_cast<const v8*>(base + AP * A_PLANE + pl * W_PLANE + off);
-      }
+      for (int pl = 0; pl < WP; ++pl)
+        wf[pl][nt] = *reinterpret_cast<const v8*>(base + AP * A_PLANE + pl * W_PLANE + off);
+    }
+  };
+  auto math = [&]() {
+    // one pass at a time over all TM x TN accumulators: back-to-back MFMAs never share an accumulator
+    // (a dependent 16x16x32 MFMA would wait ~2 issue slots for its predecessor)
+    if (AP == 2) {
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-          if (AP == 2) acc[mt][nt] = T16<T>::mfma(af[AP - 1][mt], wf[0][nt], acc[mt][nt]);
-          if (WP == 2) acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[WP - 1][nt], acc[mt][nt]);
-          acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[0][nt], acc[mt][nt]);
-        }
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = T16<T>::mfma(af[AP - 1][mt], wf[0][nt], acc[mt][nt]);
     }
-    if (GLDS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (kt + 1 < nk) {
-      lds_store(cur ^ 1);
+    if (WP == 2) {
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[WP - 1][nt], acc[mt][nt]);
     }
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[0][nt], acc[mt][nt]);
+  };
+  auto compute = [&](const char* base) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      load_frags(base, ks);
+      math();
+    }
+  };
+
+  if (GLDS && STAGGER) {
+    // Two wave groups (waves [0, NW/2) and [NW/2, NW): one wave of each per SIMD) run the SAME loop one barrier
+    // phase apart (group 1 takes one extra barrier up front, group 0 one at the end).  Each iteration is
+    // LOAD(t) |bar| MATH(t) |bar|, so while one group issues its MFMAs the other pulls its fragments out of LDS:
+    // the matrix pipe of every SIMD is fed by one wave at a time and never waits for an LDS read burst.
+    //   phase:     2t          2t+1        2t+2
+    //   group 0:   LOAD(t)     MATH(t)     LOAD(t+1)
+    //   group 1:   MATH(t-1)   LOAD(t)     MATH(t)
+    // DMA for slab t+D goes to stage (t-1) % NS at the top of a wave's iteration t: both groups' LOAD(t-1) ended
+    // (lgkmcnt(0)) before the barrier that precedes it.  Each wave confirms its share of slab t+1 (counted
+    // vmcnt, D-1 slabs stay in flight) before its mid-iteration barrier, i.e. at least one barrier before any
+    // wave of either group reads that slab.
+    constexpr int D = NS - 1;
+    constexpr int LPS = AP * CA + WP * CW;
+    const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN / 2);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nk) glds_issue(s * BK, s);
+    if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (g1) __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = D;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + D < nk;
+      if (more) glds_issue((kt + D) * BK, nxt);
+      load_frags(smem + cur * STAGE, 0);
+      if (more) wait_vmcnt<LPS*(D - 1)>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      math();
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
     __syncthreads();
+  } else
+  if (GLDS) {
+    // NS-stage LDS ring, LDS-DMA prefetch distance D = NS-1 slabs, counted vmcnt: at the end of iteration
+    // t only slab t+1 has to have landed, the newer D-1 slabs stay in flight ACROSS the barrier (raw
+    // s_barrier: __syncthreads() would drain vmcnt(0) because an LDS-DMA is a pending LDS write).
+    // WAR: iteration t refills stage (t+D) % NS == (t-1) % NS, whose readers all passed barrier t-1.
+    constexpr int D = NS - 1;
+    constexpr int LPS = AP * CA + WP * CW;  // LDS-DMA instructions per wave per slab
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nk) glds_issue(s * BK, s);
+    if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = D;  // stage holding slab t / stage to refill with slab t+D
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + D < nk;
+      if (more) glds_issue((kt + D) * BK, nxt);
+      compute(smem + cur * STAGE);
+      if (more) wait_vmcnt<LPS*(D - 1)>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+  } else {
+    gload(0);
+    lds_store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) gload((kt + 1) * BK);
+      compute(smem + cur * STAGE);
+      if (kt + 1 < nk) lds_store(cur ^ 1);
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: accumulators -> per-wave LDS tile -> 4 consecutive columns per lane ----
-  float* ct = reinterpret_cast<float*>(smem) + wave * SM * CLD;
-#pragma unroll
-  for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ct[(mt * 16 + lg * 4 + r) * CLD + nt * 16 + li] = acc[mt][nt][r];
-  __syncthreads();
-
+  // ---- epilogue: accumulators -> per-wave LDS staging (EROWS rows at a time) -> 4 consecutive columns per lane.
+  // The stage buffers are dead here (the K loop ended on a barrier); each wave owns a private EROWS x CLD slice.
+  float* ct = reinterpret_cast<float*>(smem) + wave * EROWS * CLD;
   constexpr int V4_PER_ROW = SN / 4;
   constexpr int ROWS_IT = 64 / V4_PER_ROW;
   const int c4 = lane % V4_PER_ROW;
   const int rsub = lane / V4_PER_ROW;
   const int col = n0 + wn * SN + c4 * 4;
-  if (col >= p.N) return;
+  const bool col_ok = col < p.N;
   const float* bias = p.bias ? p.bias + (long long)zi * p.bias_si : nullptr;
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
@@ -270,46 +356,57 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   T* c16l = p.c16_lo ? (T*)p.c16_lo + c_boff : nullptr;
   const bool vec = p.vec_ok && (col + 4 <= p.N);
 
+#pragma unroll
+  for (int ch = 0; ch < SM / EROWS; ++ch) {
+    if (ch > 0) __syncthreads();  // previous chunk fully read back before it is overwritten
+#pragma unroll
+    for (int mt = 0; mt < EROWS / 16; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ct[(mt * 16 + lg * 4 + r) * CLD + nt * 16 + li] = acc[ch * (EROWS / 16) + mt][nt][r];
+    __syncthreads();
 #pragma unroll 4
-  for (int it = 0; it < SM / ROWS_IT; ++it) {
-    const int lr = it * ROWS_IT + rsub;
-    const int row = m0 + wm * SM + lr;
-    if (row >= p.M) continue;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c4 * 4);
-    float v[4] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]};
+    for (int it = 0; it < EROWS / ROWS_IT; ++it) {
+      const int lr = it * ROWS_IT + rsub;
+      const int row = m0 + wm * SM + ch * EROWS + lr;
+      if (row >= p.M || !col_ok) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c4 * 4);
+      float v[4] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
-    if (vec) {
-      if (res) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col);
+      for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+      if (vec) {
+        if (res) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rr[j];
-      }
-      if (c32) *reinterpret_cast<f32x4*>(c32 + (long long)row * p.ldc32 + col) = f32x4{v[0], v[1], v[2], v[3]};
-      if (c16h) {
-        typename T16<T>::v4 h, l;
+          for (int j = 0; j < 4; ++j) v[j] += rr[j];
+        }
+        if (c32) *reinterpret_cast<f32x4*>(c32 + (long long)row * p.ldc32 + col) = f32x4{v[0], v[1], v[2], v[3]};
+        if (c16h) {
+          typename T16<T>::v4 h, l;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            T hh, ll;
+            split16<T>(v[j], hh, ll);
+            h[j] = hh;
+            l[j] = ll;
+          }
+          *reinterpret_cast<typename T16<T>::v4*>(c16h + (long long)row * p.ldc16 + col) = h;
+          if (c16l) *reinterpret_cast<typename T16<T>::v4*>(c16l + (long long)row * p.ldc16 + col) = l;
+        }
+      } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          T hh, ll;
-          split16<T>(v[j], hh, ll);
-          h[j] = hh;
-          l[j] = ll;
-        }
-        *reinterpret_cast<typename T16<T>::v4*>(c16h + (long long)row * p.ldc16 + col) = h;
-        if (c16l) *reinterpret_cast<typename T16<T>::v4*>(c16l + (long long)row * p.ldc16 + col) = l;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (col + j >= p.N) break;
-        float x = v[j];
-        if (res) x += res[(long long)row * p.ldr + col + j];
-        if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
-        if (c16h) {
-          T hh, ll;
-          split16<T>(x, hh, ll);
-          c16h[(long long)row * p.ldc16 + col + j] = hh;
-          if (c16l) c16l[(long long)row * p.ldc16 + col + j] = ll;
+          if (col + j >= p.N) break;
+          float x = v[j];
+          if (res) x += res[(long long)row * p.ldr + col + j];
+          if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
+          if (c16h) {
+            T hh, ll;
+            split16<T>(x, hh, ll);
+            c16h[(long long)row * p.ldc16 + col + j] = hh;
+            if (c16l) c16l[(long long)row * p.ldc16 + col + j] = ll;
+          }
         }
       }
     }
@@ -318,7 +415,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 int g_gemm_glds = 1;  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS>
 static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   Gemm16Params p = p0;
   p.tiles_m = (int)cdiv(p.M, BM);
@@ -331,23 +428,32 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
                  2.0 * AP * nbatch * (double)p.M * p.K + 2.0 * WP * (double)p.N * p.K * (nbatch / p.nb_inner > 0 ? p.nb_inner : 1) +
                      mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.residual ? 4 : 0)),
                  st);
-  if (g_gemm_glds && p.K % BK == 0)
-    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true>), grid, block, 0, st, p);
+  if (g_gemm_glds == 2 && p.K % BK == 0)  // A/B: LDS-DMA loader, plain double buffering
+    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, 2>), grid, block, 0, st, p);
+  else if (g_gemm_glds && p.K % BK == 0)
+    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, false, 2>), grid, block, 0, st, p);
   return check_launch("gemm16");
 }
 
 template <typename T>
 static int dispatch(const Gemm16Params& p, int nbatch, int passes, int tile, hipStream_t st) {
   if (tile == 2) {
-    if (passes == 3) return launch<T, 128, 64, 32, 2, 2, 2, 2>(p, nbatch, st);
-    if (passes == 2) return launch<T, 128, 64, 32, 2, 2, 1, 2>(p, nbatch, st);
-    return launch<T, 128, 64, 64, 2, 2, 1, 1>(p, nbatch, st);
+    if (passes == 3) return launch<T, 128, 64, 32, 2, 2, 2, 2, 3>(p, nbatch, st);
+    if (passes == 2) return launch<T, 128, 64, 32, 2, 2, 1, 2, 3>(p, nbatch, st);
+    return launch<T, 128, 64, 32, 2, 2, 1, 1, 4>(p, nbatch, st);
   }
-  if (passes == 3) return launch<T, 128, 128, 32, 2, 2, 2, 2>(p, nbatch, st);
-  if (passes == 2) return launch<T, 128, 128, 32, 2, 2, 1, 2>(p, nbatch, st);
-  return launch<T, 128, 128, 64, 2, 2, 1, 1>(p, nbatch, st);
+  if (tile == 3) {  // 256x256, 8 waves (2x4), one workgroup per CU: twice the FLOP per byte pulled into the CU
+    if (passes == 3) return launch<T, 256, 256, 32, 2, 4, 2, 2, 2>(p, nbatch, st);
+    if (passes == 2) return launch<T, 256, 256, 32, 2, 4, 1, 2, 3>(p, nbatch, st);
+    return launch<T, 256, 256, 32, 2, 4, 1, 1, 4>(p, nbatch, st);
+  }
+  // stage counts keep the LDS footprint at <= 80 KB so two workgroups share a CU (the C staging tile of the
+  // epilogue needs 69.6 KB anyway): 1-pass 4 x 16 KB, 2-pass 3 x 24 KB, 3-pass 2 x 32 KB.
+  if (passes == 3) return launch<T, 128, 128, 32, 2, 2, 2, 2, 2>(p, nbatch, st);
+  if (passes == 2) return launch<T, 128, 128, 32, 2, 2, 1, 2, 3>(p, nbatch, st);
+  return launch<T, 128, 128, 32, 2, 2, 1, 1, 4>(p, nbatch, st);
 }
 
 }  // namespace mer
@@ -394,7 +500,8 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;
-  if (tile == 0) tile = (a->N <= 64) ? 2 : 1;
+  // 256x256 (8 waves, staggered schedule) wins whenever there are enough rows; narrow / short problems keep 4-wave tiles
+  if (tile == 0) tile = (a->N <= 64) ? 2 : ((a->M >= 1024 && a->N >= 192) ? 3 : 1);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, a->passes, tile, st);
   return dispatch<bf16>(p, nbatch, a->passes, tile, st);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """GEMM microbenchmark (GPU): the encoder GEMM shapes, every pass count, loader variants A/B in one process.
+Loader variants: r = register-staged, d = LDS-DMA double-buffered, m = LDS-DMA multi-stage counted-vmcnt (default); X = 256x256 tile (else 128x128).
 Prints algorithmic TFLOP/s (2*M*N*K / time) and checks each variant against torch on the same fp16 operands."""
 import os
 import sys
@@ -43,12 +44,12 @@ def main():
             ref = ah.float() @ wh.float().T
         line = f"{name:13s} M={M:<7d} N={N:<5d} K={K:<5d}"
         for passes in (1, 2, 3):
-            for glds in (0, 1):
+            for glds, tile in ((0, 1), (2, 1), (1, 1), (1, 3)):
                 lib.mer_set_option(b"gemm_glds", glds)
-                kw = dict(a_lo=al if passes == 3 else None, w_lo=wl if passes >= 2 else None, passes=passes, dtype="f16")
+                kw = dict(a_lo=al if passes == 3 else None, w_lo=wl if passes >= 2 else None, passes=passes, dtype="f16", tile=tile)
                 fn = lambda: ops.gemm16(ah, wh, bias=bias, act="gelu", out16=True, **kw)  # noqa: E731
                 t = timeit(fn)
-                line += f" | p{passes}{'g' if glds else 'r'} {2.0 * M * N * K / t / 1e12:7.1f}"
+                line += f" | p{passes}{'rmd'[glds]}{'' if tile == 1 else 'X'} {2.0 * M * N * K / t / 1e12:6.1f}"
                 if ref is not None and passes == 1:
                     c32, _, _ = ops.gemm16(ah, wh, out32=True, **kw)
                     err = ((c32 - ref).abs().max() / ref.abs().max()).item()

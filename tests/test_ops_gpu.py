@@ -32,7 +32,8 @@ def _act_ref(x, act):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 1), (300, 200, 136, 1), (257, 48, 72, 2), (1000, 768, 768, 0),
-                                        (64, 2304, 768, 1), (130, 64, 3072, 2)])
+                                        (64, 2304, 768, 1), (130, 64, 3072, 2), (300, 200, 136, 3), (1000, 768, 768, 3),
+                                        (513, 256, 64, 3), (2000, 520, 3072, 3)])
 def test_gemm16_single_pass(dev, dtype, M, N, K, tile):
     ops = _ops()
     t16 = ops.torch16(dtype)
@@ -49,8 +50,9 @@ def test_gemm16_single_pass(dev, dtype, M, N, K, tile):
     assert_close(c16.float().cpu(), ref.float(), 1e-2 if dtype == "bf16" else 1.5e-3, f"gemm16 {dtype} c16")
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 136), (1000, 768, 768), (257, 48, 6144)])
-def test_gemm16_three_pass_is_fp32_grade(dev, M, N, K):
+@pytest.mark.parametrize("M,N,K,tile", [(300, 200, 136, 1), (1000, 768, 768, 1), (257, 48, 6144, 2), (1000, 768, 768, 3),
+                                        (700, 264, 96, 3)])
+def test_gemm16_three_pass_is_fp32_grade(dev, M, N, K, tile):
     ops = _ops()
     a = _rand((M, K), 5)
     w = _rand((N, K), 6) * 0.05
@@ -58,15 +60,19 @@ def test_gemm16_three_pass_is_fp32_grade(dev, M, N, K):
     wh, wl = ops.split16_host(w, "f16")
     ref = a.double() @ w.double().T
     c32, c16h, c16l = ops.gemm16(ah, wh.to(dev), a_lo=al, w_lo=wl.to(dev), out32=True, out16=True, out16_lo=True, passes=3,
-                                 dtype="f16", tile=2 if N <= 64 else 1)
+                                 dtype="f16", tile=tile)
     torch.cuda.synchronize()
     assert_close(c32.cpu(), ref.float(), 2e-5, "gemm16 x3 c32")
     # hi+lo planes of the output reproduce the fp32 result to ~2^-21
     assert_close((c16h.float() + c16l.float()).cpu(), ref.float(), 1e-5, "gemm16 x3 hi+lo out")
     # and a single pass on the same data is visibly worse (guards against silently running 3 passes everywhere)
-    c1, _, _ = ops.gemm16(ah, wh.to(dev), out32=True, passes=1, dtype="f16")
+    c1, _, _ = ops.gemm16(ah, wh.to(dev), out32=True, passes=1, dtype="f16", tile=tile)
     e1 = (c1.cpu().double() - ref).abs().max() / ref.abs().max()
     assert e1 > 5e-5
+    # 2-pass (weights split only): the weight-rounding error is gone, the activation rounding stays
+    c2, _, _ = ops.gemm16(ah, wh.to(dev), w_lo=wl.to(dev), out32=True, passes=2, dtype="f16", tile=tile)
+    ref2 = ah.float().cpu().double() @ w.double().T
+    assert_close(c2.cpu(), ref2.float(), 2e-5, "gemm16 w2 vs exact-weights reference")
 
 
 def test_gemm16_implicit_conv1d(dev):
