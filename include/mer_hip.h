@@ -49,6 +49,9 @@ const char* mer_target_arch(void);
 int mer_abi_sizeof(const char* name);
 /* Tuning knobs (A/B testing): "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged. */
 int mer_set_option(const char* name, int value);
+/* Kernel-phase timing for tuning: when non-NULL, every mer_gemm16 workgroup writes 4 s_memtime stamps (start, first
+ * slab ready, K loop done, end) at buffer[4*workgroup ..]; the caller sizes the device buffer. NULL disables. */
+int mer_set_debug_buffer(void* device_u64_buffer);
 int mer_prof_enable(int on);
 int mer_prof_report(char* buf, int buflen);
 

@@ -99,6 +99,7 @@ _PROTOS = {
     "mer_target_arch": (C.c_char_p, []),
     "mer_abi_sizeof": (c_int, [C.c_char_p]),
     "mer_set_option": (c_int, [C.c_char_p, c_int]),
+    "mer_set_debug_buffer": (c_int, [c_void_p]),
     "mer_prof_enable": (c_int, [c_int]),
     "mer_prof_report": (c_int, [C.c_char_p, c_int]),
     "mer_gemm16": (c_int, [C.POINTER(GemmArgs), c_void_p]),

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
   const T* qb = q + row0 * ld + h * 64;
 
   // ---- stage K (row-major, padded) and V^T into LDS; rows >= klen are zero ----
+  // (issuing all loads before the first LDS write was measured: no gain, more VGPRs)
   for (int c = tid; c < TP * 8; c += 256) {
     const int row = c >> 3, ch = c & 7;
     u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
@@ -56,14 +57,17 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
     for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
   }
 
+  __syncthreads();
+
+  // K / V^T of this (batch, head) are staged once; each wave then walks its 16-query sub-tiles
+  // (qs = wave, wave+4, ...), so the staging cost is paid once per head instead of once per 64 queries.
+  for (int qs = qt * 4 + wave; qs * 16 < Tn; qs += 4 * (int)gridDim.x) {
   // ---- this lane's query fragment (B operand: n = query li, k = d) ----
-  const int qi = qt * 64 + wave * 16 + li;
+  const int qi = qs * 16 + li;
   const int qrow = qi < Tn ? qi : Tn - 1;
   v8 qf[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const v8*>(qb + (long long)qrow * ld + kk * 32 + lg * 8);
-
-  __syncthreads();
 
   // ---- S^T tiles: s[kt][r] = score(key = 16*kt + 4*lg + r, query = li) ----
   f32x4 s[NKT];
@@ -149,13 +153,14 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
       if (ol) *reinterpret_cast<v4*>(ol + orow + dt * 16 + lg * 4) = ll;
     }
   }
+  }  // q sub-tile loop
 }
 
 template <typename T>
 static int launch_attn(const void* q, const void* k, const void* v, long long ld, void* oh, void* ol, long long ldo,
                        int B, int Tn, int H, float scale, const int* kv_len, hipStream_t st) {
   const float sl2 = scale * 1.4426950408889634f;
-  dim3 grid((unsigned)cdiv(Tn, 64), H, B), block(256);
+  dim3 grid(1, H, B), block(256);  // one workgroup per (batch, head): K/V staged once
   ProfScope prof("attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
 #define MER_ATTN_CASE(N)                                                                                       \
   hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \

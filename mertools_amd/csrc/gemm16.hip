@@ -24,6 +24,7 @@
 //     neighbouring tiles; bijective for any grid size).
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 namespace mer {
 
@@ -37,7 +38,8 @@ struct Gemm16Params {
   void* c16_hi; void* c16_lo; long long ldc16;
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
-  int vec_ok;  // N % 4 == 0 and all output/residual strides+offsets 4-element aligned
+  int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
+  unsigned long long* dbg;  // optional: 4 s_memtime stamps per workgroup (start, first slab ready, K loop done, end)
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x;
+  if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memtime();
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, lg = lane >> 4;
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memtime();
     if (g1) __builtin_amdgcn_s_barrier();
     int cur = 0, nxt = D;
     for (int kt = 0; kt < nk; ++kt) {
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     }
     if (!g1) __builtin_amdgcn_s_barrier();
     __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
   } else
   if (GLDS) {
     // NS-stage LDS ring, LDS-DMA prefetch distance D = NS-1 slabs, counted vmcnt: at the end of iteration
@@ -334,86 +339,133 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     }
   }
 
-  // ---- epilogue: accumulators -> per-wave LDS staging (EROWS rows at a time) -> 4 consecutive columns per lane.
-  // The stage buffers are dead here (the K loop ended on a barrier); each wave owns a private EROWS x CLD slice.
+  // ---- epilogue: accumulators -> per-wave LDS staging (EROWS rows at a time) -> 8 consecutive columns per lane, so
+  // that 16-bit outputs leave as one 16-byte store per lane (the store tail is issue-bound: half the instructions,
+  // half the time) and fp32 outputs / residuals as two.  The stage buffers are dead here (the K loop ended on a
+  // barrier); each wave owns a private EROWS x CLD slice.
   float* ct = reinterpret_cast<float*>(smem) + wave * EROWS * CLD;
-  constexpr int V4_PER_ROW = SN / 4;
-  constexpr int ROWS_IT = 64 / V4_PER_ROW;
-  const int c4 = lane % V4_PER_ROW;
-  const int rsub = lane / V4_PER_ROW;
-  const int col = n0 + wn * SN + c4 * 4;
+  constexpr int CPL = 8;                       // columns per lane
+  constexpr int LANES_PER_ROW = SN / CPL;
+  constexpr int ROWS_IT = 64 / LANES_PER_ROW;
+  constexpr int NIT = EROWS / ROWS_IT;         // read-back iterations per chunk
+  const int c8 = lane % LANES_PER_ROW;
+  const int rsub = lane / LANES_PER_ROW;
+  const int col = n0 + wn * SN + c8 * CPL;
   const bool col_ok = col < p.N;
   const float* bias = p.bias ? p.bias + (long long)zi * p.bias_si : nullptr;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
+  float bv[CPL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (col + j < p.N) bv[j] = bias[col + j];
-  }
+  for (int j = 0; j < CPL; ++j) bv[j] = (bias && col + j < p.N) ? bias[col + j] : 0.f;
   const float* res = p.residual ? p.residual + c_boff : nullptr;
   float* c32 = p.c32 ? p.c32 + c_boff : nullptr;
   T* c16h = p.c16_hi ? (T*)p.c16_hi + c_boff : nullptr;
   T* c16l = p.c16_lo ? (T*)p.c16_lo + c_boff : nullptr;
-  const bool vec = p.vec_ok && (col + 4 <= p.N);
+  const bool vec = p.vec_ok && (col + CPL <= p.N);
 
+  auto epilogue = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-  for (int ch = 0; ch < SM / EROWS; ++ch) {
-    if (ch > 0) __syncthreads();  // previous chunk fully read back before it is overwritten
+    for (int ch = 0; ch < SM / EROWS; ++ch) {
+      // The staging slice is private to this wave and the LDS executes one wave's accesses in order, so the
+      // write -> read-back -> overwrite sequence needs no s_barrier and, above all, no vmcnt drain: a
+      // __syncthreads() here waits for the previous chunk's global stores (vmcnt counts stores on gfx950),
+      // which serialised 4 store round trips per tile (~30k of ~100k cycles).  Compiler-level fences only.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int mt = 0; mt < EROWS / 16; ++mt)
+      for (int mt = 0; mt < EROWS / 16; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < TN; ++nt)
+        for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ct[(mt * 16 + lg * 4 + r) * CLD + nt * 16 + li] = acc[ch * (EROWS / 16) + mt][nt][r];
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < EROWS / ROWS_IT; ++it) {
-      const int lr = it * ROWS_IT + rsub;
-      const int row = m0 + wm * SM + ch * EROWS + lr;
-      if (row >= p.M || !col_ok) continue;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c4 * 4);
-      float v[4] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+          for (int r = 0; r < 4; ++r) ct[(mt * 16 + lg * 4 + r) * CLD + nt * 16 + li] = acc[ch * (EROWS / 16) + mt][nt][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int row0 = m0 + wm * SM + ch * EROWS + rsub;
       if (vec) {
+        // all residual loads of the chunk first (rows of different iterations never overlap, so this is safe even
+        // when the residual is updated in place) — otherwise every load would wait behind the previous stores
+        f32x4 rr[NIT][2];
         if (res) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += rr[j];
+          for (int it = 0; it < NIT; ++it) {
+            const int row = row0 + it * ROWS_IT;
+            const bool ok = row < p.M && col_ok;
+            const float* rp = res + (long long)row * p.ldr + col;
+            rr[it][0] = ok ? *reinterpret_cast<const f32x4*>(rp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rr[it][1] = ok ? *reinterpret_cast<const f32x4*>(rp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
-        if (c32) *reinterpret_cast<f32x4*>(c32 + (long long)row * p.ldc32 + col) = f32x4{v[0], v[1], v[2], v[3]};
-        if (c16h) {
-          typename T16<T>::v4 h, l;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int lr = it * ROWS_IT + rsub;
+          const int row = row0 + it * ROWS_IT;
+          if (row >= p.M || !col_ok) continue;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL + 4);
+          float v[CPL];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            T hh, ll;
-            split16<T>(v[j], hh, ll);
-            h[j] = hh;
-            l[j] = ll;
+            v[j] = act_apply(a0[j] + bv[j], ACT);
+            v[4 + j] = act_apply(a1[j] + bv[4 + j], ACT);
           }
-          *reinterpret_cast<typename T16<T>::v4*>(c16h + (long long)row * p.ldc16 + col) = h;
-          if (c16l) *reinterpret_cast<typename T16<T>::v4*>(c16l + (long long)row * p.ldc16 + col) = l;
+          if (res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] += rr[it][0][j];
+              v[4 + j] += rr[it][1][j];
+            }
+          }
+          if (c32) {
+            float* cp = c32 + (long long)row * p.ldc32 + col;
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+          if (c16h) {
+            v8 h, l;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+              T hh, ll;
+              split16<T>(v[j], hh, ll);
+              h[j] = hh;
+              l[j] = ll;
+            }
+            *reinterpret_cast<v8*>(c16h + (long long)row * p.ldc16 + col) = h;
+            if (c16l) *reinterpret_cast<v8*>(c16l + (long long)row * p.ldc16 + col) = l;
+          }
         }
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (col + j >= p.N) break;
-          float x = v[j];
-          if (res) x += res[(long long)row * p.ldr + col + j];
-          if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
-          if (c16h) {
-            T hh, ll;
-            split16<T>(x, hh, ll);
-            c16h[(long long)row * p.ldc16 + col + j] = hh;
-            if (c16l) c16l[(long long)row * p.ldc16 + col + j] = ll;
+        for (int it = 0; it < NIT; ++it) {
+          const int lr = it * ROWS_IT + rsub;
+          const int row = row0 + it * ROWS_IT;
+          if (row >= p.M || !col_ok) continue;
+          for (int j = 0; j < CPL; ++j) {
+            if (col + j >= p.N) break;
+            float x = act_apply(ct[lr * CLD + c8 * CPL + j] + bv[j], ACT);
+            if (res) x += res[(long long)row * p.ldr + col + j];
+            if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
+            if (c16h) {
+              T hh, ll;
+              split16<T>(x, hh, ll);
+              c16h[(long long)row * p.ldc16 + col + j] = hh;
+              if (c16l) c16l[(long long)row * p.ldc16 + col + j] = ll;
+            }
           }
         }
       }
     }
+  };
+  switch (p.act) {  // one specialised copy of the epilogue per activation: no per-element switch
+    case MER_ACT_GELU: epilogue(std::integral_constant<int, MER_ACT_GELU>{}); break;
+    case MER_ACT_QUICK_GELU: epilogue(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
+    case MER_ACT_RELU: epilogue(std::integral_constant<int, MER_ACT_RELU>{}); break;
+    default: epilogue(std::integral_constant<int, MER_ACT_NONE>{}); break;
   }
+  if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
-int g_gemm_glds = 1;  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
+int g_gemm_glds = 1;
+unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer()  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS>
 static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
@@ -458,6 +510,11 @@ static int dispatch(const Gemm16Params& p, int nbatch, int passes, int tile, hip
 
 }  // namespace mer
 
+extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
+  mer::g_gemm_dbg = (unsigned long long*)device_u64_buffer;
+  return MER_OK;
+}
+
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
@@ -491,11 +548,13 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   p.nb_inner = a->nb_inner > 0 ? a->nb_inner : 1;
   p.a_so = a->a_so; p.a_si = a->a_si; p.w_si = a->w_si; p.bias_si = a->bias_si; p.c_so = a->c_so; p.c_si = a->c_si;
   p.tiles_m = p.tiles_n = 0;
-  bool vec = (a->N % 4 == 0) && (a->c_so % 4 == 0) && (a->c_si % 4 == 0);
+  p.dbg = g_gemm_dbg;
+  // the vector epilogue moves 8 columns per lane with 16-byte accesses
+  bool vec = (a->N % 8 == 0) && (a->c_so % 8 == 0) && (a->c_si % 8 == 0);
   if (a->residual) vec = vec && (a->ldr % 4 == 0) && (((uintptr_t)a->residual & 15) == 0);
   if (a->c32) vec = vec && (a->ldc32 % 4 == 0) && (((uintptr_t)a->c32 & 15) == 0);
-  if (a->c16_hi) vec = vec && (a->ldc16 % 4 == 0) && (((uintptr_t)a->c16_hi & 7) == 0);
-  if (a->c16_lo) vec = vec && (((uintptr_t)a->c16_lo & 7) == 0);
+  if (a->c16_hi) vec = vec && (a->ldc16 % 8 == 0) && (((uintptr_t)a->c16_hi & 15) == 0);
+  if (a->c16_lo) vec = vec && (((uintptr_t)a->c16_lo & 15) == 0);
   p.vec_ok = vec ? 1 : 0;
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");

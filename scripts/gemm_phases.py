@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Per-workgroup phase timing of the 256x256 GEMM (s_memtime stamps): prologue / K loop / epilogue cycles."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mertools_amd import _lib, ops
+dev = torch.device("cuda:0")
+lib = _lib.lib()
+g = torch.Generator().manual_seed(0)
+for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 2), ("qkv none p2", 100864, 2304, 768, None, 2),
+                                     ("fc2 res p2", 100864, 768, 3072, None, 2), ("fc1 gelu p1", 100864, 3072, 768, "gelu", 1),
+                                     ("fc1 qgelu p2", 100864, 3072, 768, "quick_gelu", 2)]:
+    a = torch.randn(M, K, generator=g).to(dev); w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    ah, _ = ops.split16(a, "f16", lo=False); wh, wl = ops.split16(w, "f16")
+    bias = torch.randn(N, device=dev)
+    nblk = ((M + 255) // 256) * ((N + 255) // 256)
+    buf = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
+    kw = dict(w_lo=wl if passes >= 2 else None, passes=passes, dtype="f16", tile=3, bias=bias, act=act, out16=True)
+    ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
+    lib.mer_set_debug_buffer(buf.data_ptr())
+    ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
+    lib.mer_set_debug_buffer(None)
+    t = buf.view(nblk, 4).cpu().double()
+    pro, loop, epi, tot = (t[:, 1] - t[:, 0]), (t[:, 2] - t[:, 1]), (t[:, 3] - t[:, 2]), (t[:, 3] - t[:, 0])
+    span = (t[:, 3].max() - t[:, 0].min()).item()
+    print(f"{name:13s} blocks={nblk} median cycles/ticks: prologue {pro.median():.0f}  kloop {loop.median():.0f}  epilogue {epi.median():.0f}  total {tot.median():.0f}"
+          f" | per-slab {loop.median() / (K / 32):.0f} | kernel span {span:.0f} ticks; sum(total)/256/span = {tot.sum().item() / 256 / span:.2f}")
