@@ -108,7 +108,7 @@ int mer_layernorm(const float* x, long long ldx, const float* gamma, const float
 /* Multi-head self-attention, softmax(q k^T * scale) v, no causal mask; optional per-sequence key
  * length (keys >= kv_len[b] are masked out; rows >= kv_len[b] produce unspecified output).
  * q,k,v: 16-bit [B*T, ld] with head h at columns [h*64, h*64+64) of each pointer; head_dim = 64.
- * out: 16-bit planes [B*T, ldo].  T <= 288 uses the single-pass kernel (K and V^T of one head
+ * out: 16-bit planes [B*T, ldo].  T <= 512 uses the single-pass kernel (K and V^T of one head
  * resident in LDS); larger T uses the streaming (online-softmax) kernel.
  * (HF:hubert/modeling_hubert.py:236-259 eager_attention_forward; same math in CLIP/RoBERTa.) */
 int mer_attention(const void* q, const void* k, const void* v, long long ld,
@@ -126,16 +126,29 @@ int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* w /*[C,k]*/
                         const float* gamma, const float* beta, float eps, double* stats,
                         void* out_hi, void* out_lo, int dtype, mer_stream_t stream);
 
+/* Layer-0 conv for feat_extract_norm == "layer" (HuBERT-large / wav2vec2-large, HF:hubert/modeling_hubert.py:127-151):
+ * out[b,t,c] = bias[c] + conv, fp32 channels-last [B,T0,C]; the per-frame LayerNorm + GELU is mer_layernorm(act=GELU). */
+int mer_hubert_conv0_plain(const float* wav, int B, int L, const float* w, const float* bias, int C, int k, int stride,
+                           float* out, mer_stream_t stream);
+
 /* Channels-last hidden [B,T,D] fp32 -> zero-padded, group-major 16-bit planes [B, G, T+K, D/G]
  * with x[b,t,g*Dg+c] at row t + K/2, so that the grouped positional Conv1d becomes one batched
  * implicit-im2col GEMM (HF:hubert/modeling_hubert.py:45-92). */
 int mer_posconv_pack(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo,
                      int dtype, mer_stream_t stream);
 
-/* ViT patchify: pixel_values fp32 [N,3,H,W] -> 16-bit planes [N*(H/P)*(W/P), 3*P*P] with the
- * (c, i, j) ordering of a flattened Conv2d weight (HF:clip/modeling_clip.py:138-217). */
+/* ViT patchify: pixel_values fp32 [N,3,H,W] -> 16-bit planes [N*(H/P)*(W/P), ceil8(3*P*P)] with the
+ * (c, i, j) ordering of a flattened Conv2d weight (HF:clip/modeling_clip.py:138-217); rows are zero-padded to a
+ * multiple of 8 columns (CLIP-L/14: 588 -> 592) and the weight must be padded the same way. */
 int mer_vit_patchify(const float* pixels, int N, int C, int H, int W, int P, void* out_hi, void* out_lo,
                      int dtype, mer_stream_t stream);
+
+/* VideoMAE tubelet patchify: pixel_values fp32 [B,F,C,H,W] -> 16-bit planes [B*(F/ts)*(H/P)*(W/P), C*ts*P*P] in the
+ * (c, dt, i, j) order of the flattened Conv3d weight (HF:videomae/modeling_videomae.py:119-176). */
+int mer_video_patchify(const float* pixels, int B, int F, int C, int H, int W, int P, int ts, void* out_hi, void* out_lo,
+                       int dtype, mer_stream_t stream);
+/* x[r,:] += pos[r % P,:] in place (fixed sin-cos position table). */
+int mer_add_pos(float* x, const float* pos, long long rows, int P, int D, mer_stream_t stream);
 
 /* ViT token assembly + optional LayerNorm: tok[n,0,:] = cls + pos[0]; tok[n,1+p,:] = patch[n,p,:]
  * + pos[1+p]; y = LN(tok) if gamma != NULL else tok.  out32 [N*(1+P), D]; optional 16-bit. */
@@ -267,7 +280,7 @@ typedef struct {
   int image_size, patch_size, channels, proj_dim;
 } mer_vit_config;
 typedef struct {
-  mer_w16 patch_w;                      /* [D, C*P*P] (no bias) */
+  mer_w16 patch_w;                      /* [D, ceil8(C*P*P)] (no bias; zero-padded columns) */
   const float* cls; const float* pos;   /* [D], [1+P, D] */
   const float* pre_ln_g; const float* pre_ln_b;
   const float* post_ln_g; const float* post_ln_b;
@@ -283,6 +296,30 @@ long long mer_vit_workspace_bytes(const mer_vit* h, int N);
 int mer_vit_forward(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
                     float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
                     mer_stream_t stream);
+
+/* ---- VideoMAE video encoder ------------------------------------------------------------------
+ * Replaces `model(inputs).last_hidden_state` at
+ * MERBench/feature_extraction/visual/extract_vision_huggingface.py:155 and the per-segment patch mean of :156-158. */
+typedef struct {
+  mer_tf_config tf;          /* pre_ln = 1 */
+  int image_size, patch_size, channels, num_frames, tubelet_size;
+  int final_ln;              /* VideoMAEModel.layernorm present (config.use_mean_pooling == False) */
+} mer_videomae_config;
+typedef struct {
+  mer_w16 patch_w; const float* patch_b;   /* [D, C*ts*P*P], [D] */
+  const float* pos;                          /* [num_patches, D] fixed sin-cos table */
+  const float* final_ln_g; const float* final_ln_b;
+  const mer_tf_layer* layers;
+} mer_videomae_weights;
+typedef struct mer_videomae mer_videomae;
+int mer_videomae_create(const mer_videomae_config* cfg, const mer_videomae_weights* w, mer_videomae** out);
+void mer_videomae_destroy(mer_videomae* h);
+long long mer_videomae_workspace_bytes(const mer_videomae* h, int B);
+/* pixels: device fp32 [B,F,C,S,S].  last_hidden_state fp32 [B*num_patches, D] (may be NULL);
+ * pooled fp32 [nseg, D] = mean of last_hidden_state rows per segment (may be NULL). */
+int mer_videomae_forward(const mer_videomae* h, const float* pixels, int B, void* workspace, long long workspace_bytes,
+                         float* last_hidden_state, const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                         mer_stream_t stream);
 
 /* ---- BERT / RoBERTa text encoder ------------------------------------------------------------
  * Replaces `model(**inputs, output_hidden_states=True).hidden_states` at

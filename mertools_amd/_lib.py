@@ -82,6 +82,16 @@ class VitWeights(C.Structure):
                 ("post_ln_g", c_void_p), ("post_ln_b", c_void_p), ("proj_w", W16), ("layers", C.POINTER(TfLayer))]
 
 
+class VideoMAEConfig(C.Structure):
+    _fields_ = [("tf", TfConfig), ("image_size", c_int), ("patch_size", c_int), ("channels", c_int), ("num_frames", c_int),
+                ("tubelet_size", c_int), ("final_ln", c_int)]
+
+
+class VideoMAEWeights(C.Structure):
+    _fields_ = [("patch_w", W16), ("patch_b", c_void_p), ("pos", c_void_p), ("final_ln_g", c_void_p), ("final_ln_b", c_void_p),
+                ("layers", C.POINTER(TfLayer))]
+
+
 class BertConfig(C.Structure):
     _fields_ = [("tf", TfConfig), ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("pad_id", c_int),
                 ("pos_mode", c_int), ("emb_ln_eps", c_float)]
@@ -112,8 +122,11 @@ _PROTOS = {
     "mer_split16": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     "mer_hubert_conv0_gn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mer_hubert_conv0_plain": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mer_posconv_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mer_vit_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "mer_video_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "mer_add_pos": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p]),
     "mer_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mer_bert_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -142,6 +155,11 @@ _PROTOS = {
     "mer_vit_workspace_bytes": (c_ll, [c_void_p, c_int]),
     "mer_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_void_p]),
+    "mer_videomae_create": (c_int, [C.POINTER(VideoMAEConfig), C.POINTER(VideoMAEWeights), C.POINTER(c_void_p)]),
+    "mer_videomae_destroy": (None, [c_void_p]),
+    "mer_videomae_workspace_bytes": (c_ll, [c_void_p, c_int]),
+    "mer_videomae_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p]),
     "mer_bert_create": (c_int, [C.POINTER(BertConfig), C.POINTER(BertWeights), C.POINTER(c_void_p)]),
     "mer_bert_destroy": (None, [c_void_p]),
     "mer_bert_workspace_bytes": (c_ll, [c_void_p, c_int, c_int, c_int]),

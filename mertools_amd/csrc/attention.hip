@@ -156,6 +156,136 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
   }  // q sub-tile loop
 }
 
+// Streaming (online-softmax) kernel for T > 512 (VideoMAE: 1568 tokens).  One workgroup = (batch, head, 64
+// queries); keys/values are walked in blocks of 64 through LDS.  Same swapped-operand trick as above: a lane owns one
+// query, so the running max m / normaliser l and the rescale factor are per-lane scalars and apply directly to the
+// lane's O^T accumulator columns (HF:videomae/modeling_videomae.py eager_attention_forward).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          const T* __restrict__ v, long long ld, T* oh, T* ol,
+                                                          long long ldo, int Tn, float scale_log2e, const int* kv_len) {
+  typedef typename T16<T>::v8 v8;
+  typedef typename T16<T>::v4 v4;
+  constexpr int KB = 64, KS = 72, VS = KB + 4;
+  __shared__ __attribute__((aligned(16))) T Ks[KB * KS];
+  __shared__ __attribute__((aligned(16))) T Vt[64 * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+  int klen = Tn;
+  if (kv_len) {
+    klen = kv_len[b];
+    klen = klen < Tn ? klen : Tn;
+  }
+  const long long row0 = (long long)b * Tn;
+  const T* kb = k + row0 * ld + h * 64;
+  const T* vb = v + row0 * ld + h * 64;
+  const T* qb = q + row0 * ld + h * 64;
+  const int qi = qt * 64 + wave * 16 + li;
+  const int qrow = qi < Tn ? qi : Tn - 1;
+  v8 qf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const v8*>(qb + (long long)qrow * ld + kk * 32 + lg * 8);
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+  for (int k0 = 0; k0 < klen; k0 += KB) {
+    __syncthreads();  // previous block fully consumed
+    for (int c = tid; c < KB * 8; c += 256) {
+      const int row = c >> 3, ch = c & 7;
+      u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+      if (k0 + row < klen) {
+        kv = *reinterpret_cast<const u32x4*>(kb + (long long)(k0 + row) * ld + ch * 8);
+        vv = *reinterpret_cast<const u32x4*>(vb + (long long)(k0 + row) * ld + ch * 8);
+      }
+      *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kv;
+      const v8 vh = __builtin_bit_cast(v8, vv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
+    }
+    __syncthreads();
+    f32x4 s[4];
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const v8 kf = *reinterpret_cast<const v8*>(Ks + (kt * 16 + li) * KS + kk * 32 + lg * 8);
+        a = T16<T>::mfma(kf, qf[kk], a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + kt * 16 + lg * 4 + r;
+        a[r] = key < klen ? a[r] * scale_log2e : -INFINITY;
+        bmax = fmaxf(bmax, a[r]);
+      }
+      s[kt] = a;
+    }
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
+    const float mnew = fmaxf(m, bmax);                 // finite: every block holds at least one unmasked key
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // first block: exp2(-inf) = 0
+    m = mnew;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = __builtin_amdgcn_exp2f(s[kt][r] - mnew);
+        s[kt][r] = pe;
+        psum += pe;
+      }
+    lsum = lsum * alpha + psum;  // per-lane partial of the query's normaliser (4 lanes share a query and its alpha)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      v8 pf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[j] = T16<T>::from_f32(s[2 * c][j]);
+        pf[4 + j] = T16<T>::from_f32(s[2 * c + 1][j]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const T* vr = Vt + (dt * 16 + li) * VS + lg * 4;
+        const v4 v0 = *reinterpret_cast<const v4*>(vr + (2 * c) * 16);
+        const v4 v1 = *reinterpret_cast<const v4*>(vr + (2 * c + 1) * 16);
+        v8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = v0[j];
+          vf[4 + j] = v1[j];
+        }
+        o[dt] = T16<T>::mfma(vf, pf, o[dt]);
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+  if (qi < Tn) {
+    const long long orow = (row0 + qi) * ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      v4 hh, ll;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T a, c;
+        split16<T>(o[dt][r] * inv, a, c);
+        hh[r] = a;
+        ll[r] = c;
+      }
+      *reinterpret_cast<v4*>(oh + orow + dt * 16 + lg * 4) = hh;
+      if (ol) *reinterpret_cast<v4*>(ol + orow + dt * 16 + lg * 4) = ll;
+    }
+  }
+}
+
 template <typename T>
 static int launch_attn(const void* q, const void* k, const void* v, long long ld, void* oh, void* ol, long long ldo,
                        int B, int Tn, int H, float scale, const int* kv_len, hipStream_t st) {
@@ -172,8 +302,9 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   else if (Tn <= 288) MER_ATTN_CASE(18);
   else if (Tn <= 512) MER_ATTN_CASE(32);
   else {
-    set_error("mer_attention: T=%d > 512 needs the streaming kernel (not built yet)", Tn);
-    return MER_EUNSUPPORTED;
+    dim3 sgrid((unsigned)cdiv(Tn, 64), H, B);
+    hipLaunchKernelGGL((attn_stream_kernel<T>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
+                       ldo, Tn, sl2, kv_len);
   }
 #undef MER_ATTN_CASE
   return check_launch("attention");

@@ -154,8 +154,6 @@ extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_
   MER_TRY(check_tf(cfg->tf, "mer_hubert_create"));
   MER_REQUIRE(cfg->n_conv >= 2 && cfg->n_conv <= MER_MAX_CONV, MER_EINVAL, "mer_hubert_create: n_conv=%d", cfg->n_conv);
   MER_REQUIRE(cfg->conv_dim % 8 == 0, MER_ESHAPE, "mer_hubert_create: conv_dim %% 8 != 0");
-  MER_REQUIRE(cfg->feat_norm_group == 1, MER_EUNSUPPORTED,
-              "mer_hubert_create: feat_extract_norm='layer' (HuBERT-large front end) is not built yet");
   MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 3, MER_EINVAL, "mer_hubert_create: conv_passes must be 1, 2 or 3");
   MER_REQUIRE(cfg->tf.hidden % cfg->pos_groups == 0 && (cfg->tf.hidden / cfg->pos_groups) % 8 == 0, MER_ESHAPE,
               "mer_hubert_create: hidden/pos_groups must be a multiple of 8");
@@ -187,6 +185,7 @@ extern "C" int mer_hubert_out_frames(const mer_hubert* h, int L) {
 struct HubertPlan {
   double* stats;
   P16 convA, convB;
+  float* conv32;       // feat_extract_norm == "layer": fp32 conv output awaiting its LayerNorm
   float* conv_last32;
   P16 fp16;
   float* hproj;
@@ -206,6 +205,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   p.stats = (double*)ar.take((long long)B * C * 2 * 8);
   p.convA = take16(ar, (long long)B * p.T[0] * C, clo);
   p.convB = take16(ar, (long long)B * p.T[1] * C, clo);
+  p.conv32 = c.feat_norm_group ? nullptr : (float*)ar.take((long long)B * p.T[0] * C * 4);
   p.conv_last32 = (float*)ar.take(M * C * 4);
   p.fp16 = take16(ar, M * C, clo);
   p.hproj = (float*)ar.take(M * D * 4);
@@ -241,11 +241,19 @@ extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, 
   const int M = B * Tn;
   const P16 none = {nullptr, nullptr};
 
-  // conv0 + GroupNorm + GELU -> channels-last planes
-  MER_TRY(mer_hubert_conv0_gn(wav, B, L, w.conv0_w, C, c.conv_kernel[0], c.conv_stride[0], w.conv_norm_g[0], w.conv_norm_b[0],
-                              1e-5f, p.stats, p.convA.hi, p.convA.lo, dt, st));
-  // conv1.. as implicit-im2col GEMMs (row m=(b,t) starts at b*T_in*C + t*stride*C, K = k*C contiguous)
   P16 src = p.convA, dst = p.convB;
+  if (c.feat_norm_group) {
+    // conv0 + GroupNorm + GELU -> channels-last planes
+    MER_TRY(mer_hubert_conv0_gn(wav, B, L, w.conv0_w, C, c.conv_kernel[0], c.conv_stride[0], w.conv_norm_g[0], w.conv_norm_b[0],
+                                1e-5f, p.stats, p.convA.hi, p.convA.lo, dt, st));
+  } else {
+    // "layer" front end: every conv is followed by LayerNorm(C) over channels, then GELU (HF:hubert/modeling_hubert.py:127-151)
+    MER_TRY(mer_hubert_conv0_plain(wav, B, L, w.conv0_w, c.conv_bias ? w.conv_b[0] : nullptr, C, c.conv_kernel[0], c.conv_stride[0],
+                                   p.conv32, st));
+    MER_TRY(mer_layernorm(p.conv32, C, w.conv_norm_g[0], w.conv_norm_b[0], 1e-5f, B * p.T[0], C, MER_ACT_GELU, nullptr, 0,
+                          p.convA.hi, p.convA.lo, C, dt, st));
+  }
+  // conv1.. as implicit-im2col GEMMs (row m=(b,t) starts at b*T_in*C + t*stride*C, K = k*C contiguous)
   for (int i = 1; i < c.n_conv; ++i) {
     const bool last = i == c.n_conv - 1;
     mer_gemm16_args g;
@@ -254,11 +262,22 @@ extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, 
     g.a_hi = src.hi; g.a_lo = src.lo; g.lda = (long long)c.conv_stride[i] * C;
     g.a_rows_per_batch = p.T[i]; g.a_batch_stride = (long long)p.T[i - 1] * C;
     g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.ldw = g.K;
-    g.bias = c.conv_bias ? w.conv_b[i] : nullptr; g.act = MER_ACT_GELU;
-    if (last) { g.c32 = p.conv_last32; g.ldc32 = C; }
-    if (!last || !c.feat_proj_layer_norm) { g.c16_hi = (last ? p.fp16.hi : dst.hi); g.c16_lo = (last ? p.fp16.lo : dst.lo); g.ldc16 = C; }
+    g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
-    MER_TRY(mer_gemm16(&g, stream));
+    if (c.feat_norm_group) {
+      g.act = MER_ACT_GELU;
+      if (last) { g.c32 = p.conv_last32; g.ldc32 = C; }
+      if (!last || !c.feat_proj_layer_norm) { g.c16_hi = (last ? p.fp16.hi : dst.hi); g.c16_lo = (last ? p.fp16.lo : dst.lo); g.ldc16 = C; }
+      MER_TRY(mer_gemm16(&g, stream));
+    } else {
+      g.act = MER_ACT_NONE;
+      g.c32 = p.conv32; g.ldc32 = C;
+      MER_TRY(mer_gemm16(&g, stream));
+      const bool want32 = last && c.feat_proj_layer_norm;
+      P16 o = last ? p.fp16 : dst;
+      MER_TRY(mer_layernorm(p.conv32, C, w.conv_norm_g[i], w.conv_norm_b[i], 1e-5f, B * p.T[i], C, MER_ACT_GELU,
+                            want32 ? p.conv_last32 : nullptr, C, want32 ? nullptr : o.hi, want32 ? nullptr : o.lo, C, dt, st));
+    }
     P16 t = src; src = dst; dst = t;
   }
   // feature projection: LayerNorm(C) -> Linear(C -> D)   (HF:hubert/modeling_hubert.py:216-231)
@@ -312,8 +331,7 @@ extern "C" int mer_vit_create(const mer_vit_config* cfg, const mer_vit_weights* 
   MER_REQUIRE(cfg && w && out, MER_EINVAL, "mer_vit_create: null argument");
   MER_TRY(check_tf(cfg->tf, "mer_vit_create"));
   MER_REQUIRE(cfg->tf.pre_ln == 1, MER_EUNSUPPORTED, "mer_vit_create: ViT blocks are pre-LN");
-  MER_REQUIRE(cfg->image_size % cfg->patch_size == 0 && cfg->patch_size % 4 == 0, MER_ESHAPE, "mer_vit_create: image/patch size");
-  MER_REQUIRE((cfg->channels * cfg->patch_size * cfg->patch_size) % 8 == 0, MER_ESHAPE, "mer_vit_create: C*P*P %% 8 != 0");
+  MER_REQUIRE(cfg->image_size % cfg->patch_size == 0, MER_ESHAPE, "mer_vit_create: image/patch size");
   MER_REQUIRE(w->layers && w->patch_w.hi && w->cls && w->pos, MER_EINVAL, "mer_vit_create: missing weights");
   mer_vit* h = new mer_vit();
   h->cfg = *cfg;
@@ -337,7 +355,7 @@ struct VitPlan {
 static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   const mer_vit_config& c = h->cfg;
   const long long g = c.image_size / c.patch_size, P = g * g, D = c.tf.hidden;
-  const long long cols = (long long)c.channels * c.patch_size * c.patch_size;
+  const long long cols = ((long long)c.channels * c.patch_size * c.patch_size + 7) / 8 * 8;
   const bool lo = c.tf.passes == 3;
   p.patches = take16(ar, N * P * cols, lo);
   p.patch32 = (float*)ar.take(N * P * D * 4);
@@ -368,7 +386,7 @@ extern "C" int mer_vit_forward(const mer_vit* h, const float* pixels, int N, voi
   vit_plan(h, ar, N, p);
   MER_REQUIRE(ar.ok(), MER_ENOMEM, "mer_vit_forward: workspace too small (%lld < %lld bytes)", workspace_bytes, ar.off);
   const int g = c.image_size / c.patch_size, P = g * g, D = c.tf.hidden, dt = c.tf.dtype, ps = c.tf.passes;
-  const int cols = c.channels * c.patch_size * c.patch_size;
+  const int cols = (c.channels * c.patch_size * c.patch_size + 7) / 8 * 8;
   const P16 none = {nullptr, nullptr};
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
@@ -384,6 +402,83 @@ extern "C" int mer_vit_forward(const mer_vit* h, const float* pixels, int N, voi
   float* feats = image_features ? image_features : p.feats;
   MER_TRY(gemm(st, dt, ps, N, c.proj_dim, D, p.cls16, D, w.proj_w, nullptr, MER_ACT_NONE, nullptr, 0, feats, c.proj_dim, none, 0));
   if (pooled) MER_TRY(mer_sum_pool(feats, nullptr, nullptr, nullptr, N, c.proj_dim, nullptr, seg_start, seg_len, nseg, pooled, st));
+  return MER_OK;
+}
+
+// =============================================================================================
+// VideoMAE
+// =============================================================================================
+struct mer_videomae {
+  mer_videomae_config cfg;
+  mer_videomae_weights w;
+  std::vector<mer_tf_layer> layers;
+};
+
+extern "C" int mer_videomae_create(const mer_videomae_config* cfg, const mer_videomae_weights* w, mer_videomae** out) {
+  MER_REQUIRE(cfg && w && out, MER_EINVAL, "mer_videomae_create: null argument");
+  MER_TRY(check_tf(cfg->tf, "mer_videomae_create"));
+  MER_REQUIRE(cfg->tf.pre_ln == 1, MER_EUNSUPPORTED, "mer_videomae_create: VideoMAE blocks are pre-LN");
+  MER_REQUIRE(cfg->image_size % cfg->patch_size == 0 && cfg->patch_size % 4 == 0 && cfg->num_frames % cfg->tubelet_size == 0,
+              MER_ESHAPE, "mer_videomae_create: image/patch/tubelet size");
+  MER_REQUIRE(w->layers && w->patch_w.hi && w->pos, MER_EINVAL, "mer_videomae_create: missing weights");
+  mer_videomae* h = new mer_videomae();
+  h->cfg = *cfg;
+  h->w = *w;
+  h->layers.assign(w->layers, w->layers + cfg->tf.layers);
+  h->w.layers = h->layers.data();
+  *out = h;
+  return MER_OK;
+}
+extern "C" void mer_videomae_destroy(mer_videomae* h) { delete h; }
+
+struct VmaePlan {
+  P16 patches;
+  float* x;
+  TfBufs tf;
+};
+static long long vmae_plan(const mer_videomae* h, Arena& ar, int B, VmaePlan& p) {
+  const mer_videomae_config& c = h->cfg;
+  const long long g = c.image_size / c.patch_size, NP = g * g * (c.num_frames / c.tubelet_size), D = c.tf.hidden;
+  const long long cols = (long long)c.channels * c.tubelet_size * c.patch_size * c.patch_size;
+  p.patches = take16(ar, B * NP * cols, c.tf.passes == 3);
+  p.x = (float*)ar.take(B * NP * D * 4);
+  tf_plan(ar, c.tf, B * NP, p.tf);
+  return ar.off;
+}
+extern "C" long long mer_videomae_workspace_bytes(const mer_videomae* h, int B) {
+  if (!h || B <= 0) return MER_EINVAL;
+  Arena ar(nullptr, 0, true);
+  VmaePlan p;
+  return vmae_plan(h, ar, B, p) + 256;
+}
+
+extern "C" int mer_videomae_forward(const mer_videomae* h, const float* pixels, int B, void* workspace, long long workspace_bytes,
+                                    float* last_hidden_state, const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                                    mer_stream_t stream) {
+  MER_REQUIRE(h && pixels && workspace && B > 0, MER_EINVAL, "mer_videomae_forward: bad argument");
+  MER_REQUIRE(((uintptr_t)workspace & 255) == 0, MER_EINVAL, "mer_videomae_forward: workspace must be 256-byte aligned");
+  const mer_videomae_config& c = h->cfg;
+  const mer_videomae_weights& w = h->w;
+  hipStream_t st = (hipStream_t)stream;
+  Arena ar(workspace, workspace_bytes, false);
+  VmaePlan p;
+  vmae_plan(h, ar, B, p);
+  MER_REQUIRE(ar.ok(), MER_ENOMEM, "mer_videomae_forward: workspace too small (%lld < %lld bytes)", workspace_bytes, ar.off);
+  const int g = c.image_size / c.patch_size, NP = g * g * (c.num_frames / c.tubelet_size), D = c.tf.hidden;
+  const int cols = c.channels * c.tubelet_size * c.patch_size * c.patch_size, dt = c.tf.dtype, ps = c.tf.passes;
+  const P16 none = {nullptr, nullptr};
+  float* x = last_hidden_state ? last_hidden_state : p.x;
+  // tubelet embedding: Conv3d(stride == kernel, bias) == GEMM over tubelet rows; + fixed sin-cos positions
+  MER_TRY(mer_video_patchify(pixels, B, c.num_frames, c.channels, c.image_size, c.image_size, c.patch_size, c.tubelet_size,
+                             p.patches.hi, p.patches.lo, dt, st));
+  MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0));
+  MER_TRY(mer_add_pos(x, w.pos, (long long)B * NP, NP, D, st));
+  HsMap hs;
+  hs.base = x; hs.stride = 0; hs.ring = 1;
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, NP, hs, p.tf, nullptr));
+  if (c.final_ln)
+    MER_TRY(mer_layernorm(x, D, w.final_ln_g, w.final_ln_b, c.tf.ln_eps, B * NP, D, MER_ACT_NONE, x, D, nullptr, nullptr, 0, dt, st));
+  if (pooled) MER_TRY(mer_sum_pool(x, nullptr, nullptr, nullptr, (long long)B * NP, D, nullptr, seg_start, seg_len, nseg, pooled, st));
   return MER_OK;
 }
 
@@ -468,6 +563,8 @@ extern "C" int mer_abi_sizeof(const char* name) {
   MER_SZ(mer_vit_weights);
   MER_SZ(mer_bert_config);
   MER_SZ(mer_bert_weights);
+  MER_SZ(mer_videomae_config);
+  MER_SZ(mer_videomae_weights);
 #undef MER_SZ
   return MER_EINVAL;
 }

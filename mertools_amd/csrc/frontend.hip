@@ -69,6 +69,33 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int
   }
 }
 
+// conv0 without normalisation (feat_extract_norm == "layer": HuBERT-large / wav2vec2-large, HF:hubert/modeling_hubert.py:127-151):
+// y[b,t,c] = bias[c] + sum_j w[c,j] x[b, t*stride + j], fp32 channels-last; LayerNorm + GELU follow as mer_layernorm.
+__global__ __launch_bounds__(256) void conv0_plain_kernel(const float* wav, int L, int T0, const float* w, const float* bias, int C,
+                                                          int k, int stride, float* out) {
+  __shared__ float xs[C0_TCH * 8 + C0_KMAX];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * C0_TCH;
+  const int nt = (T0 - t0) < C0_TCH ? (T0 - t0) : C0_TCH;
+  const int nin = (nt - 1) * stride + k;
+  const float* xb = wav + (long long)b * L + (long long)t0 * stride;
+  for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wr[C0_KMAX];
+#pragma unroll
+    for (int j = 0; j < C0_KMAX; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
+    const float bc = bias ? bias[c] : 0.f;
+    for (int t = 0; t < nt; ++t) {
+      float y = 0.f;
+#pragma unroll
+      for (int j = 0; j < C0_KMAX; ++j)
+        if (j < k) y = fmaf(wr[j], xs[t * stride + j], y);
+      out[((long long)b * T0 + t0 + t) * C + c] = y + bc;
+    }
+  }
+}
+
 // x [B,T,D] fp32 -> out [B,G,T+K,Dg]; 4 channels per thread.
 template <typename T>
 __global__ void posconv_pack_kernel(const float* x, int B, int Tn, int D, int G, int K, T* ohi, T* olo) {
@@ -121,6 +148,70 @@ __global__ void patchify_kernel(const float* px, int N, int C, int H, int W, int
     }
     *reinterpret_cast<typename T16<T>::v4*>(ohi + e) = h;
     if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + e) = l;
+  }
+}
+
+// video [B,F,C,H,W] -> tubelet rows [B*(F/ts)*gh*gw, C*ts*P*P] in the (c, dt, i, j) order of a flattened Conv3d weight
+template <typename T>
+__global__ void video_patchify_kernel(const float* px, int B, int F, int C, int H, int W, int P, int ts, T* ohi, T* olo) {
+  const int gh = H / P, gw = W / P, nt = F / ts, cols = C * ts * P * P;
+  const long long total4 = (long long)B * nt * gh * gw * cols / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int col = (int)(e % cols);
+    const long long row = e / cols;
+    const int c = col / (ts * P * P), dt = (col / (P * P)) % ts, ii = (col % (P * P)) / P, j = col % P;
+    const int pp = (int)(row % (gh * gw));
+    const long long bt = row / (gh * gw);
+    const int tt = (int)(bt % nt);
+    const long long b = bt / nt;
+    const int py = pp / gw, pxx = pp % gw;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(px + (((b * F + tt * ts + dt) * C + c) * H + (py * P + ii)) * (long long)W + pxx * P + j);
+    typename T16<T>::v4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      T hh, ll;
+      split16<T>(v[q], hh, ll);
+      h[q] = hh;
+      l[q] = ll;
+    }
+    *reinterpret_cast<typename T16<T>::v4*>(ohi + e) = h;
+    if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + e) = l;
+  }
+}
+
+// x[r, :] += pos[r % P, :]   (fixed sin-cos position table of VideoMAE, HF:videomae/modeling_videomae.py:80-118)
+__global__ void add_pos_kernel(float* x, const float* pos, long long rows, int P, int D) {
+  const long long n4 = rows * D / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const long long r = e / D;
+    const int c = (int)(e % D);
+    f32x4 a = *reinterpret_cast<f32x4*>(x + e);
+    a = a + *reinterpret_cast<const f32x4*>(pos + (r % P) * D + c);
+    *reinterpret_cast<f32x4*>(x + e) = a;
+  }
+}
+
+// generic patchify (any P, e.g. CLIP-L/14): one element per thread, rows padded with zeros to ldo columns (ldo % 8 == 0)
+template <typename T>
+__global__ void patchify_generic_kernel(const float* px, int N, int C, int H, int W, int P, int ldo, T* ohi, T* olo) {
+  const int gh = H / P, gw = W / P, cols = C * P * P;
+  const long long total = (long long)N * gh * gw * ldo;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % ldo);
+    const long long row = e / ldo;
+    float v = 0.f;
+    if (col < cols) {
+      const int c = col / (P * P), ii = (col % (P * P)) / P, j = col % P;
+      const int pp = (int)(row % (gh * gw));
+      const long long n = row / (gh * gw);
+      v = px[((n * C + c) * H + ((pp / gw) * P + ii)) * (long long)W + (pp % gw) * P + j];
+    }
+    T hh, ll;
+    split16<T>(v, hh, ll);
+    ohi[e] = hh;
+    if (olo) olo[e] = ll;
   }
 }
 
@@ -207,6 +298,17 @@ extern "C" int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* 
   return check_launch("hubert_conv0_gn");
 }
 
+extern "C" int mer_hubert_conv0_plain(const float* wav, int B, int L, const float* w, const float* bias, int C, int k, int stride,
+                                      float* out, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(wav && w && out, MER_EINVAL, "mer_hubert_conv0_plain: null pointer");
+  MER_REQUIRE(k >= 1 && k <= C0_KMAX && stride >= 1 && stride <= 8 && L >= k, MER_EUNSUPPORTED, "mer_hubert_conv0_plain: kernel/stride unsupported");
+  const int T0 = (L - k) / stride + 1;
+  dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
+  hipLaunchKernelGGL(conv0_plain_kernel, grid, block, 0, (hipStream_t)stream, wav, L, T0, w, bias, C, k, stride, out);
+  return check_launch("hubert_conv0_plain");
+}
+
 extern "C" int mer_posconv_pack(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo, int dtype,
                                 mer_stream_t stream) {
   using namespace mer;
@@ -225,14 +327,44 @@ extern "C" int mer_vit_patchify(const float* pixels, int N, int C, int H, int W,
                                 int dtype, mer_stream_t stream) {
   using namespace mer;
   MER_REQUIRE(pixels && out_hi && N > 0, MER_EINVAL, "mer_vit_patchify: bad args");
-  MER_REQUIRE(H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0, MER_ESHAPE, "mer_vit_patchify: H=%d W=%d P=%d unsupported", H, W, P);
-  const long long n4 = (long long)N * C * H * W / 4;
+  MER_REQUIRE(H % P == 0 && W % P == 0, MER_ESHAPE, "mer_vit_patchify: H=%d W=%d P=%d unsupported", H, W, P);
+  hipStream_t st = (hipStream_t)stream;
+  const int cols = C * P * P, ldo = (cols + 7) / 8 * 8;  // rows are zero-padded to a multiple of 8 columns
+  if (P % 4 == 0 && W % 4 == 0 && ldo == cols) {
+    const long long n4 = (long long)N * C * H * W / 4;
+    if (dtype == MER_DT_F16)
+      hipLaunchKernelGGL((patchify_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, (f16*)out_hi, (f16*)out_lo);
+    else
+      hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, (bf16*)out_hi, (bf16*)out_lo);
+  } else {
+    const long long n = (long long)N * (H / P) * (W / P) * ldo;
+    if (dtype == MER_DT_F16)
+      hipLaunchKernelGGL((patchify_generic_kernel<f16>), dim3(grid_for(n, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, ldo, (f16*)out_hi, (f16*)out_lo);
+    else
+      hipLaunchKernelGGL((patchify_generic_kernel<bf16>), dim3(grid_for(n, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, ldo, (bf16*)out_hi, (bf16*)out_lo);
+  }
+  return check_launch("vit_patchify");
+}
+
+extern "C" int mer_video_patchify(const float* pixels, int B, int F, int C, int H, int W, int P, int ts, void* out_hi,
+                                  void* out_lo, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(pixels && out_hi && B > 0, MER_EINVAL, "mer_video_patchify: bad args");
+  MER_REQUIRE(H % P == 0 && W % P == 0 && P % 4 == 0 && F % ts == 0, MER_ESHAPE, "mer_video_patchify: F=%d H=%d W=%d P=%d ts=%d unsupported", F, H, W, P, ts);
+  const long long n4 = (long long)B * F * C * H * W / 4;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MER_DT_F16)
-    hipLaunchKernelGGL((patchify_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, (f16*)out_hi, (f16*)out_lo);
+    hipLaunchKernelGGL((video_patchify_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, B, F, C, H, W, P, ts, (f16*)out_hi, (f16*)out_lo);
   else
-    hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, N, C, H, W, P, (bf16*)out_hi, (bf16*)out_lo);
-  return check_launch("vit_patchify");
+    hipLaunchKernelGGL((video_patchify_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, pixels, B, F, C, H, W, P, ts, (bf16*)out_hi, (bf16*)out_lo);
+  return check_launch("video_patchify");
+}
+
+extern "C" int mer_add_pos(float* x, const float* pos, long long rows, int P, int D, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && pos && rows > 0 && P > 0 && D % 4 == 0, MER_EINVAL, "mer_add_pos: bad args");
+  hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for(rows * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, pos, rows, P, D);
+  return check_launch("add_pos");
 }
 
 extern "C" int mer_split16(const float* x, void* hi, void* lo, long long n, int dtype, mer_stream_t stream) {

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import (BertConfig, BertWeights, HubertConfig, HubertWeights, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_MAX_CONV,
-                   TfConfig, TfLayer, VitConfig, VitWeights, W16)
+                   TfConfig, TfLayer, VideoMAEConfig, VideoMAEWeights, VitConfig, VitWeights, W16)
 from .ops import dt_code, split16_host, stream
 
 
@@ -296,7 +296,11 @@ class HipCLIPModel(_HipModule):
         cfg.image_size, cfg.patch_size, cfg.channels, cfg.proj_dim = vc.image_size, vc.patch_size, vc.num_channels, config.projection_dim
         v = "vision_model."
         w = VitWeights()
-        w.patch_w = hold.w16(sd[v + "embeddings.patch_embedding.weight"].reshape(vc.hidden_size, -1), lo)
+        pw = sd[v + "embeddings.patch_embedding.weight"].reshape(vc.hidden_size, -1)
+        pad = (-pw.shape[1]) % 8   # CLIP-L/14: 588 -> 592 zero columns (16-byte rows for the MFMA GEMM)
+        if pad:
+            pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
+        w.patch_w = hold.w16(pw, lo)
         w.cls = hold.f32(sd[v + "embeddings.class_embedding"])
         w.pos = hold.f32(sd[v + "embeddings.position_embedding.weight"])
         w.pre_ln_g, w.pre_ln_b = hold.f32(sd[v + "pre_layrnorm.weight"]), hold.f32(sd[v + "pre_layrnorm.bias"])
@@ -350,6 +354,99 @@ class HipCLIPModel(_HipModule):
             lens.append(n)
             r += n
         return self.forward_raw(pixel_values, features=False, seg_start=starts, seg_len=lens)[1]
+
+
+# =================================================================================================
+def sinusoid_table(n_position, d_hid):
+    """VideoMAE's fixed position table (HF:videomae/modeling_videomae.py:80-91), float64 numpy then float32."""
+    import numpy as np
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)
+    table = pos / np.power(10000, 2 * (j // 2) / d_hid)[None, :]
+    table[:, 0::2] = np.sin(table[:, 0::2])
+    table[:, 1::2] = np.cos(table[:, 1::2])
+    return torch.tensor(table, dtype=torch.float32)
+
+
+class HipVideoMAEModel(_HipModule):
+    """`model(inputs).last_hidden_state` of extract_vision_huggingface.py:155 (VideoMAE branch)."""
+    _destroy = "mer_videomae_destroy"
+
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
+        super().__init__()
+        sd = _sd_of(state_dict)
+        self.config = config
+        self.device = torch.device(device)
+        _, tf_passes = _PREC[precision]
+        lo = tf_passes >= 2
+        hold = self._hold = _Holder(device, dtype)
+        D = config.hidden_size
+        cfg = VideoMAEConfig()
+        cfg.tf = _tf_config(D, config.num_attention_heads, config.intermediate_size, config.num_hidden_layers, True, MER_ACT_GELU,
+                            config.layer_norm_eps, dtype, tf_passes)
+        cfg.image_size, cfg.patch_size, cfg.channels = config.image_size, config.patch_size, config.num_channels
+        cfg.num_frames, cfg.tubelet_size = config.num_frames, config.tubelet_size
+        cfg.final_ln = int("layernorm.weight" in sd)
+        self.num_patches = (config.image_size // config.patch_size) ** 2 * (config.num_frames // config.tubelet_size)
+        w = VideoMAEWeights()
+        w.patch_w = hold.w16(sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1), lo)
+        w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
+        w.pos = hold.f32(sinusoid_table(self.num_patches, D))
+        if cfg.final_ln:
+            w.final_ln_g, w.final_ln_b = hold.f32(sd["layernorm.weight"]), hold.f32(sd["layernorm.bias"])
+        layers = (TfLayer * config.num_hidden_layers)()
+        zeros = torch.zeros(D)
+        for l in range(config.num_hidden_layers):
+            q = f"encoder.layer.{l}."
+            a = q + "attention.attention."
+            if a + "query.bias" in sd:
+                bq, bk, bv = sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]
+            else:  # transformers <= 4.x: separate q_bias / v_bias parameters, no key bias
+                bq, bk, bv = sd.get(a + "q_bias", zeros), zeros, sd.get(a + "v_bias", zeros)
+            layers[l] = _tf_layer(
+                hold, lo, sd[a + "query.weight"], bq, sd[a + "key.weight"], bk, sd[a + "value.weight"], bv,
+                sd[q + "attention.output.dense.weight"], sd[q + "attention.output.dense.bias"],
+                (sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"]),
+                sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"],
+                sd[q + "output.dense.bias"], (sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"]))
+        w.layers = C.cast(layers, C.POINTER(TfLayer))
+        self._layers = layers
+        _lib.check(_lib.lib().mer_videomae_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_videomae_create")
+        self._cfg = cfg
+
+    @classmethod
+    def from_hf(cls, hf_model, **kw):
+        return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def forward_raw(self, pixel_values, *, hidden=True, seg_start=None, seg_len=None):
+        x = pixel_values
+        if not x.is_cuda:
+            x = x.to(self.device)
+        x = x.to(torch.float32).contiguous()
+        B = x.shape[0]
+        c = self._cfg
+        assert x.shape[1:] == (c.num_frames, c.channels, c.image_size, c.image_size), x.shape
+        D = self.config.hidden_size
+        out = torch.empty((B, self.num_patches, D), dtype=torch.float32, device=self.device) if hidden else None
+        ss, sl, nseg = self._seg(seg_start, seg_len)
+        pooled = torch.empty((nseg, D), dtype=torch.float32, device=self.device) if nseg else None
+        wp, wn = self._workspace(_lib.lib().mer_videomae_workspace_bytes(self._handle, B))
+        _lib.check(_lib.lib().mer_videomae_forward(
+            self._handle, x.data_ptr(), B, wp, wn, out.data_ptr() if hidden else None, ss.data_ptr() if nseg else None,
+            sl.data_ptr() if nseg else None, nseg, pooled.data_ptr() if nseg else None, stream()), "mer_videomae_forward")
+        return out, pooled
+
+    def __call__(self, pixel_values=None, **_):
+        return EncoderOutput(last_hidden_state=self.forward_raw(pixel_values)[0])
+
+    def extract_segments(self, pixel_values):
+        """Fused path of extract_vision_huggingface.py:156-158: view(F/ts, patches_per_frame, D).mean(1) per video
+        -> [B * F/ts, D]."""
+        B = pixel_values.shape[0]
+        nseg = self._cfg.num_frames // self._cfg.tubelet_size
+        per = self.num_patches // nseg
+        starts = [b * self.num_patches + s * per for b in range(B) for s in range(nseg)]
+        return self.forward_raw(pixel_values, hidden=False, seg_start=starts, seg_len=[per] * len(starts))[1]
 
 
 # =================================================================================================

@@ -104,3 +104,53 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
         pending.append((vid, px))
         nframes += len(px)
     flush()
+
+
+# ---- VideoMAE branch (reference :147-159) -------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def videomae_preprocess(frames_bgr, size=224):
+    """func_opencv_to_numpy + VideoMAEImageProcessor (reference :29-35,151-153): BGR->RGB, resize shortest edge to
+    `size` (PIL bilinear), centre crop, /255, ImageNet normalise.  uint8 [16,h,w,3] -> float32 [1,16,3,size,size]."""
+    from PIL import Image
+    out = np.empty((len(frames_bgr), 3, size, size), dtype=np.float32)
+    mean = np.array(IMAGENET_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(IMAGENET_STD, dtype=np.float32)[:, None, None]
+    for i, f in enumerate(frames_bgr):
+        img = Image.fromarray(np.ascontiguousarray(f[:, :, ::-1]))
+        w, h = img.size
+        if (w, h) != (size, size):
+            short, long = (w, h) if w <= h else (h, w)
+            nw, nh = (size, int(size * long / short)) if w <= h else (int(size * long / short), size)
+            img = img.resize((nw, nh), resample=Image.BILINEAR)
+            left, top = (nw - size) // 2, (nh - size) // 2
+            img = img.crop((left, top, left + size, top + size))
+        arr = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+        out[i] = (arr - mean) / std
+    return torch.from_numpy(out)[None]
+
+
+def extract_videomae(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, videos_per_batch=8, reader=func_read_frames):
+    """VideoMAE branch of the reference loop: 16 uniformly resampled frames per video -> last_hidden_state ->
+    view(8, 196, D).mean(1) -> [8, D] (FRAME) or its mean (UTTERANCE).  `model`: HipVideoMAEModel; videos are batched."""
+    os.makedirs(save_dir, exist_ok=True)
+    vids = vids if vids is not None else os.listdir(face_dir)
+    nseg = model.config.num_frames // model.config.tubelet_size
+    pending = []
+
+    def flush():
+        if not pending:
+            return
+        seg = model.extract_segments(torch.cat([p for _, p in pending], 0)).cpu().numpy()
+        for i, (vid, _) in enumerate(pending):
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), seg[i * nseg:(i + 1) * nseg], feature_level, seg.shape[-1])
+        pending.clear()
+
+    for vid in vids:
+        frames = resample_frames_uniform(reader(face_dir, vid), nframe=model.config.num_frames)
+        pending.append((vid, videomae_preprocess(frames, model.config.image_size)))
+        if len(pending) >= videos_per_batch:
+            flush()
+    flush()

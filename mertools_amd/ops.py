@@ -132,7 +132,7 @@ def posconv_pack(x, G, K, *, dtype="f16", lo=False):
 
 def vit_patchify(px, P, *, dtype="f16", lo=False):
     N, Cc, H, W = px.shape
-    oh = torch.empty((N * (H // P) * (W // P), Cc * P * P), dtype=torch16(dtype), device=px.device)
+    oh = torch.empty((N * (H // P) * (W // P), (Cc * P * P + 7) // 8 * 8), dtype=torch16(dtype), device=px.device)
     ol = torch.empty_like(oh) if lo else None
     _lib.check(_lib.lib().mer_vit_patchify(_p(px), N, Cc, H, W, P, _p(oh), _p(ol), dt_code(dtype), stream()), "mer_vit_patchify")
     return oh, ol

@@ -30,6 +30,9 @@ def hubert_config(size="base", **over):
                 conv_dim=(512,) * 7, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2),
                 feat_extract_norm="group", conv_bias=False, feat_proj_layer_norm=True, num_conv_pos_embeddings=128,
                 num_conv_pos_embedding_groups=16, do_stable_layer_norm=False, layer_norm_eps=1e-5, model_type="hubert")
+    if size == "large":
+        base.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                    feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
     if size == "tiny":
         base.update(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
                     num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
@@ -73,6 +76,9 @@ def clip_config(size="base16", **over):
     v = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, patch_size=16,
              image_size=224, num_channels=3, layer_norm_eps=1e-5, hidden_act="quick_gelu")
     proj = 512
+    if size == "large14":
+        v.update(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, patch_size=14)
+        proj = 768
     if size == "tiny":
         v.update(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=64)
         proj = 64
@@ -103,10 +109,49 @@ def clip_state_dict(cfg, seed=0):
     return sd
 
 
+def videomae_config(size="base", **over):
+    base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, image_size=224,
+                patch_size=16, num_channels=3, num_frames=16, tubelet_size=2, layer_norm_eps=1e-12, use_mean_pooling=False,
+                model_type="videomae")
+    if size == "large":
+        base.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    if size == "tiny":
+        base.update(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, image_size=96, num_frames=8)
+    base.update(over)
+    return SimpleNamespace(**base)
+
+
+def videomae_state_dict(cfg, seed=0):
+    g = _g(seed)
+    D, P, ts, Cn = cfg.hidden_size, cfg.patch_size, cfg.tubelet_size, cfg.num_channels
+    sd = {"embeddings.patch_embeddings.projection.weight": torch.randn(D, Cn, ts, P, P, generator=g) / math.sqrt(Cn * ts * P * P),
+          "embeddings.patch_embeddings.projection.bias": torch.randn(D, generator=g) * 0.05}
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        for nme in ("query", "key", "value"):
+            sd[p + f"attention.attention.{nme}.weight"], sd[p + f"attention.attention.{nme}.bias"] = _lin(g, D, D)
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = _lin(g, D, D)
+        sd[p + "layernorm_before.weight"], sd[p + "layernorm_before.bias"] = _ln(g, D)
+        sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"] = _ln(g, D)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = _lin(g, cfg.intermediate_size, D)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = _lin(g, D, cfg.intermediate_size, std=0.5 / math.sqrt(cfg.intermediate_size))
+    if not cfg.use_mean_pooling:
+        sd["layernorm.weight"], sd["layernorm.bias"] = _ln(g, D)
+    return sd
+
+
+def synth_video(B, F=16, S=224, seed=1238):
+    px = torch.randint(0, 256, (B, F, S, S, 3), generator=_g(seed), dtype=torch.uint8).float() / 255.0
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    return ((px - mean) / std).permute(0, 1, 4, 2, 3).contiguous()
+
+
 def bert_config(size="roberta-base", **over):
     base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=50265,
                 max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5, hidden_act="gelu",
                 model_type="roberta")
+    if size == "roberta-large":
+        base.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
     if size == "bert-base":
         base.update(vocab_size=21128, max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
                     model_type="bert")

@@ -171,6 +171,40 @@ def clip_cfg_from_hf(c):
 
 
 # ------------------------------------------------------------------------------------------------
+# VideoMAE  (HF:videomae/modeling_videomae.py)
+# ------------------------------------------------------------------------------------------------
+def videomae_sinusoid(n_position, d_hid):
+    """HF:videomae/modeling_videomae.py:80-91 (float64 numpy table cast to float32)."""
+    import numpy as np
+    tab = np.array([[pos / np.power(10000, 2 * (j // 2) / d_hid) for j in range(d_hid)] for pos in range(n_position)])
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    return torch.FloatTensor(tab)
+
+
+def videomae_last_hidden_state(sd, cfg, pixel_values):
+    """`model(inputs).last_hidden_state` (extract_vision_huggingface.py:155).  pixel_values [B,F,C,H,W]."""
+    eps = cfg.get("layer_norm_eps", 1e-12)
+    P, ts = cfg["patch_size"], cfg["tubelet_size"]
+    x = F.conv3d(pixel_values.permute(0, 2, 1, 3, 4), sd["embeddings.patch_embeddings.projection.weight"],
+                 sd["embeddings.patch_embeddings.projection.bias"], stride=(ts, P, P)).flatten(2).transpose(1, 2)
+    x = x + videomae_sinusoid(x.shape[1], x.shape[2])[None]
+    H = cfg["num_attention_heads"]
+    for l in range(cfg["num_hidden_layers"]):  # HF:...:326-358 (pre-LN)
+        p = f"encoder.layer.{l}."
+        a = p + "attention.attention."
+        h = _ln(x, sd, p + "layernorm_before", eps)
+        x = x + _mhsa(h, sd[a + "query.weight"], sd.get(a + "query.bias"), sd[a + "key.weight"], sd.get(a + "key.bias"),
+                      sd[a + "value.weight"], sd.get(a + "value.bias"), sd[p + "attention.output.dense.weight"],
+                      sd[p + "attention.output.dense.bias"], H)
+        h = _gelu(F.linear(_ln(x, sd, p + "layernorm_after", eps), sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        x = x + F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    if "layernorm.weight" in sd:
+        x = _ln(x, sd, "layernorm", eps)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
 # BERT / RoBERTa  (HF:roberta/modeling_roberta.py, HF:bert/modeling_bert.py)
 # ------------------------------------------------------------------------------------------------
 def bert_hidden_states(sd, cfg, input_ids, attention_mask=None, token_type_ids=None):

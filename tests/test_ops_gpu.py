@@ -147,7 +147,7 @@ def test_layernorm(dev, D):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (2, 50, 3), (1, 197, 12), (2, 249, 4), (1, 257, 2), (1, 499, 2)])
+@pytest.mark.parametrize("B,T,H", [(2, 64, 2), (2, 50, 3), (1, 197, 12), (2, 249, 4), (1, 257, 2), (1, 499, 2), (1, 600, 2), (2, 1568, 1)])
 def test_attention(dev, dtype, B, T, H):
     ops = _ops()
     t16 = ops.torch16(dtype)

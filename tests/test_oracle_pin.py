@@ -58,6 +58,21 @@ def test_encoder_oracle_matches_live_hf_stable_layer_norm():
         assert rel_err(a, b)[0] < 2e-6
 
 
+def test_videomae_oracle_matches_live_hf():
+    tr = pytest.importorskip("transformers")
+    cfg = W.videomae_config("tiny")
+    sd = W.videomae_state_dict(cfg, 5)
+    hc = tr.VideoMAEConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, image_size=96,
+                           num_frames=8, use_mean_pooling=False, attn_implementation="eager")
+    m = tr.VideoMAEModel(hc).eval()
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    px = W.synth_video(2, 8, 96, seed=9)
+    with torch.no_grad():
+        ref = m(px).last_hidden_state
+    assert rel_err(R.videomae_last_hidden_state(sd, vars(cfg), px), ref)[0] < 2e-6
+
+
 def test_fusion_oracle_matches_reference_goldens():
     g = _g("fusion_attention.npz")
     sd = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init_")}
