@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
     ap.add_argument("--precision", default="balanced", choices=["fast", "balanced", "accurate"],
                     help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo, default, meets 1e-3 parity), accurate=3")
+    ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -116,14 +117,29 @@ def main():
     frames_per_clip = [8] * B
     lengths = [64] * B
 
+    # the three encoders are independent: each runs on its own HIP stream so that the tail of one kernel (a partial
+    # last wave of workgroups) and the small text GEMMs overlap with another modality's work
+    streams = {m: torch.cuda.Stream(device=dev) for m in "avt"} if args.streams else None
+
+    def run(m):
+        if m == "a":
+            return models["a"].extract_utterance(inputs["a"])
+        if m == "v":
+            return models["v"].extract_utterance(inputs["v"], frames_per_clip)
+        return models["t"].extract_utterance(inputs["t"], lengths, 1, -1)
+
     def step():
         out = []
-        if "a" in mods:
-            out.append(models["a"].extract_utterance(inputs["a"]))
-        if "v" in mods:
-            out.append(models["v"].extract_utterance(inputs["v"], frames_per_clip))
-        if "t" in mods:
-            out.append(models["t"].extract_utterance(inputs["t"], lengths, 1, -1))
+        if streams is None:
+            return [run(m) for m in "avt" if m in mods]
+        cur = torch.cuda.current_stream()
+        for m in "vat":   # longest first
+            if m in mods:
+                streams[m].wait_stream(cur)
+                with torch.cuda.stream(streams[m]):
+                    out.append(run(m))
+        for m in mods:
+            cur.wait_stream(streams[m])
         return out
 
     def barrier():
@@ -163,8 +179,15 @@ def main():
         tot_ms = sum(r["ms"] for r in recs.values())
         dom = max(recs.values(), key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic = None  # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc) and dom["name"].startswith("gemm16"):
+            k = json.load(open(pmc)).get("gemm16<DF16_Li256>")
+            if k:
+                traffic = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
+                           "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/r01_pmc_hbm_traffic.txt"}
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2), "launches": dom["calls"],
                     "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
                     "other_kernels": {k: {"ms_share": round(v["ms"] / tot_ms, 4),
@@ -182,7 +205,7 @@ def main():
             "config": {"workload": "tri-modal base extract: HuBERT-base 5s@16kHz + CLIP-ViT-B/16 8x224^2 + RoBERTa-base 64 tok "
                                    "(BASELINE.json configs[3] extraction leg = configs[1]+[2]+text on each GPU)",
                        "clips_per_gpu_per_step": B, "modalities": "".join(sorted(mods)), "precision": args.precision,
-                       "weights": "random-init (seed 0), HF architectures", "parallelism": f"clip-sharded x{world}, no collective",
+                       "weights": "random-init (seed 0), HF architectures", "streams": 3 if args.streams else 1, "parallelism": f"clip-sharded x{world}, no collective",
                        "gflop_per_clip": gflop_clip},
             "roofline": roofline,
         }

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Aggregates rocprofv3 counter_collection CSVs (FETCH_SIZE / WRITE_SIZE passes) per kernel: mean per launch.
+FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B (bytes = value * 1024); on gfx950 FETCH_SIZE reports half
+the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md §HBM), so fetch is also shown doubled."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+agg = defaultdict(lambda: defaultdict(list))
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"]
+                short = "gemm16<" + ",".join(name.split("gemm16_kernelI")[1].split("E")[0:1]) + ">" if "gemm16_kernel" in name else name.split("(")[0][-60:]
+                agg[short][counter].append(float(row["Counter_Value"]))
+out = {}
+print(f"{'kernel':70s} {'launches':>8s} {'fetch MB/launch':>16s} {'x2 (gfx950)':>12s} {'write MB/launch':>16s}")
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
+    fe, wr = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
+    fmb = sum(fe) / max(len(fe), 1) * 1024 / 1e6
+    wmb = sum(wr) / max(len(wr), 1) * 1024 / 1e6
+    out[k] = dict(launches=len(fe) or len(wr), fetch_mb=fmb, fetch_mb_x2=2 * fmb, write_mb=wmb)
+    print(f"{k[:70]:70s} {len(fe) or len(wr):8d} {fmb:16.2f} {2 * fmb:12.2f} {wmb:16.2f}")
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
