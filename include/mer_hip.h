@@ -86,6 +86,10 @@ typedef struct {
   long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int passes;   /* 1 = a_hi*w_hi; 2 = + a_hi*w_lo (needs w_lo); 3 = + a_lo*w_hi (needs a_lo too) */
   int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N); 3 = 256x256 (8 waves, 1 workgroup/CU) */
+  /* headmajor_T > 0: the 16-bit output is written head-major for attention instead of row-major:
+   * element (row = b*T + t, col = which*64*H + h*64 + d) goes to c16[which][b][h][t][d] (contiguous [T,64] per head);
+   * needs M % T == 0, N % (64*H) == 0, c16_hi, no batching. */
+  int headmajor_T, headmajor_H;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
@@ -114,6 +118,11 @@ int mer_layernorm(const float* x, long long ldx, const float* gamma, const float
 int mer_attention(const void* q, const void* k, const void* v, long long ld,
                   void* out_hi, void* out_lo, long long ldo,
                   int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
+
+/* Same attention on head-major operands: q, k, v are [B][H][T][64] planes (as written by mer_gemm16's head-major
+ * output), so every head's K/V tile is one contiguous 128*T-byte stream.  out stays row-major [B*T, ldo]. */
+int mer_attention_hm(const void* q, const void* k, const void* v, void* out_hi, void* out_lo, long long ldo,
+                     int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
 
 /* fp32 -> 16-bit planes (lo may be NULL). n elements. */
 int mer_split16(const float* x, void* hi, void* lo, long long n, int dtype, mer_stream_t stream);

@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("c16_hi", c_void_p), ("c16_lo", c_void_p), ("ldc16", c_ll),
         ("nbatch", c_int), ("nb_inner", c_int),
         ("a_so", c_ll), ("a_si", c_ll), ("w_si", c_ll), ("bias_si", c_ll), ("c_so", c_ll), ("c_si", c_ll),
-        ("passes", c_int), ("tile", c_int),
+        ("passes", c_int), ("tile", c_int), ("headmajor_T", c_int), ("headmajor_H", c_int),
     ]
 
 
@@ -119,6 +119,8 @@ _PROTOS = {
                               c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     "mer_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                               c_float, c_void_p, c_int, c_void_p]),
+    "mer_attention_hm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_float, c_void_p,
+                                 c_int, c_void_p]),
     "mer_split16": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     "mer_hubert_conv0_gn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

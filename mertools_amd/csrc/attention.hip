@@ -17,10 +17,13 @@
 
 namespace mer {
 
+extern unsigned long long* g_gemm_dbg;
+int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
+
 template <typename T, int NKT>
 __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
-                                                      long long ldo, int Tn, float scale_log2e, const int* kv_len) {
+                                                      long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
   constexpr int TP = NKT * 16;
@@ -32,36 +35,59 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+  const long long dbi = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * 4;
+  if (dbg && tid == 0) dbg[dbi] = __builtin_amdgcn_s_memtime();
   int klen = Tn;
   if (kv_len) {
     klen = kv_len[b];
     klen = klen < Tn ? klen : Tn;
   }
   const long long row0 = (long long)b * Tn;
-  const T* kb = k + row0 * ld + h * 64;
-  const T* vb = v + row0 * ld + h * 64;
-  const T* qb = q + row0 * ld + h * 64;
+  // row-major: head h lives at column 64h of every [B*T, ld] row; head-major (hm): [B][H][T][64], row stride 64
+  const long long hbase = hm ? ((long long)b * gridDim.y + h) * Tn * 64 : row0 * ld + h * 64;
+  if (hm) ld = 64;
+  const T* kb = k + hbase;
+  const T* vb = v + hbase;
+  const T* qb = q + hbase;
 
-  // ---- stage K (row-major, padded) and V^T into LDS; rows >= klen are zero ----
-  // (issuing all loads before the first LDS write was measured: no gain, more VGPRs)
-  for (int c = tid; c < TP * 8; c += 256) {
-    const int row = c >> 3, ch = c & 7;
-    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-    if (row < klen) {
-      kv = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
-      vv = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
-    }
-    *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kv;
-    const v8 vh = __builtin_bit_cast(v8, vv);
+  // ---- stage K (row-major, padded) and V^T into LDS; rows >= klen are zero.  Loads are issued SG chunks at a time
+  // ahead of their LDS writes: one memory round trip per SG*32 rows instead of one per 32 rows. ----
+  constexpr int SIT = TP * 8 / 256, SG = 4;
+  for (int g0 = 0; g0 < SIT; g0 += SG) {
+    u32x4 kreg[SG], vreg[SG];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
+    for (int it = 0; it < SG; ++it) {
+      const int c = tid + (g0 + it) * 256;
+      const int row = c >> 3, ch = c & 7;
+      kreg[it] = u32x4{0u, 0u, 0u, 0u};
+      vreg[it] = u32x4{0u, 0u, 0u, 0u};
+      if (g0 + it < SIT && row < klen) {
+        kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
+        vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < SG; ++it) {
+      if (g0 + it < SIT) {
+        const int c = tid + (g0 + it) * 256;
+        const int row = c >> 3, ch = c & 7;
+        *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kreg[it];
+        const v8 vh = __builtin_bit_cast(v8, vreg[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
+      }
+    }
   }
 
   __syncthreads();
+  if (dbg && tid == 0) dbg[dbi + 1] = __builtin_amdgcn_s_memtime();
 
   // K / V^T of this (batch, head) are staged once; each wave then walks its 16-query sub-tiles
   // (qs = wave, wave+4, ...), so the staging cost is paid once per head instead of once per 64 queries.
   for (int qs = qt * 4 + wave; qs * 16 < Tn; qs += 4 * (int)gridDim.x) {
+  // K / V^T fragments are loop-invariant LDS reads: without this clobber hipcc hoists all of them out of the loop
+  // (28 + 56 fragment registers -> 256 VGPR + ~90 AGPR, one workgroup per CU instead of two)
+  asm volatile("" ::: "memory");
   // ---- this lane's query fragment (B operand: n = query li, k = d) ----
   const int qi = qs * 16 + li;
   const int qrow = qi < Tn ? qi : Tn - 1;
@@ -154,6 +180,7 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
     }
   }
   }  // q sub-tile loop
+  if (dbg && tid == 0) dbg[dbi + 2] = __builtin_amdgcn_s_memtime();
 }
 
 // Streaming (online-softmax) kernel for T > 512 (VideoMAE: 1568 tokens).  One workgroup = (batch, head, 64
@@ -163,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
 template <typename T>
 __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, long long ld, T* oh, T* ol,
-                                                          long long ldo, int Tn, float scale_log2e, const int* kv_len) {
+                                                          long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
   constexpr int KB = 64, KS = 72, VS = KB + 4;
@@ -178,9 +205,12 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
     klen = klen < Tn ? klen : Tn;
   }
   const long long row0 = (long long)b * Tn;
-  const T* kb = k + row0 * ld + h * 64;
-  const T* vb = v + row0 * ld + h * 64;
-  const T* qb = q + row0 * ld + h * 64;
+  // row-major: head h lives at column 64h of every [B*T, ld] row; head-major (hm): [B][H][T][64], row stride 64
+  const long long hbase = hm ? ((long long)b * gridDim.y + h) * Tn * 64 : row0 * ld + h * 64;
+  if (hm) ld = 64;
+  const T* kb = k + hbase;
+  const T* vb = v + hbase;
+  const T* qb = q + hbase;
   const int qi = qt * 64 + wave * 16 + li;
   const int qrow = qi < Tn ? qi : Tn - 1;
   v8 qf[2];
@@ -288,14 +318,18 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
 
 template <typename T>
 static int launch_attn(const void* q, const void* k, const void* v, long long ld, void* oh, void* ol, long long ldo,
-                       int B, int Tn, int H, float scale, const int* kv_len, hipStream_t st) {
+                       int B, int Tn, int H, float scale, const int* kv_len, int hm, hipStream_t st) {
   const float sl2 = scale * 1.4426950408889634f;
   dim3 grid(1, H, B), block(256);  // one workgroup per (batch, head): K/V staged once
   ProfScope prof("attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
 #define MER_ATTN_CASE(N)                                                                                       \
   hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
-                     (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len)
-  if (Tn <= 64) MER_ATTN_CASE(4);
+                     (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg)
+  const int f = g_attn_force_nkt;
+  if (f == 14 && Tn <= 224) MER_ATTN_CASE(14);
+  else if (f == 18 && Tn <= 288) MER_ATTN_CASE(18);
+  else if (f == 32 && Tn <= 512) MER_ATTN_CASE(32);
+  else if (Tn <= 64) MER_ATTN_CASE(4);
   else if (Tn <= 128) MER_ATTN_CASE(8);
   else if (Tn <= 224) MER_ATTN_CASE(14);
   else if (Tn <= 256) MER_ATTN_CASE(16);
@@ -304,7 +338,7 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   else {
     dim3 sgrid((unsigned)cdiv(Tn, 64), H, B);
     hipLaunchKernelGGL((attn_stream_kernel<T>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
-                       ldo, Tn, sl2, kv_len);
+                       ldo, Tn, sl2, kv_len, hm);
   }
 #undef MER_ATTN_CASE
   return check_launch("attention");
@@ -321,8 +355,21 @@ extern "C" int mer_attention(const void* q, const void* k, const void* v, long l
   MER_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, MER_ESHAPE, "mer_attention: ld %% 8 / ldo %% 4 alignment");
   MER_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, MER_EINVAL, "mer_attention: q/k/v must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, st);
-  if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, st);
+  if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 0, st);
+  if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 0, st);
   set_error("mer_attention: bad dtype %d", dtype);
+  return MER_EINVAL;
+}
+
+extern "C" int mer_attention_hm(const void* q, const void* k, const void* v, void* out_hi, void* out_lo, long long ldo, int B,
+                                int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(q && k && v && out_hi, MER_EINVAL, "mer_attention_hm: null pointer");
+  MER_REQUIRE(B > 0 && T > 0 && H > 0 && ldo % 4 == 0, MER_ESHAPE, "mer_attention_hm: bad shape B=%d T=%d H=%d", B, T, H);
+  MER_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, MER_EINVAL, "mer_attention_hm: q/k/v must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, 64, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 1, st);
+  if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, 64, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 1, st);
+  set_error("mer_attention_hm: bad dtype %d", dtype);
   return MER_EINVAL;
 }

@@ -39,6 +39,7 @@ struct Gemm16Params {
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
+  int hm_T, hm_H;  // > 0: 16-bit output scattered head-major [N/(64*hm_H)][M/hm_T][hm_H][hm_T][64] (QKV for attention)
   unsigned long long* dbg;  // optional: 4 s_memtime stamps per workgroup (start, first slab ready, K loop done, end)
 };
 
@@ -430,8 +431,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
               h[j] = hh;
               l[j] = ll;
             }
-            *reinterpret_cast<v8*>(c16h + (long long)row * p.ldc16 + col) = h;
-            if (c16l) *reinterpret_cast<v8*>(c16l + (long long)row * p.ldc16 + col) = l;
+            long long o16 = (long long)row * p.ldc16 + col;
+            if (p.hm_T > 0) {  // head-major scatter: (which, b, h, t, d); 8 columns never straddle a 64-wide head
+              const int dd = p.hm_H * 64, which = col / dd, hh2 = (col % dd) >> 6, d0 = col & 63;
+              const int bb = row / p.hm_T, tt = row % p.hm_T;
+              o16 = ((((long long)which * (p.M / p.hm_T) + bb) * p.hm_H + hh2) * p.hm_T + tt) * 64 + d0;
+            }
+            *reinterpret_cast<v8*>(c16h + o16) = h;
+            if (c16l) *reinterpret_cast<v8*>(c16l + o16) = l;
           }
         }
       } else {
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 }
 
 int g_gemm_glds = 1;
-unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer()  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
+unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS>
 static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
@@ -515,8 +522,10 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
   return MER_OK;
 }
 
+namespace mer { extern int g_attn_force_nkt; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
+  if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
 }
@@ -535,6 +544,9 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
               "mer_gemm16: batch strides of A / W must be multiples of 8 elements");
   MER_REQUIRE(a->dtype == MER_DT_F16 || a->dtype == MER_DT_BF16, MER_EINVAL, "mer_gemm16: bad dtype %d", a->dtype);
   MER_REQUIRE(a->c32 || a->c16_hi, MER_EINVAL, "mer_gemm16: no output given");
+  MER_REQUIRE(a->headmajor_T == 0 || (a->headmajor_T > 0 && a->headmajor_H > 0 && a->M % a->headmajor_T == 0 && a->N % (64 * a->headmajor_H) == 0 &&
+                                      a->c16_hi && a->N % 8 == 0 && (a->nbatch <= 1)),
+              MER_ESHAPE, "mer_gemm16: head-major output needs M %% T == 0, N %% (64*H) == 0, a 16-bit output and no batching");
   MER_REQUIRE(!a->c16_lo || a->c16_hi, MER_EINVAL, "mer_gemm16: c16_lo without c16_hi");
   const int nbatch = a->nbatch > 0 ? a->nbatch : 1;
   Gemm16Params p;
@@ -549,6 +561,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   p.a_so = a->a_so; p.a_si = a->a_si; p.w_si = a->w_si; p.bias_si = a->bias_si; p.c_so = a->c_so; p.c_si = a->c_si;
   p.tiles_m = p.tiles_n = 0;
   p.dbg = g_gemm_dbg;
+  p.hm_T = a->headmajor_T; p.hm_H = a->headmajor_H;
   // the vector epilogue moves 8 columns per lane with 16-byte accesses
   bool vec = (a->N % 8 == 0) && (a->c_so % 8 == 0) && (a->c_si % 8 == 0);
   if (a->residual) vec = vec && (a->ldr % 4 == 0) && (((uintptr_t)a->residual & 15) == 0);

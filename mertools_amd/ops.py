@@ -55,7 +55,8 @@ def split16_host(x, dtype="f16", lo=True):
 
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
-           out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0):
+           out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
+           headmajor=None):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -76,6 +77,8 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.c32, g.ldc32 = _p(c32), N
     g.c16_hi, g.c16_lo, g.ldc16 = _p(c16h), _p(c16l), N
     g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, passes, tile
+    if headmajor is not None:
+        g.headmajor_T, g.headmajor_H = headmajor
     _lib.check(_lib.lib().mer_gemm16(g, stream()), "mer_gemm16")
     return c32, c16h, c16l
 
@@ -107,6 +110,18 @@ def attention(qkv, B, T, H, scale, *, kv_len=None, out_lo=False):
     _lib.check(_lib.lib().mer_attention(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, 3 * D,
                                         _p(oh), _p(ol), D, B, T, H, float(scale), _p(kv_len), dt_code(qkv.dtype), stream()),
                "mer_attention")
+    return oh, ol
+
+
+def attention_hm(qkv_hm, B, T, H, scale, *, kv_len=None, out_lo=False):
+    """qkv_hm: 16-bit [3, B, H, T, 64] (head-major, as written by gemm16(headmajor=(T, H))) -> ctx [B*T, H*64]."""
+    D = H * 64
+    assert qkv_hm.numel() == 3 * B * T * D and qkv_hm.is_contiguous()
+    oh = torch.empty((B * T, D), dtype=qkv_hm.dtype, device=qkv_hm.device)
+    ol = torch.empty_like(oh) if out_lo else None
+    plane = B * T * D * qkv_hm.element_size()
+    _lib.check(_lib.lib().mer_attention_hm(qkv_hm.data_ptr(), qkv_hm.data_ptr() + plane, qkv_hm.data_ptr() + 2 * plane, _p(oh), _p(ol),
+                                           D, B, T, H, float(scale), _p(kv_len), dt_code(qkv_hm.dtype), stream()), "mer_attention_hm")
     return oh, ol
 
 

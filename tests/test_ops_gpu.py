@@ -162,6 +162,26 @@ def test_attention(dev, dtype, B, T, H):
     assert_close((oh.float() + ol.float()).cpu(), ref, 6e-3 if dtype == "bf16" else 8e-4, f"attention {dtype}")
 
 
+@pytest.mark.parametrize("B,T,H,tile", [(3, 50, 2, 1), (2, 197, 4, 3), (1, 600, 2, 3)])
+def test_qkv_headmajor_gemm_and_attention(dev, B, T, H, tile):
+    """QKV projection written head-major by the GEMM epilogue + attention reading that layout == the row-major path."""
+    ops = _ops()
+    D = H * 64
+    x = _rand((B * T, D), 60).half()
+    w = (_rand((3 * D, D), 61) * 0.05).half()
+    bias = _rand((3 * D,), 62)
+    xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
+    _, qkv_rm, _ = ops.gemm16(xd, wd, bias=bd, out16=True, dtype="f16", tile=tile)
+    _, qkv_hm, _ = ops.gemm16(xd, wd, bias=bd, out16=True, dtype="f16", tile=tile, headmajor=(T, H))
+    torch.cuda.synchronize()
+    exp = qkv_rm.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous()
+    assert torch.equal(qkv_hm.view(3, B, H, T, 64), exp), "head-major scatter must hold exactly the row-major values"
+    o_rm, _ = ops.attention(qkv_rm, B, T, H, 0.125)
+    o_hm, _ = ops.attention_hm(qkv_hm.view(3, B, H, T, 64), B, T, H, 0.125)
+    torch.cuda.synchronize()
+    assert torch.equal(o_rm, o_hm)
+
+
 def test_attention_kv_len_mask(dev):
     ops = _ops()
     B, T, H = 3, 64, 2
