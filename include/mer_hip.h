@@ -207,6 +207,12 @@ int mer_mse_loss_bwd(const float* pred, const float* target, const float* gout, 
 int mer_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float clip_value, mer_stream_t stream);
 
+/* hipGraph-replayable Adam: reads the 0-based step count from device memory (uses step+1); call mer_inc_i32 on the
+ * counter once per optimiser step after all tensors were updated. */
+int mer_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int* step_dev, float clip_value, mer_stream_t stream);
+int mer_inc_i32(int* x, mer_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Encoder level                                                                               */
 /* ------------------------------------------------------------------------------------------ */

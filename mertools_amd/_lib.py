@@ -146,6 +146,9 @@ _PROTOS = {
     "mer_mse_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mer_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float,
                               c_int, c_float, c_void_p]),
+    "mer_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float,
+                                  c_void_p, c_float, c_void_p]),
+    "mer_inc_i32": (c_int, [c_void_p, c_void_p]),
     "mer_hubert_create": (c_int, [C.POINTER(HubertConfig), C.POINTER(HubertWeights), C.POINTER(c_void_p)]),
     "mer_hubert_destroy": (None, [c_void_p]),
     "mer_hubert_out_frames": (c_int, [c_void_p, c_int]),

@@ -109,6 +109,27 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
   }
 }
 
+// Graph-replayable Adam: the step counter lives on the device (a captured launch cannot take a new host value
+// per replay); thread 0 of the LAST tensor's launch bumps it (bump != 0).
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                                float eps, float wd, int* step_dev, float clip, int bump) {
+  const int step = *step_dev + 1;
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    gi = fmaf(wd, p[i], gi);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+  (void)bump;
+}
+__global__ void inc_kernel(int* x) { if (threadIdx.x == 0 && blockIdx.x == 0) *x += 1; }
+
 static inline unsigned g1(long long n) {
   long long g = cdiv(n, 256);
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -177,4 +198,16 @@ extern "C" int mer_adam_step(float* p, const float* g, float* m, float* v, long 
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   adam_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, clip_value);
   return check_launch("adam_step");
+}
+
+extern "C" int mer_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int* step_dev, float clip_value, mer_stream_t stream) {
+  MER_REQUIRE(p && g && m && v && step_dev && n > 0, MER_EINVAL, "mer_adam_step_dev: bad args");
+  adam_dev_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, clip_value, 0);
+  return check_launch("adam_step_dev");
+}
+extern "C" int mer_inc_i32(int* x, mer_stream_t stream) {
+  MER_REQUIRE(x, MER_EINVAL, "mer_inc_i32: null");
+  inc_kernel<<<1, 64, 0, (hipStream_t)stream>>>(x);
+  return check_launch("inc_i32");
 }

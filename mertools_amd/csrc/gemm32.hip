@@ -17,14 +17,31 @@ __global__ __launch_bounds__(64) void gemm32_kernel(const float* __restrict__ a,
   const int m = blockIdx.y * 16 + li;   // A row this lane feeds
   const int n = blockIdx.x * 16 + li;   // W row this lane feeds
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // contiguous-k operands are fetched as one 16-byte load per lane and k-step when alignment allows
+  const bool va = !TA && (lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0) && (K % 16 == 0) && m < M;
+  const bool vw = !TW && (ldw % 4 == 0) && ((((uintptr_t)w) & 15) == 0) && (K % 16 == 0) && n < N;
   for (int k0 = 0; k0 < K; k0 += 16) {
     float av[4], wv[4];
+    const int kb = k0 + lg * 4;
+    if (va) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a + (long long)m * lda + kb);
+      av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + lg * 4 + j;
-      const bool kin = k < K;
-      av[j] = (kin && m < M) ? (TA ? a[(long long)k * lda + m] : a[(long long)m * lda + k]) : 0.f;
-      wv[j] = (kin && n < N) ? (TW ? w[(long long)k * ldw + n] : w[(long long)n * ldw + k]) : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const int k = kb + j;
+        av[j] = (k < K && m < M) ? (TA ? a[(long long)k * lda + m] : a[(long long)m * lda + k]) : 0.f;
+      }
+    }
+    if (vw) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(w + (long long)n * ldw + kb);
+      wv[0] = t[0]; wv[1] = t[1]; wv[2] = t[2]; wv[3] = t[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kb + j;
+        wv[j] = (k < K && n < N) ? (TW ? w[(long long)k * ldw + n] : w[(long long)n * ldw + k]) : 0.f;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc, 0, 0, 0);

@@ -276,6 +276,12 @@ class HipHubertModel(_HipModule):
         return pooled
 
 
+# wav2vec 2.0 shares HuBERT's architecture and HF parameter names (feature_extractor.conv_layers.*,
+# feature_projection.*, encoder.pos_conv_embed.*, encoder.layers.*): the reference's audio script treats them alike
+# (extract_audio_huggingface.py:92-100), and so does this class.
+HipWav2Vec2Model = HipHubertModel
+
+
 # =================================================================================================
 class HipCLIPModel(_HipModule):
     _destroy = "mer_vit_destroy"

@@ -16,6 +16,7 @@ run() { # name timeout cmd...
 if [[ $what == tests || $what == all ]]; then
   run ops 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x --no-header -p no:cacheprovider
   run enc 900 python -m pytest tests/test_encoders_gpu.py -m gpu -q --no-header -p no:cacheprovider -s
+  run fusion 600 python -m pytest tests/test_fusion_gpu.py tests/test_extract_gpu.py -m gpu -q --no-header -p no:cacheprovider
   run smoke 300 python __graft_entry__.py smoke
 fi
 if [[ $what == bench || $what == all ]]; then
@@ -23,7 +24,7 @@ if [[ $what == bench || $what == all ]]; then
 fi
 if [[ $what == prof || $what == all ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?" | tee -a "$OLDPWD/gpurun_out/suite.log")
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --streams 0 > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?" | tee -a "$OLDPWD/gpurun_out/suite.log")
   find gpurun_out/prof -name "*kernel_stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && head -30 "$f"
   # keep only the small summaries
   find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete

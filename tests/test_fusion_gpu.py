@@ -114,3 +114,24 @@ def test_dropout_is_inverted_and_seeded(dev):
     y.sum().backward()
     assert torch.equal((x.grad != 0), (y != 0))
     assert dropout(x, 0.25, False) is x
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_graph_trainer_matches_reference(dev, use_graph):
+    """FusionGraphTrainer (flat parameters, device-side Adam step counter, hipGraph replay) reproduces the reference's
+    5 training steps; graph replay and eager execution of the same kernels agree bit for bit."""
+    from mertools_amd.fusion_trainer import FusionGraphTrainer
+    from mertools_amd.toolkit.models import get_models
+    g = np.load(os.path.join(G, "fusion_attention.npz"))
+    m = get_models(_args()).to(dev)
+    _load(m.model, g, "init_")
+    tr = FusionGraphTrainer(m, lr=1e-3, weight_decay=1e-5, grad_clip=-1.0, use_graph=use_graph)
+    losses = []
+    for s in range(len(g["losses"])):
+        batch = {k: torch.from_numpy(g["x_" + k][s]).to(dev) for k in ("audios", "texts", "videos")}
+        loss, e, v = tr.train_step(batch, torch.from_numpy(g["emos"][s]).to(dev), torch.from_numpy(g["vals"][s]).to(dev))
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=5e-5)
+    for k, p in m.model.state_dict().items():
+        assert_close(p.cpu(), torch.from_numpy(g["final_" + k]), 1e-4, f"final {k} (graph={use_graph})")
+    assert sorted(m.model.state_dict()) == sorted(k[5:] for k in g.files if k.startswith("init_"))

@@ -58,6 +58,24 @@ def test_encoder_oracle_matches_live_hf_stable_layer_norm():
         assert rel_err(a, b)[0] < 2e-6
 
 
+def test_wav2vec2_shares_the_hubert_restatement():
+    """Wav2Vec2Model (chinese-wav2vec2-base/large in the reference's model list) has HuBERT's forward and key names."""
+    tr = pytest.importorskip("transformers")
+    cfg = W.hubert_config("tiny")
+    sd = W.hubert_state_dict(cfg, 7)
+    wc = tr.Wav2Vec2Config(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
+                           num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, attn_implementation="eager",
+                           feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False)
+    m = tr.Wav2Vec2Model(wc).eval()
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and set(r.missing_keys) <= {"masked_spec_embed"}, r
+    wav = W.synth_audio(2, 6000, seed=13)
+    with torch.no_grad():
+        hs = m(wav, output_hidden_states=True).hidden_states
+    for a, b in zip(R.hubert_hidden_states(sd, vars(cfg), wav), hs):
+        assert rel_err(a, b)[0] < 2e-6
+
+
 def test_videomae_oracle_matches_live_hf():
     tr = pytest.importorskip("transformers")
     cfg = W.videomae_config("tiny")
