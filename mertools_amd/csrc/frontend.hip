@@ -69,6 +69,101 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int
   }
 }
 
+// Fast path (k <= 10, C % 8 == 0): a thread owns 8 CONSECUTIVE channels (80 weights in registers) and every 4th frame of
+// the workgroup's 256-frame chunk, so the apply pass writes one 16-byte store per frame and lane — a wave emits whole
+// 1 KiB channel rows (C = 512) instead of 2-byte scattered stores — and the stats pass needs 8x fewer LDS broadcasts
+// per FMA.  Waves of a workgroup cover the same channels at different frames; their partial sums meet in LDS.
+constexpr int C0_KF = 10;
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void conv0_fast_kernel(const float* wav, int L, int T0, const float* w, int C, int k,
+                                                         int stride, const float* gamma, const float* beta, float eps,
+                                                         double* stats, T* ohi, T* olo) {
+  __shared__ float xs[C0_TCH * 8 + C0_KMAX];
+  __shared__ float part[2][4][64 * 8];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * C0_TCH;
+  const int nt = (T0 - t0) < C0_TCH ? (T0 - t0) : C0_TCH;
+  const int nin = (nt - 1) * stride + k;
+  const float* xb = wav + (long long)b * L + (long long)t0 * stride;
+  for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  for (int cb = 0; cb < C; cb += 512) {   // uniform trip count: the loop body contains workgroup barriers
+    const int c0 = cb + lane * 8;
+    const bool on = c0 < C;               // C % 8 == 0: a lane's 8 channels are all in or all out
+    float wr[8][C0_KF];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int j = 0; j < C0_KF; ++j) wr[c][j] = (on && j < k) ? w[(c0 + c) * k + j] : 0.f;
+    if (!APPLY) {
+      float s[8], q[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s[c] = q[c] = 0.f;
+      for (int t = tq; t < nt; t += 4) {
+        float xv[C0_KF];
+#pragma unroll
+        for (int j = 0; j < C0_KF; ++j) xv[j] = xs[t * stride + j];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float y = 0.f;
+#pragma unroll
+          for (int j = 0; j < C0_KF; ++j) y = fmaf(wr[c][j], xv[j], y);
+          s[c] += y;
+          q[c] = fmaf(y, y, q[c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        part[0][tq][lane * 8 + c] = s[c];
+        part[1][tq][lane * 8 + c] = q[c];
+      }
+      __syncthreads();
+      if (tq == 0 && on) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int i = lane * 8 + c;
+          const float ss = (part[0][0][i] + part[0][1][i]) + (part[0][2][i] + part[0][3][i]);
+          const float qq = (part[1][0][i] + part[1][1][i]) + (part[1][2][i] + part[1][3][i]);
+          atomicAdd(&stats[((long long)b * C + c0 + c) * 2 + 0], (double)ss);
+          atomicAdd(&stats[((long long)b * C + c0 + c) * 2 + 1], (double)qq);
+        }
+      }
+      __syncthreads();
+    } else if (on) {
+      float ga[8], be[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double mean_d = stats[((long long)b * C + c0 + c) * 2 + 0] / (double)T0;
+        const double var_d = stats[((long long)b * C + c0 + c) * 2 + 1] / (double)T0 - mean_d * mean_d;
+        const float rstd = 1.0f / sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + eps);
+        ga[c] = gamma[c0 + c] * rstd;
+        be[c] = beta[c0 + c] - (float)mean_d * ga[c];
+      }
+      for (int t = tq; t < nt; t += 4) {
+        float xv[C0_KF];
+#pragma unroll
+        for (int j = 0; j < C0_KF; ++j) xv[j] = xs[t * stride + j];
+        typename T16<T>::v8 h, l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float y = 0.f;
+#pragma unroll
+          for (int j = 0; j < C0_KF; ++j) y = fmaf(wr[c][j], xv[j], y);
+          const float z = act_apply(fmaf(y, ga[c], be[c]), MER_ACT_GELU);
+          T hh, ll;
+          split16<T>(z, hh, ll);
+          h[c] = hh;
+          l[c] = ll;
+        }
+        const long long o = ((long long)b * T0 + t0 + t) * C + c0;
+        *reinterpret_cast<typename T16<T>::v8*>(ohi + o) = h;
+        if (olo) *reinterpret_cast<typename T16<T>::v8*>(olo + o) = l;
+      }
+    }
+  }
+}
+
 // conv0 without normalisation (feat_extract_norm == "layer": HuBERT-large / wav2vec2-large, HF:hubert/modeling_hubert.py:127-151):
 // y[b,t,c] = bias[c] + sum_j w[c,j] x[b, t*stride + j], fp32 channels-last; LayerNorm + GELU follow as mer_layernorm.
 __global__ __launch_bounds__(256) void conv0_plain_kernel(const float* wav, int L, int T0, const float* w, const float* bias, int C,
@@ -284,17 +379,16 @@ extern "C" int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* 
   MER_REQUIRE(e == hipSuccess, MER_ELAUNCH, "mer_hubert_conv0_gn: memset failed: %s", hipGetErrorString(e));
   dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
   ProfScope prof("hubert_conv0_gn", 2.0 * 2 * (double)B * T0 * C * k, (double)B * L * 4 * 2 + (double)B * T0 * C * (out_lo ? 4 : 2), st);
+  const bool fast = k <= C0_KF && C % 8 == 0;
+#define MER_CONV0(K, TT, AP, OH, OL) hipLaunchKernelGGL((K<TT, AP>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats, OH, OL)
   if (dtype == MER_DT_F16) {
-    hipLaunchKernelGGL((conv0_kernel<f16, false>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
-                       (f16*)nullptr, (f16*)nullptr);
-    hipLaunchKernelGGL((conv0_kernel<f16, true>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
-                       (f16*)out_hi, (f16*)out_lo);
+    if (fast) { MER_CONV0(conv0_fast_kernel, f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(conv0_fast_kernel, f16, true, (f16*)out_hi, (f16*)out_lo); }
+    else { MER_CONV0(conv0_kernel, f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(conv0_kernel, f16, true, (f16*)out_hi, (f16*)out_lo); }
   } else {
-    hipLaunchKernelGGL((conv0_kernel<bf16, false>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
-                       (bf16*)nullptr, (bf16*)nullptr);
-    hipLaunchKernelGGL((conv0_kernel<bf16, true>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats,
-                       (bf16*)out_hi, (bf16*)out_lo);
+    if (fast) { MER_CONV0(conv0_fast_kernel, bf16, false, (bf16*)nullptr, (bf16*)nullptr); MER_CONV0(conv0_fast_kernel, bf16, true, (bf16*)out_hi, (bf16*)out_lo); }
+    else { MER_CONV0(conv0_kernel, bf16, false, (bf16*)nullptr, (bf16*)nullptr); MER_CONV0(conv0_kernel, bf16, true, (bf16*)out_hi, (bf16*)out_lo); }
   }
+#undef MER_CONV0
   return check_launch("hubert_conv0_gn");
 }
 

@@ -39,6 +39,7 @@ struct Gemm16Params {
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
+  int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
   int hm_T, hm_H;  // > 0: 16-bit output scattered head-major [N/(64*hm_H)][M/hm_T][hm_H][hm_T][64] (QKV for attention)
   unsigned long long* dbg;  // optional: 4 s_memtime stamps per workgroup (start, first slab ready, K loop done, end)
 };
@@ -423,14 +424,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
             *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
           }
           if (c16h) {
-            v8 h, l;
+            v8 h;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-              T hh, ll;
-              split16<T>(v[j], hh, ll);
-              h[j] = hh;
-              l[j] = ll;
-            }
+            for (int j = 0; j < CPL; ++j) h[j] = T16<T>::from_f32(v[j]);
             long long o16 = (long long)row * p.ldc16 + col;
             if (p.hm_T > 0) {  // head-major scatter: (which, b, h, t, d); 8 columns never straddle a 64-wide head
               const int dd = p.hm_H * 64, which = col / dd, hh2 = (col % dd) >> 6, d0 = col & 63;
@@ -438,7 +434,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
               o16 = ((((long long)which * (p.M / p.hm_T) + bb) * p.hm_H + hh2) * p.hm_T + tt) * 64 + d0;
             }
             *reinterpret_cast<v8*>(c16h + o16) = h;
-            if (c16l) *reinterpret_cast<v8*>(c16l + o16) = l;
+            if (c16l) {  // lo plane only when a 3-pass consumer needs it (3 extra VALU per element otherwise wasted)
+              v8 l;
+#pragma unroll
+              for (int j = 0; j < CPL; ++j) l[j] = T16<T>::from_f32(v[j] - T16<T>::to_f32(h[j]));
+              *reinterpret_cast<v8*>(c16l + o16) = l;
+            }
           }
         }
       } else {
@@ -462,6 +463,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       }
     }
   };
+  if (p.dbg_skip == 2) {
+    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
+    return;
+  }
+  if (p.dbg_skip == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
   switch (p.act) {  // one specialised copy of the epilogue per activation: no per-element switch
     case MER_ACT_GELU: epilogue(std::integral_constant<int, MER_ACT_GELU>{}); break;
     case MER_ACT_QUICK_GELU: epilogue(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
@@ -471,6 +477,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
+int g_gemm_skip = 0;
 int g_gemm_glds = 1;
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
@@ -525,6 +532,7 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
 namespace mer { extern int g_attn_force_nkt; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
@@ -561,6 +569,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   p.a_so = a->a_so; p.a_si = a->a_si; p.w_si = a->w_si; p.bias_si = a->bias_si; p.c_so = a->c_so; p.c_si = a->c_si;
   p.tiles_m = p.tiles_n = 0;
   p.dbg = g_gemm_dbg;
+  p.dbg_skip = g_gemm_skip;
   p.hm_T = a->headmajor_T; p.hm_H = a->headmajor_H;
   // the vector epilogue moves 8 columns per lane with 16-byte accesses
   bool vec = (a->N % 8 == 0) && (a->c_so % 8 == 0) && (a->c_si % 8 == 0);
