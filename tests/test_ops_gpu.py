@@ -291,3 +291,31 @@ def test_gemm32_exact_fp32(dev, M, N, K):
     acc = ops.gemm32(a.to(dev), w.to(dev), None, None, out=out_t.clone(), accumulate=True)
     torch.cuda.synchronize()
     assert_close(acc.cpu(), (2 * (a.double() @ w.double().T)).float(), 2e-6, "gemm32 accumulate")
+
+
+def test_gemm16_random_shape_sweep(dev):
+    """Ragged / tiny / odd shapes through every tile and pass count (row & column guards, K tails, scalar epilogue)."""
+    ops = _ops()
+    import random
+    rnd = random.Random(1234)
+    cases = [(1, 8, 8), (1, 1, 8), (5, 3, 16), (17, 24, 40), (129, 257, 72), (255, 100, 200), (256, 256, 32), (260, 8, 520)]
+    cases += [(rnd.randint(1, 700), rnd.randint(1, 90) * 4 if rnd.random() < 0.7 else rnd.randint(1, 300), rnd.randint(1, 60) * 8) for _ in range(12)]
+    for idx, (M, N, K) in enumerate(cases):
+        a = _rand((M, K), 100 + idx)
+        w = _rand((N, K), 200 + idx) * 0.1
+        bias = _rand((N,), 300 + idx)
+        res = _rand((M, N), 400 + idx)
+        ah, al = ops.split16(a.to(dev), "f16")
+        wh, wl = ops.split16_host(w, "f16")
+        wh, wl = wh.to(dev), wl.to(dev)
+        ref1 = F.relu(ah.float().cpu().double() @ wh.float().cpu().double().T + bias.double()) + res.double()
+        ref3 = F.relu(a.double() @ w.double().T + bias.double()) + res.double()
+        for tile in (1, 2, 3):
+            for passes in (1, 2, 3):
+                c32, c16, _ = ops.gemm16(ah, wh, a_lo=al if passes == 3 else None, w_lo=wl if passes >= 2 else None, bias=bias.to(dev),
+                                         act="relu", residual=res.to(dev), out32=True, out16=True, passes=passes, dtype="f16", tile=tile)
+                torch.cuda.synchronize()
+                ref = ref1 if passes == 1 else ref3
+                tol = 2e-5 if passes != 2 else 1e-3
+                assert_close(c32.cpu(), ref.float(), tol, f"gemm16 M={M} N={N} K={K} tile={tile} passes={passes}")
+                assert_close(c16.float().cpu(), ref.float(), 2e-3, f"gemm16 c16 M={M} N={N} K={K} tile={tile} passes={passes}")
