@@ -33,6 +33,9 @@ GFLOP_PER_CLIP = {"hubert-base": 71.67, "clip-vit-b16-8f": 281.0, "roberta-base-
 PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
+MFMA_PASSES = {"gemm16": 1, "gemm16_w2": 2, "gemm16_x3": 3, "gemm16_mx": 1.5}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,8 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
-    ap.add_argument("--precision", default="balanced", choices=["fast", "balanced", "accurate"],
-                    help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo, default, meets 1e-3 parity), accurate=3")
+    ap.add_argument("--precision", default="balanced", choices=["fast", "balanced", "mx", "accurate"],
+                    help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo, default, meets 1e-3 parity), "
+                         "mx=1 + MX-fp4 correction of the weight residual (same parity as balanced), accurate=3")
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -183,7 +187,7 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic = None  # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc) and dom["name"].startswith("gemm16"):
+        if os.path.exists(pmc) and dom["name"] == "gemm16_w2":
             k = json.load(open(pmc)).get("gemm16<DF16_Li256>")
             if k:
                 traffic = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
@@ -191,8 +195,9 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     # the default 2-pass (weights hi+lo) kernel issues 2x the algorithmic MFMA work; 3-pass 3x
-                    "mfma_passes": {"gemm16": 1, "gemm16_w2": 2, "gemm16_x3": 3}.get(dom["name"], 1),
-                    "mfma_issued_frac": round(ach * {"gemm16": 1, "gemm16_w2": 2, "gemm16_x3": 3}.get(dom["name"], 1) / PEAK_F16_TFLOPS, 4),
+                    # (gemm16_mx: one f16 pass + a bf8 x fp4 K=128 correction at the fp8 MFMA rate = 1.5 f16-pass equivalents)
+                    "mfma_passes": MFMA_PASSES.get(dom["name"], 1),
+                    "mfma_issued_frac": round(ach * MFMA_PASSES.get(dom["name"], 1) / PEAK_F16_TFLOPS, 4),
                     "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 2), "launches": dom["calls"],
                     "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
                     "other_kernels": {k: {"ms_share": round(v["ms"] / tot_ms, 4),

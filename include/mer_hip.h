@@ -84,14 +84,25 @@ typedef struct {
   void* c16_hi; void* c16_lo; long long ldc16;
   int nbatch, nb_inner;
   long long a_so, a_si, w_si, bias_si, c_so, c_si;
-  int passes;   /* 1 = a_hi*w_hi; 2 = + a_hi*w_lo (needs w_lo); 3 = + a_lo*w_hi (needs a_lo too) */
+  int passes;   /* 1 = a_hi*w_hi; 2 = + a_hi*w_lo (needs w_lo); 3 = + a_lo*w_hi (needs a_lo too);
+                 * 4 = a_hi*w_hi + bf8(a_hi)*mxfp4(w - w_hi): the weight residual as an MX-scaled fp4 plane (w_mx, from
+                 * mer_mx_pack) through v_mfma_scale_f32_16x16x128_f8f6f4, 1/4 of an f16 pass; f16, 256x256 tile,
+                 * K % 128 == 0, no batching — other shapes run passes=2 with w_lo */
   int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N); 3 = 256x256 (8 waves, 1 workgroup/CU) */
   /* headmajor_T > 0: the 16-bit output is written head-major for attention instead of row-major:
    * element (row = b*T + t, col = which*64*H + h*64 + d) goes to c16[which][b][h][t][d] (contiguous [T,64] per head);
    * needs M % T == 0, N % (64*H) == 0, c16_hi, no batching. */
   int headmajor_T, headmajor_H;
+  const void* w_mx;   /* passes == 4: packed MX-fp4 residual plane of W (mer_mx_pack), 16-byte aligned */
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
+
+/* Host-side packer of the MX correction plane.  w_res: HOST fp32 [N, K] (row stride ldw) = W - f16(W);
+ * out: HOST buffer of mer_mx_packed_bytes(N, K) bytes (then copied to the device once).  Per (256-column tile,
+ * 32-deep k-slab) one 5 KB block: four 16-column tiles of e2m1 codes in the lane order of the MFMA B operand
+ * + the E8M0 scales (one per column and 32 k-slots) of the slab's 128-k group; K % 128 == 0.  Returns 0 bytes / MER_ESHAPE for unsupported shapes. */
+long long mer_mx_packed_bytes(int N, int K);
+int mer_mx_pack(const float* w_res, long long ldw, int N, int K, void* out);
 
 /* Exact-fp32 GEMM on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain): C = act(A*W^T + bias).
  * A [M,K] fp32 (lda), W [N,K] fp32 (ldw), C [M,N] fp32 (ldc).  Used by the fusion classifier
@@ -217,7 +228,7 @@ int mer_inc_i32(int* x, mer_stream_t stream);
 /* Encoder level                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-typedef struct { const void* hi; const void* lo; } mer_w16; /* 16-bit weight planes [N,K] */
+typedef struct { const void* hi; const void* lo; const void* mx; } mer_w16; /* 16-bit weight planes [N,K] (+ MX residual plane for passes == 4, may be null) */
 
 /* One transformer block (HuBERT / wav2vec2 / CLIP-ViT / VideoMAE / BERT / RoBERTa).
  * wqkv = cat(q,k,v) rows [3D, D]; bqkv fp32 [3D] (zeros where the model has no bias). */
@@ -236,7 +247,7 @@ typedef struct {
   int act;        /* MER_ACT_GELU | MER_ACT_QUICK_GELU */
   float ln_eps;
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
-  int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split) or 3 (both split) */
+  int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split) or 4 (MX-corrected, see mer_gemm16) */
 } mer_tf_config;
 
 /* ---- HuBERT / wav2vec2 audio encoder --------------------------------------------------------
@@ -252,7 +263,7 @@ typedef struct {
   int feat_proj_layer_norm;
   int pos_k, pos_groups;
   int stable_layer_norm;    /* 1: HubertEncoderStableLayerNorm (large) */
-  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1, 2 or 3 */
+  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1, 2, 3 or 4 */
 } mer_hubert_config;
 
 typedef struct {

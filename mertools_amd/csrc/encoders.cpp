@@ -52,7 +52,7 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
   g.a_hi = a.hi; g.a_lo = a.lo; g.lda = lda;
-  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = K;
+  g.w_hi = w.hi; g.w_lo = w.lo; g.w_mx = w.mx; g.ldw = K;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
@@ -121,7 +121,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.hidden > 0 && c.heads > 0 && c.hidden % c.heads == 0, MER_EINVAL, "%s: bad hidden/heads", who);
   MER_REQUIRE(c.hidden / c.heads == 64, MER_EUNSUPPORTED, "%s: head_dim %d != 64 unsupported", who, c.hidden / c.heads);
   MER_REQUIRE(c.hidden % 8 == 0 && c.ffn % 8 == 0, MER_ESHAPE, "%s: hidden/ffn must be multiples of 8", who);
-  MER_REQUIRE(c.passes >= 1 && c.passes <= 3, MER_EINVAL, "%s: passes must be 1, 2 or 3", who);
+  MER_REQUIRE(c.passes >= 1 && c.passes <= 4, MER_EINVAL, "%s: passes must be 1, 2, 3 or 4 (MX-corrected)", who);
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
   MER_REQUIRE(c.dtype == MER_DT_F16 || c.dtype == MER_DT_BF16, MER_EINVAL, "%s: bad dtype", who);
   return MER_OK;
@@ -156,7 +156,7 @@ extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_
   MER_TRY(check_tf(cfg->tf, "mer_hubert_create"));
   MER_REQUIRE(cfg->n_conv >= 2 && cfg->n_conv <= MER_MAX_CONV, MER_EINVAL, "mer_hubert_create: n_conv=%d", cfg->n_conv);
   MER_REQUIRE(cfg->conv_dim % 8 == 0, MER_ESHAPE, "mer_hubert_create: conv_dim %% 8 != 0");
-  MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 3, MER_EINVAL, "mer_hubert_create: conv_passes must be 1, 2 or 3");
+  MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 4, MER_EINVAL, "mer_hubert_create: conv_passes must be 1, 2, 3 or 4");
   MER_REQUIRE(cfg->tf.hidden % cfg->pos_groups == 0 && (cfg->tf.hidden / cfg->pos_groups) % 8 == 0, MER_ESHAPE,
               "mer_hubert_create: hidden/pos_groups must be a multiple of 8");
   MER_REQUIRE(w->layers && w->conv0_w && w->fp_w.hi && w->pos_w.hi, MER_EINVAL, "mer_hubert_create: missing weights");
@@ -263,7 +263,7 @@ extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, 
     g.M = B * p.T[i]; g.N = C; g.K = c.conv_kernel[i] * C; g.dtype = dt;
     g.a_hi = src.hi; g.a_lo = src.lo; g.lda = (long long)c.conv_stride[i] * C;
     g.a_rows_per_batch = p.T[i]; g.a_batch_stride = (long long)p.T[i - 1] * C;
-    g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.ldw = g.K;
+    g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.w_mx = w.conv_w[i].mx; g.ldw = g.K;
     g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
     if (c.feat_norm_group) {

@@ -24,6 +24,7 @@
 //     neighbouring tiles; bijective for any grid size).
 #include "common.h"
 #include <string.h>
+#include <math.h>
 #include <type_traits>
 
 namespace mer {
@@ -32,6 +33,7 @@ struct Gemm16Params {
   int M, N, K;
   const void* a_hi; const void* a_lo; long long lda; int a_rpb; long long a_bstride;
   const void* w_hi; const void* w_lo; long long ldw;
+  const void* w_mx;   // MX kernel: packed fp4 + E8M0 correction plane (mer_mx_pack)
   const float* bias; int act;
   const float* residual; long long ldr;
   float* c32; long long ldc32;
@@ -62,7 +64,43 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS>
+// MX mode (256x256 tile, 4x2 waves of 64x128, f16 only): acc += a_hi*w_hi on the f16 MFMA, and once per 128 k the weight
+// residual w - w_hi is added through ONE v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator: A = the f16 fragments the
+// wave already holds, rounded to bf8 (e5m2: the f16 exponent range, so no scale search and no overflow) in registers,
+// B = the residual as MX-fp4 (e2m1, one E8M0 scale per 32 k) packed offline by mer_mx_pack() in exactly the lane
+// order the instruction wants.  The correction costs 1/4 of an f16 pass instead of a whole one (the residual only
+// needs ~3 bits), and its plane is 1/4 of the bytes of the f16 lo plane.
+//   operand layout (measured, scripts/probes/mx_probe*.py): 8-bit A: lane (i, g) byte p <-> k-slot 16g + p (p < 16),
+//   64 + 16g + (p - 16) (p >= 16); fp4 B: lane (n, g) element j <-> k-slot 32g + j, low nibble first; the E8M0 scale
+//   of (n, slots 32b..32b+31) is byte `opsel` of lane n + 16b's scale register.  A lane's A bytes 8s..8s+7 are its
+//   fragment of slab s of the group (k = 32s + 8g + e), which fixes the k <-> slot permutation the packer applies.
+//   Registers are the constraint (8 waves x 256): the bf8 A copy is 8 dwords per 16-row tile per group, so the wave
+//   tile is 64 rows (32 dwords) and the B fragments are read from LDS only when they are used.
+//   LDS: the fp4 plane of a 128-k group (16 column tiles x 1 KB + 1 KB of scales) lives in a double-buffered group
+//   area behind the slab ring; every slab's DMA brings one quarter of it (+ the scales), one instruction per wave.
+constexpr int MX_BLOCK = 5120;                 // global bytes per (256-column tile, slab): 4 column tiles + group scales
+constexpr int MXG_BYTES = 16384 + 1024;        // LDS bytes of one group buffer
+constexpr int MX_LDS = 2 * MXG_BYTES + 1024;   // two groups + a dump KB for the waves with nothing to fetch
+
+// 16-byte-per-lane LDS-DMA with a uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: one VGPR per address
+// instead of the VGPR pair the builtin's flat form needs.  lds_off (uniform) goes to M0; lane l lands at lds_off + 16 l.
+__device__ __forceinline__ void dma16_sbase(const void* sbase_any, unsigned voff, unsigned lds_off) {
+  const unsigned long long pv = (unsigned long long)sbase_any;   // wave-uniform by construction: pin it to SGPRs
+  const unsigned long long sbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int OPS>
+__device__ __forceinline__ f32x4 mx_mfma(i32x8 a, i32x8 b, f32x4 c, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 1 /*A bf8*/, 4 /*B fp4*/, 0, 0x7f7f7f7f, OPS, sb);
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
   constexpr int NT = WM * WN * 64;
@@ -77,10 +115,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   constexpr int ROWS_PER_IT = NT / C;
   constexpr int A_PLANE = BM * RB, W_PLANE = BN * RB;
   constexpr int STAGE = AP * A_PLANE + WP * W_PLANE;
+  static_assert(!MX || (GLDS && STAGGER && AP == 1 && WP == 1 && BN == 256 && WN == 2 && TN == 8 && std::is_same<T, f16>::value),
+                "MX correction: 256-wide 8-wave (4x2) f16 tile only");
   constexpr int CLD = SN + 4;          // padded fp32 row of the per-wave C staging tile
-  constexpr int EROWS = SM > 64 ? 32 : SM;   // rows of the wave tile staged per epilogue chunk
+  constexpr int EROWS = SN > 64 ? 16 : (SM > 64 ? 32 : SM);   // rows of the wave tile staged per epilogue chunk
   constexpr int CSTAGE = WM * WN * EROWS * CLD * 4;
-  constexpr int SMEM = (NS * STAGE > CSTAGE) ? NS * STAGE : CSTAGE;
+  constexpr int RING = NS * STAGE + (MX ? MX_LDS : 0);
+  constexpr int SMEM = (RING > CSTAGE) ? RING : CSTAGE;
   static_assert(NS >= 2 && (GLDS || NS == 2), "register-staged loader is double-buffered only");
   static_assert(NT % C == 0 && (BM * C) % NT == 0 && (BN * C) % NT == 0, "bad tile/thread split");
 
@@ -188,20 +229,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     }
   }
   const int wave_row0 = (tid >> 6) * (64 / C);  // first tile row of this wave's 1 KiB piece
+  // MX kernel: registers are scarce, so the DMA addresses are a uniform base (SGPRs, advanced by k) + a 32-bit per-lane
+  // byte offset (the launcher checks that the planes are < 4 GB) instead of a 64-bit VGPR pair per load.
+  unsigned a_o32[CA], w_o32[CW], mx_o32 = 0;
+  if (MX) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) a_o32[i] = (unsigned)(a_src[i] * 2);
+#pragma unroll
+    for (int i = 0; i < CW; ++i) w_o32[i] = (unsigned)(w_src[i] * 2);
+    mx_o32 = (unsigned)((tid < 320 ? tid : 256 + (tid & 63)) * 16);
+  }
+  const char* mx_base = MX ? (const char*)p.w_mx + ((long long)tile_n * ((p.K + BK - 1) / BK)) * MX_BLOCK : nullptr;
   auto glds_issue = [&](int k0, int stage) {
     char* base = smem + stage * STAGE;
+    if constexpr (MX) {
+      const char* ab = (const char*)a_pl[0] + (long long)k0 * 2;
+      const char* wb = (const char*)w_pl[0] + (long long)k0 * 2;
+      const unsigned lb = lds_offset_of(base) + wave_row0 * RB;
 #pragma unroll
-    for (int pl = 0; pl < AP; ++pl)
+      for (int i = 0; i < CA; ++i) dma16_sbase(ab, a_o32[i], lb + i * ROWS_PER_IT * RB);
 #pragma unroll
-      for (int i = 0; i < CA; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0),
-                                         (lds_void_t*)(base + pl * A_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
+      for (int i = 0; i < CW; ++i) dma16_sbase(wb, w_o32[i], lb + A_PLANE + i * ROWS_PER_IT * RB);
+      // this tile column's block of slab kt: waves 0-3 one column tile each, wave 4 the scales, 5-7 -> dump
+      const int kt = k0 / BK, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const unsigned g = lds_offset_of(smem) + NS * STAGE + ((kt >> 2) & 1) * MXG_BYTES;
+      const unsigned dst = w < 4 ? g + ((kt & 3) * 4 + w) * 1024 : (w == 4 ? g + 16384 : lds_offset_of(smem) + NS * STAGE + 2 * MXG_BYTES);
+      dma16_sbase(mx_base + (long long)kt * MX_BLOCK, mx_o32, dst);
+    } else {
 #pragma unroll
-    for (int pl = 0; pl < WP; ++pl)
+      for (int pl = 0; pl < AP; ++pl)
 #pragma unroll
-      for (int i = 0; i < CW; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(w_pl[pl] + w_src[i] + k0),
-                                         (lds_void_t*)(base + AP * A_PLANE + pl * W_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
+        for (int i = 0; i < CA; ++i)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0),
+                                           (lds_void_t*)(base + pl * A_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
+#pragma unroll
+      for (int pl = 0; pl < WP; ++pl)
+#pragma unroll
+        for (int i = 0; i < CW; ++i)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(w_pl[pl] + w_src[i] + k0),
+                                           (lds_void_t*)(base + AP * A_PLANE + pl * W_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
+    }
   };
 
   f32x4 acc[TM][TN];
@@ -273,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     // vmcnt, D-1 slabs stay in flight) before its mid-iteration barrier, i.e. at least one barrier before any
     // wave of either group reads that slab.
     constexpr int D = NS - 1;
-    constexpr int LPS = AP * CA + WP * CW;
+    constexpr int LPS = AP * CA + WP * CW + (MX ? 1 : 0);
     const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN / 2);
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -284,21 +351,79 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memtime();
     if (g1) __builtin_amdgcn_s_barrier();
     int cur = 0, nxt = D;
-    for (int kt = 0; kt < nk; ++kt) {
+    // MX: bf8 copies of this wave's A fragments of the current 128-k group
+    i32x8 aq[MX ? TM : 1];
+#pragma unroll
+    for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto iter = [&](int kt) {
       const bool more = kt + D < nk;
       if (more) glds_issue((kt + D) * BK, nxt);
       load_frags(smem + cur * STAGE, 0);
+      i32x4 wcur, wnx1;   // deliberately not initialised (10 v_mov per slab): only read on the slabs that load them
+      int sc0, sc1;
+      const char* mg = smem + NS * STAGE + ((kt >> 2) & 1) * MXG_BYTES;
+      const bool mx_slab = MX && (kt & 3) == 3;
+      if (mx_slab) {   // last slab of a group: the first two fp4 fragments + the scales come in with the f16 fragments
+        wcur = *reinterpret_cast<const i32x4*>(mg + (wn * TN) * 1024 + lane * 16);
+        wnx1 = *reinterpret_cast<const i32x4*>(mg + (wn * TN + 1) * 1024 + lane * 16);
+        sc0 = *reinterpret_cast<const int*>(mg + 16384 + (wn * 2) * 256 + lane * 4);
+        sc1 = *reinterpret_cast<const int*>(mg + 16384 + (wn * 2 + 1) * 256 + lane * 4);
+      }
       if (more) wait_vmcnt<LPS*(D - 1)>();
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(1);
       math();
+      if constexpr (MX) {
+        // 8 f16 -> 8 bf8 (RNE) per 16-row tile; the group's window shifts by one slab (oldest slab in dwords 0-1) so that
+        // one loop body serves all four slab positions.  Tried and measured worse or spilling: the 4x-unrolled loop with
+        // static indices (21 spills), per-position uniform branches (the conversions get hoisted into temporaries + 16
+        // copies), in-place inline-asm conversions (16 copies), a 64-bit window (the whole window gets copied).
+        {
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) {
+            const v8 a = af[0][mt];
+            i16x2 r0 = __builtin_bit_cast(i16x2, aq[mt][0]), r1 = __builtin_bit_cast(i16x2, aq[mt][1]);   // fully overwritten
+            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[0], a[1]}, 1.0f, false);
+            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[2], a[3]}, 1.0f, true);
+            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[4], a[5]}, 1.0f, false);
+            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[6], a[7]}, 1.0f, true);
+            aq[mt] = i32x8{aq[mt][2], aq[mt][3], aq[mt][4], aq[mt][5], aq[mt][6], aq[mt][7],
+                           __builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)};
+          }
+        }
+        if (mx_slab) {   // the group's fp4 residual fragments straight from the group buffer, one column tile at a time
+          // two column tiles ahead (the LDS is busy with the other wave group's fragment reads: one tile ahead stalled),
+          // no further: the compiler would otherwise pull all 8 reads to the top (32 live registers the kernel lacks)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) {
+            asm volatile("" ::: "memory");
+            i32x4 wnx2 = wnx1;
+            if (nt + 2 < TN) wnx2 = *reinterpret_cast<const i32x4*>(mg + (wn * TN + nt + 2) * 1024 + lane * 16);
+            __builtin_amdgcn_sched_barrier(0);   // keep the read ahead of this tile's MFMAs (it was sunk below them)
+            const i32x8 wb = {wcur[0], wcur[1], wcur[2], wcur[3], 0, 0, 0, 0};
+            const int sc = nt < 4 ? sc0 : sc1;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+              switch (nt & 3) {
+                case 0: acc[mt][nt] = mx_mfma<0>(aq[mt], wb, acc[mt][nt], sc); break;
+                case 1: acc[mt][nt] = mx_mfma<1>(aq[mt], wb, acc[mt][nt], sc); break;
+                case 2: acc[mt][nt] = mx_mfma<2>(aq[mt], wb, acc[mt][nt], sc); break;
+                default: acc[mt][nt] = mx_mfma<3>(aq[mt], wb, acc[mt][nt], sc); break;
+              }
+            }
+            wcur = wnx1;
+            wnx1 = wnx2;
+          }
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
       cur = cur + 1 == NS ? 0 : cur + 1;
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
-    }
+    };
+    for (int kt = 0; kt < nk; ++kt) iter(kt);   // MX: K % 128 == 0 (checked by the launcher)
     if (!g1) __builtin_amdgcn_s_barrier();
     __syncthreads();
     if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -463,11 +588,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       }
     }
   };
-  if (p.dbg_skip == 2) {
+  if ((p.dbg_skip & 3) == 2) {
     if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
     return;
   }
-  if (p.dbg_skip == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
+  if ((p.dbg_skip & 3) == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
   switch (p.act) {  // one specialised copy of the epilogue per activation: no per-element switch
     case MER_ACT_GELU: epilogue(std::integral_constant<int, MER_ACT_GELU>{}); break;
     case MER_ACT_QUICK_GELU: epilogue(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
@@ -477,11 +602,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
+constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 int g_gemm_skip = 0;
 int g_gemm_glds = 1;
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>
 static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   Gemm16Params p = p0;
   p.tiles_m = (int)cdiv(p.M, BM);
@@ -490,21 +616,30 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   // algorithmic work of this launch: 2*M*N*K flops (one pass, whatever AP/WP execute), A + W read once,
   // outputs (+ residual) touched once
   const double mn = (double)p.M * p.N * nbatch;
-  ProfScope prof(AP == 2 ? "gemm16_x3" : (WP == 2 ? "gemm16_w2" : "gemm16"), 2.0 * mn * p.K,
-                 2.0 * AP * nbatch * (double)p.M * p.K + 2.0 * WP * (double)p.N * p.K * (nbatch / p.nb_inner > 0 ? p.nb_inner : 1) +
+  ProfScope prof(MX ? "gemm16_mx" : (AP == 2 ? "gemm16_x3" : (WP == 2 ? "gemm16_w2" : "gemm16")), 2.0 * mn * p.K,
+                 2.0 * AP * nbatch * (double)p.M * p.K + (2.0 * WP + (MX ? 0.25 : 0.0)) * (double)p.N * p.K * (nbatch / p.nb_inner > 0 ? p.nb_inner : 1) +
                      mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.residual ? 4 : 0)),
                  st);
-  if (g_gemm_glds == 2 && p.K % BK == 0)  // A/B: LDS-DMA loader, plain double buffering
-    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, 2>), grid, block, 0, st, p);
-  else if (g_gemm_glds && p.K % BK == 0)
-    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, false, 2>), grid, block, 0, st, p);
-  return check_launch("gemm16");
+  if constexpr (MX) {
+    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, true>), grid, block, 0, st, p);
+    return check_launch("gemm16_mx");
+  } else {
+    if (g_gemm_glds == 2 && p.K % BK == 0)  // A/B: LDS-DMA loader, plain double buffering
+      hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, 2>), grid, block, 0, st, p);
+    else if (g_gemm_glds && p.K % BK == 0)
+      hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, false, 2>), grid, block, 0, st, p);
+    return check_launch("gemm16");
+  }
 }
 
 template <typename T>
 static int dispatch(const Gemm16Params& p, int nbatch, int passes, int tile, hipStream_t st) {
+  if (passes == 4) {  // MX-corrected: eligibility was checked by mer_gemm16
+    if constexpr (std::is_same<T, f16>::value) return launch<T, 256, 256, 32, 4, 2, 1, 1, MX_NS, true>(p, nbatch, st);
+    else return MER_EINVAL;
+  }
   if (tile == 2) {
     if (passes == 3) return launch<T, 128, 64, 32, 2, 2, 2, 2, 3>(p, nbatch, st);
     if (passes == 2) return launch<T, 128, 64, 32, 2, 2, 1, 2, 3>(p, nbatch, st);
@@ -538,14 +673,82 @@ extern "C" int mer_set_option(const char* name, int value) {
   return MER_EINVAL;
 }
 
+// ---- host-side packer of the MX correction plane (weights are prepared once, offline) ----
+extern "C" long long mer_mx_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 128 != 0) return 0;
+  return (long long)((N + 255) / 256) * (K / 32) * mer::MX_BLOCK;
+}
+
+extern "C" int mer_mx_pack(const float* w_res, long long ldw, int N, int K, void* out) {
+  using namespace mer;
+  MER_REQUIRE(w_res && out, MER_EINVAL, "mer_mx_pack: null pointer");
+  MER_REQUIRE(N > 0 && K > 0 && K % 128 == 0, MER_ESHAPE, "mer_mx_pack: K must be a positive multiple of 128 (N=%d K=%d)", N, K);
+  static const float GRID[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};   // e2m1 magnitudes
+  unsigned char* o = (unsigned char*)out;
+  const int nslab = K / 32, ntile = (N + 255) / 256;
+  memset(o, 0, (size_t)mer_mx_packed_bytes(N, K));
+  auto quant = [&](float x, float inv_scale) -> int {   // nearest e2m1 code (ties to the even code), saturating
+    const float m = fabsf(x) * inv_scale;
+    int best = 0; float bd = m;
+    for (int c = 1; c < 8; ++c) {
+      const float d = fabsf(m - GRID[c]);
+      if (d < bd || (d == bd && (c & 1) == 0)) { bd = d; best = c; }
+    }
+    return best | (x < 0.f && best ? 8 : 0);
+  };
+  for (int tn = 0; tn < ntile; ++tn)
+    for (int kg = 0; kg < K / 128; ++kg)
+      for (int ctg = 0; ctg < 16; ++ctg)          // 16-column tile of the 256-column block
+        for (int n16 = 0; n16 < 16; ++n16) {
+          const int n = tn * 256 + ctg * 16 + n16;
+          float v[128];
+          for (int h = 0; h < 128; ++h) {   // k-slot h of the instruction <-> k of the group (see gemm16_kernel)
+            const int hh = h & 63, g = hh >> 4, r = hh & 15, s = (h >> 6) * 2 + (r >> 3), e = r & 7;
+            v[h] = n < N ? w_res[(long long)n * ldw + kg * 128 + 32 * s + 8 * g + e] : 0.f;
+          }
+          // column tile ctg travels with slab (ctg / 4) of the group, as entry (ctg % 4) of that slab's block
+          unsigned char* frag = o + ((size_t)tn * nslab + kg * 4 + ctg / 4) * MX_BLOCK + (ctg % 4) * 1024;
+          for (int b = 0; b < 4; ++b) {
+            float amax = 0.f;
+            for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[32 * b + j]));
+            int sbyte = 0;
+            if (amax > 0.f) {
+              int ex; frexpf(amax, &ex);                 // amax = f * 2^ex, f in [0.5, 1)  ->  floor(log2) = ex - 1
+              const int e0 = ex - 1 - 2;                 // OCP MX: 2^(floor(log2 amax) - emax(e2m1))
+              double best_err = -1.0;
+              for (int cand = e0; cand <= e0 + 1; ++cand) {   // amax/2^e0 is in [4, 8): the coarser scale may fit better
+                const int sb = cand + 127 < 0 ? 0 : (cand + 127 > 254 ? 254 : cand + 127);
+                const float sc = ldexpf(1.f, sb - 127), inv = 1.f / sc;
+                double err = 0.0;
+                for (int j = 0; j < 32; ++j) {
+                  const float x = v[32 * b + j];
+                  const int c = quant(x, inv);
+                  const double d = (double)x - (double)((c & 8) ? -GRID[c & 7] : GRID[c & 7]) * sc;
+                  err += d * d;
+                }
+                if (best_err < 0.0 || err < best_err) { best_err = err; sbyte = sb; }
+              }
+            }
+            const float inv = 1.f / ldexpf(1.f, sbyte - 127);
+            const int lane = n16 + 16 * b;
+            for (int j = 0; j < 32; j += 2)
+              frag[lane * 16 + j / 2] = (unsigned char)(quant(v[32 * b + j], inv) | (quant(v[32 * b + j + 1], inv) << 4));
+            for (int q = 0; q < 4; ++q)   // every slab of the group carries the group's scales: dword [ctg / 4][lane], byte ctg % 4
+              o[((size_t)tn * nslab + kg * 4 + q) * MX_BLOCK + 4096 + (ctg / 4) * 256 + lane * 4 + (ctg % 4)] = (unsigned char)sbyte;
+          }
+        }
+  return MER_OK;
+}
+
 extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   using namespace mer;
   MER_REQUIRE(a != nullptr, MER_EINVAL, "mer_gemm16: null args");
   MER_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, MER_ESHAPE, "mer_gemm16: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   MER_REQUIRE(a->a_hi && a->w_hi, MER_EINVAL, "mer_gemm16: a_hi / w_hi must be non-null");
-  MER_REQUIRE(a->passes >= 1 && a->passes <= 3, MER_EINVAL, "mer_gemm16: passes must be 1, 2 or 3 (got %d)", a->passes);
-  MER_REQUIRE(a->passes < 2 || a->w_lo, MER_EINVAL, "mer_gemm16: passes>=2 needs w_lo");
-  MER_REQUIRE(a->passes < 3 || a->a_lo, MER_EINVAL, "mer_gemm16: passes=3 needs a_lo");
+  MER_REQUIRE(a->passes >= 1 && a->passes <= 4, MER_EINVAL, "mer_gemm16: passes must be 1, 2, 3 or 4 (got %d)", a->passes);
+  MER_REQUIRE(a->passes == 4 || a->passes < 2 || a->w_lo, MER_EINVAL, "mer_gemm16: passes 2/3 need w_lo");
+  MER_REQUIRE(a->passes != 3 || a->a_lo, MER_EINVAL, "mer_gemm16: passes=3 needs a_lo");
+  MER_REQUIRE(a->passes != 4 || a->w_mx || a->w_lo, MER_EINVAL, "mer_gemm16: passes=4 needs w_mx (or w_lo for the 2-pass fallback)");
   MER_REQUIRE(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0, MER_ESHAPE,
               "mer_gemm16: K, lda, ldw must be multiples of 8 (K=%d lda=%lld ldw=%lld)", a->K, a->lda, a->ldw);
   MER_REQUIRE(a->a_so % 8 == 0 && a->a_si % 8 == 0 && a->w_si % 8 == 0 && a->a_batch_stride % 8 == 0, MER_ESHAPE,
@@ -560,7 +763,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   Gemm16Params p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
-  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw;
+  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx;
   p.bias = a->bias; p.act = a->act;
   p.residual = a->residual; p.ldr = a->ldr;
   p.c32 = a->c32; p.ldc32 = a->ldc32;
@@ -578,12 +781,27 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   if (a->c16_hi) vec = vec && (a->ldc16 % 8 == 0) && (((uintptr_t)a->c16_hi & 15) == 0);
   if (a->c16_lo) vec = vec && (((uintptr_t)a->c16_lo & 15) == 0);
   p.vec_ok = vec ? 1 : 0;
-  MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo) & 15) == 0, MER_EINVAL,
+  MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;
   // 256x256 (8 waves, staggered schedule) wins whenever there are enough rows; narrow / short problems keep 4-wave tiles
   if (tile == 0) tile = (a->N <= 64) ? 2 : ((a->M >= 1024 && a->N >= 192) ? 3 : 1);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, a->passes, tile, st);
-  return dispatch<bf16>(p, nbatch, a->passes, tile, st);
+  int passes = a->passes;
+  if (passes == 4) {
+    // the MX correction lives in the 256x256 f16 kernel; anything it does not cover runs the f16 2-pass path
+    // (its DMA uses 32-bit byte offsets from the plane bases, so both planes must span < 4 GB)
+    const long long a_last = a->a_rows_per_batch > 0
+        ? (long long)((a->M - 1) / a->a_rows_per_batch) * a->a_batch_stride + (long long)((a->M - 1) % a->a_rows_per_batch) * a->lda
+        : (long long)(a->M - 1) * a->lda;
+    const bool small = (a_last + a->K) * 2 < (1ll << 32) && ((long long)a->N * a->ldw) * 2 < (1ll << 32);
+    const bool mx_ok = a->w_mx && tile == 3 && a->dtype == MER_DT_F16 && a->K % 128 == 0 && nbatch == 1 && g_gemm_glds == 1 && small;
+    if (!mx_ok) {
+      MER_REQUIRE(a->w_lo, MER_EINVAL, "mer_gemm16: passes=4 on a shape the MX kernel does not cover (tile %d, K=%d, nbatch=%d, dtype %d) needs w_lo",
+                  tile, a->K, nbatch, a->dtype);
+      passes = 2;
+    }
+  }
+  if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, passes, tile, st);
+  return dispatch<bf16>(p, nbatch, passes, tile, st);
 }

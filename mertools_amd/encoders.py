@@ -27,6 +27,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .ops import torch16
 from ._lib import (BertConfig, BertWeights, HubertConfig, HubertWeights, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_MAX_CONV,
                    TfConfig, TfLayer, VideoMAEConfig, VideoMAEWeights, VitConfig, VitWeights, W16)
 from .ops import dt_code, split16_host, stream
@@ -64,32 +65,42 @@ class _Holder:
         self.keep.append(d)
         return d.data_ptr()
 
-    def w16(self, t, lo):
-        hi, lo_t = split16_host(t.contiguous(), self.dtype, lo)
+    def w16(self, t, lo, mx=False):
+        t = t.contiguous()
+        hi, lo_t = split16_host(t, self.dtype, lo)
         hi = hi.contiguous().to(self.device)
         self.keep.append(hi)
         w = W16()
         w.hi = hi.data_ptr()
         w.lo = None
+        w.mx = None
         if lo:
             lo_t = lo_t.contiguous().to(self.device)
             self.keep.append(lo_t)
             w.lo = lo_t.data_ptr()
+        if mx and torch16(self.dtype) == torch.float16 and t.dim() == 2:
+            # MX-fp4 plane of the rounding residual for the passes=4 GEMM (shapes without one keep using `lo`)
+            from .ops import mx_pack
+            packed = mx_pack(t.to(torch.float32) - hi.to("cpu", torch.float32))
+            if packed is not None:
+                packed = packed.to(self.device)
+                self.keep.append(packed)
+                w.mx = packed.data_ptr()
         return w
 
 
-def _tf_layer(hold, lo, wq, bq, wk, bk, wv, bv, wo, bo, ln1, w1, b1, w2, b2, ln2):
+def _tf_layer(hold, lo, wq, bq, wk, bk, wv, bv, wo, bo, ln1, w1, b1, w2, b2, ln2, mx=False):
     D = wq.shape[0]
     z = torch.zeros(D)
     L = TfLayer()
-    L.wqkv = hold.w16(torch.cat([wq, wk, wv], 0), lo)
+    L.wqkv = hold.w16(torch.cat([wq, wk, wv], 0), lo, mx)
     L.bqkv = hold.f32(torch.cat([bq if bq is not None else z, bk if bk is not None else z, bv if bv is not None else z], 0))
-    L.wo = hold.w16(wo, lo)
+    L.wo = hold.w16(wo, lo, mx)
     L.bo = hold.f32(bo)
     L.ln1_g, L.ln1_b = hold.f32(ln1[0]), hold.f32(ln1[1])
-    L.w1 = hold.w16(w1, lo)
+    L.w1 = hold.w16(w1, lo, mx)
     L.b1 = hold.f32(b1)
-    L.w2 = hold.w16(w2, lo)
+    L.w2 = hold.w16(w2, lo, mx)
     L.b2 = hold.f32(b2)
     L.ln2_g, L.ln2_b = hold.f32(ln2[0]), hold.f32(ln2[1])
     return L
@@ -103,7 +114,7 @@ def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes):
 
 
 # precision preset -> (GEMM passes in the HuBERT conv stack, GEMM passes in the transformer blocks)
-_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2),
+_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2), "mx": (4, 4),
          "accurate": (3, 3), "x3": (3, 3)}
 
 
@@ -180,7 +191,7 @@ class HipHubertModel(_HipModule):
         cfg.pos_k, cfg.pos_groups = config.num_conv_pos_embeddings, config.num_conv_pos_embedding_groups
         cfg.stable_layer_norm = int(config.do_stable_layer_norm)
         cfg.conv_passes = conv_passes
-        clo = conv_passes >= 2
+        clo, cmx = conv_passes >= 2, conv_passes == 4
         w = HubertWeights()
         fe = "feature_extractor.conv_layers."
         w.conv0_w = hold.f32(sd[fe + "0.conv.weight"].reshape(Cc, -1))
@@ -192,10 +203,10 @@ class HipHubertModel(_HipModule):
                 w.conv_b[i] = hold.f32(sd[fe + f"{i}.conv.bias"])
             if i >= 1:  # [Cout, Cin, k] -> [Cout, k*Cin] (column kk*Cin + ci == one contiguous im2col row)
                 wt = sd[fe + f"{i}.conv.weight"]
-                w.conv_w[i] = hold.w16(wt.permute(0, 2, 1).reshape(Cc, -1), clo)
+                w.conv_w[i] = hold.w16(wt.permute(0, 2, 1).reshape(Cc, -1), clo, cmx)
         if cfg.feat_proj_layer_norm:
             w.fp_ln_g, w.fp_ln_b = hold.f32(sd["feature_projection.layer_norm.weight"]), hold.f32(sd["feature_projection.layer_norm.bias"])
-        w.fp_w = hold.w16(sd["feature_projection.projection.weight"], clo)
+        w.fp_w = hold.w16(sd["feature_projection.projection.weight"], clo, cmx)
         w.fp_b = hold.f32(sd["feature_projection.projection.bias"])
         # positional conv: fold weight-norm (dim=2), then [D, Dg, K] -> [G, Dg, K*Dg] with column kk*Dg + ci
         p = "encoder.pos_conv_embed.conv."
@@ -212,7 +223,7 @@ class HipHubertModel(_HipModule):
         w.pos_w = hold.w16(pw.reshape(G, Dg, Dg, K).permute(0, 1, 3, 2).reshape(G * Dg, K * Dg), clo)
         w.pos_b = hold.f32(sd[p + "bias"])
         w.enc_ln_g, w.enc_ln_b = hold.f32(sd["encoder.layer_norm.weight"]), hold.f32(sd["encoder.layer_norm.bias"])
-        tlo = tf_passes >= 2
+        tlo, tmx = tf_passes >= 2, tf_passes == 4
         layers = (TfLayer * config.num_hidden_layers)()
         for l in range(config.num_hidden_layers):
             q = f"encoder.layers.{l}."
@@ -223,7 +234,7 @@ class HipHubertModel(_HipModule):
                 (sd[q + "layer_norm.weight"], sd[q + "layer_norm.bias"]),
                 sd[q + "feed_forward.intermediate_dense.weight"], sd[q + "feed_forward.intermediate_dense.bias"],
                 sd[q + "feed_forward.output_dense.weight"], sd[q + "feed_forward.output_dense.bias"],
-                (sd[q + "final_layer_norm.weight"], sd[q + "final_layer_norm.bias"]))
+                (sd[q + "final_layer_norm.weight"], sd[q + "final_layer_norm.bias"]), mx=tmx)
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers
         _lib.check(_lib.lib().mer_hubert_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_hubert_create")
@@ -293,7 +304,7 @@ class HipCLIPModel(_HipModule):
         vc = config.vision_config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo = tf_passes >= 2
+        lo, tmx = tf_passes >= 2, tf_passes == 4
         hold = self._hold = _Holder(device, dtype)
         act = MER_ACT_QUICK_GELU if vc.hidden_act == "quick_gelu" else MER_ACT_GELU
         cfg = VitConfig()
@@ -306,12 +317,12 @@ class HipCLIPModel(_HipModule):
         pad = (-pw.shape[1]) % 8   # CLIP-L/14: 588 -> 592 zero columns (16-byte rows for the MFMA GEMM)
         if pad:
             pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
-        w.patch_w = hold.w16(pw, lo)
+        w.patch_w = hold.w16(pw, lo, tmx)
         w.cls = hold.f32(sd[v + "embeddings.class_embedding"])
         w.pos = hold.f32(sd[v + "embeddings.position_embedding.weight"])
         w.pre_ln_g, w.pre_ln_b = hold.f32(sd[v + "pre_layrnorm.weight"]), hold.f32(sd[v + "pre_layrnorm.bias"])
         w.post_ln_g, w.post_ln_b = hold.f32(sd[v + "post_layernorm.weight"]), hold.f32(sd[v + "post_layernorm.bias"])
-        w.proj_w = hold.w16(sd["visual_projection.weight"], lo)
+        w.proj_w = hold.w16(sd["visual_projection.weight"], lo, tmx)
         layers = (TfLayer * vc.num_hidden_layers)()
         for l in range(vc.num_hidden_layers):
             q = f"{v}encoder.layers.{l}."
@@ -320,7 +331,7 @@ class HipCLIPModel(_HipModule):
                 hold, lo, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"], sd[a + "k_proj.weight"], sd[a + "k_proj.bias"],
                 sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"],
                 (sd[q + "layer_norm1.weight"], sd[q + "layer_norm1.bias"]), sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"],
-                sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"], (sd[q + "layer_norm2.weight"], sd[q + "layer_norm2.bias"]))
+                sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"], (sd[q + "layer_norm2.weight"], sd[q + "layer_norm2.bias"]), mx=tmx)
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers
         _lib.check(_lib.lib().mer_vit_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_vit_create")
@@ -384,7 +395,7 @@ class HipVideoMAEModel(_HipModule):
         self.config = config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo = tf_passes >= 2
+        lo, tmx = tf_passes >= 2, tf_passes == 4
         hold = self._hold = _Holder(device, dtype)
         D = config.hidden_size
         cfg = VideoMAEConfig()
@@ -395,7 +406,7 @@ class HipVideoMAEModel(_HipModule):
         cfg.final_ln = int("layernorm.weight" in sd)
         self.num_patches = (config.image_size // config.patch_size) ** 2 * (config.num_frames // config.tubelet_size)
         w = VideoMAEWeights()
-        w.patch_w = hold.w16(sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1), lo)
+        w.patch_w = hold.w16(sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1), lo, tmx)
         w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
         w.pos = hold.f32(sinusoid_table(self.num_patches, D))
         if cfg.final_ln:
@@ -414,7 +425,7 @@ class HipVideoMAEModel(_HipModule):
                 sd[q + "attention.output.dense.weight"], sd[q + "attention.output.dense.bias"],
                 (sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"]),
                 sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"],
-                sd[q + "output.dense.bias"], (sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"]))
+                sd[q + "output.dense.bias"], (sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"]), mx=tmx)
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers
         _lib.check(_lib.lib().mer_videomae_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_videomae_create")
@@ -466,7 +477,7 @@ class HipBertModel(_HipModule):
         self.config = config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo = tf_passes >= 2
+        lo, tmx = tf_passes >= 2, tf_passes == 4
         hold = self._hold = _Holder(device, dtype)
         if config.hidden_act != "gelu":
             raise _lib.MerError(f"hidden_act={config.hidden_act} unsupported")
@@ -493,7 +504,7 @@ class HipBertModel(_HipModule):
                 sd[q + "attention.output.dense.bias"],
                 (sd[q + "attention.output.LayerNorm.weight"], sd[q + "attention.output.LayerNorm.bias"]),
                 sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"],
-                sd[q + "output.dense.bias"], (sd[q + "output.LayerNorm.weight"], sd[q + "output.LayerNorm.bias"]))
+                sd[q + "output.dense.bias"], (sd[q + "output.LayerNorm.weight"], sd[q + "output.LayerNorm.bias"]), mx=tmx)
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers
         _lib.check(_lib.lib().mer_bert_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_bert_create")

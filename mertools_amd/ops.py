@@ -56,7 +56,7 @@ def split16_host(x, dtype="f16", lo=True):
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
            out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
-           headmajor=None):
+           headmajor=None, w_mx=None):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -68,6 +68,7 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.lda = lda if lda is not None else a_hi.stride(0)
     g.a_rows_per_batch, g.a_batch_stride = a_rows_per_batch, a_batch_stride
     g.w_hi, g.w_lo, g.ldw = _p(w_hi), _p(w_lo), w_hi.stride(0)
+    g.w_mx = _p(w_mx)
     g.bias, g.act = _p(bias), ACT[act]
     g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     dev = a_hi.device
@@ -81,6 +82,19 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
         g.headmajor_T, g.headmajor_H = headmajor
     _lib.check(_lib.lib().mer_gemm16(g, stream()), "mer_gemm16")
     return c32, c16h, c16l
+
+
+def mx_pack(w_res):
+    """Packs W - f16(W) ([N, K] fp32, host) into the MX-fp4 correction plane of gemm16(passes=4) (mer_mx_pack, host C++).
+    Returns a uint8 CPU tensor, or None when the shape has no MX form (K % 128 != 0)."""
+    w_res = w_res.detach().to("cpu", torch.float32).contiguous()
+    N, K = w_res.shape
+    nbytes = _lib.lib().mer_mx_packed_bytes(N, K)
+    if nbytes <= 0:
+        return None
+    out = torch.empty(nbytes, dtype=torch.uint8)
+    _lib.check(_lib.lib().mer_mx_pack(w_res.data_ptr(), w_res.stride(0), N, K, out.data_ptr()), "mer_mx_pack")
+    return out
 
 
 def gemm16_raw(args: GemmArgs):

@@ -11,13 +11,18 @@ SKIP = int(os.environ.get("SKIP", "0"))
 lib.mer_set_option(b"gemm_dbg_skip", SKIP)
 for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 2), ("qkv none p2", 100864, 2304, 768, None, 2),
                                      ("fc2 res p2", 100864, 768, 3072, None, 2), ("fc1 gelu p1", 100864, 3072, 768, "gelu", 1),
-                                     ("fc1 qgelu p2", 100864, 3072, 768, "quick_gelu", 2)][:2]:
+                                     ("fc1 qgelu p2", 100864, 3072, 768, "quick_gelu", 2), ("qkv none p1", 100864, 2304, 768, None, 1),
+                                     ("qkv none mx", 100864, 2304, 768, None, 4), ("fc2 res mx", 100864, 768, 3072, None, 4),
+                                     ("hub qkv p2", 15936, 2304, 768, None, 2), ("hub qkv mx", 15936, 2304, 768, None, 4)]:
+    if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        continue
     a = torch.randn(M, K, generator=g).to(dev); w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
     ah, _ = ops.split16(a, "f16", lo=False); wh, wl = ops.split16(w, "f16")
+    mx = ops.mx_pack(w.cpu() - wh.cpu().float()).to(dev) if passes == 4 else None
     bias = torch.randn(N, device=dev)
     nblk = ((M + 255) // 256) * ((N + 255) // 256)
     buf = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
-    kw = dict(w_lo=wl if passes >= 2 else None, passes=passes, dtype="f16", tile=3, bias=bias, act=act, out16=True)
+    kw = dict(w_lo=wl if passes >= 2 else None, w_mx=mx, passes=passes, dtype="f16", tile=3, bias=bias, act=act, out16=True)
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
     lib.mer_set_debug_buffer(buf.data_ptr())
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()

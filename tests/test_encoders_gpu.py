@@ -187,7 +187,7 @@ def test_hubert_base_5s(dev):
     feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
     utt = feat.mean(1)
     res = {}
-    for prec in ("fast", "mixed", "balanced", "balanced3", "accurate"):
+    for prec in ("fast", "mixed", "balanced", "mx", "balanced3", "accurate"):
         m = HipHubertModel(sd, cfg, device=dev, precision=prec)
         assert m.out_frames(80000) == 249
         hsd, fr, pooled = m.forward_raw(wav.to(dev), hidden_states=True, frames=True, seg_start=[0, 249], seg_len=[249, 249])
@@ -197,6 +197,7 @@ def test_hubert_base_5s(dev):
         _report(f"hubert-base[{prec}]", res[prec])
         del m
     assert res["balanced"]["utt"] <= TOL, res
+    assert res["mx"]["utt"] <= TOL, res     # conv stack on the MX-corrected GEMM (M = B*T_i >= 1024), blocks fall back at B = 2
     assert res["accurate"]["utt"] <= X3 and res["accurate"]["frame"] <= TOL and res["accurate"]["hs12"] <= TOL, res
 
 
@@ -208,7 +209,7 @@ def test_clip_base16_8frames(dev):
     px = W.synth_frames(8)
     ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
     res = {}
-    for prec in ("fast", "balanced", "accurate"):
+    for prec in ("fast", "balanced", "mx", "accurate"):
         m = HipCLIPModel(sd, cfg, device=dev, precision=prec)
         out = m.get_image_features(px.to(dev))
         pooled = m.extract_utterance(px.to(dev), [8])
@@ -217,6 +218,7 @@ def test_clip_base16_8frames(dev):
         _report(f"clip-B/16[{prec}]", res[prec])
         del m
     assert res["balanced"]["utt"] <= TOL, res
+    assert res["mx"]["utt"] <= TOL and res["mx"]["frames"] <= 2 * TOL, res   # 1576 rows: every block GEMM runs the MX kernel
     assert res["accurate"]["frames"] <= TOL and res["accurate"]["utt"] <= X3, res
 
 

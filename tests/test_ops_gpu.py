@@ -319,3 +319,47 @@ def test_gemm16_random_shape_sweep(dev):
                 tol = 2e-5 if passes != 2 else 1e-3
                 assert_close(c32.cpu(), ref.float(), tol, f"gemm16 M={M} N={N} K={K} tile={tile} passes={passes}")
                 assert_close(c16.float().cpu(), ref.float(), 2e-3, f"gemm16 c16 M={M} N={N} K={K} tile={tile} passes={passes}")
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1024, 256, 128, None), (3000, 768, 768, "gelu"), (2048, 2304, 768, None),
+                                       (1500, 512, 1536, "quick_gelu"), (1100, 300, 3072, None)])
+def test_gemm16_mx_corrected(dev, M, N, K, act):
+    """passes=4: a_hi*w_hi on the f16 MFMA + bf8(a_hi) * mxfp4(w - w_hi) on v_mfma_scale_f32_16x16x128_f8f6f4.
+    (1) bit-level layout check: equals the fp64 emulation built from the packed plane by an independent decoder;
+    (2) accuracy: as close to the true product as the f16 2-pass path (the residual only needs ~3 bits)."""
+    from util import bf8_round, mx_decode
+    ops = _ops()
+    a = _rand((M, K), 31).half()
+    w = _rand((N, K), 32) * 0.05
+    wh, wl = ops.split16_host(w, "f16")
+    packed = ops.mx_pack(w - wh.float())
+    bias = _rand((N,), 33)
+    res = _rand((M, N), 34)
+    c32, c16, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), w_mx=packed.to(dev), bias=bias.to(dev), act=act,
+                             residual=res.to(dev), out32=True, out16=True, passes=4, tile=3)
+    torch.cuda.synchronize()
+    emu = a.double() @ wh.double().T + bf8_round(a) @ mx_decode(packed, N, K).T + bias.double()
+    emu = _act_ref(emu, act) + res.double()
+    assert_close(c32.cpu(), emu.float(), 3e-6, "gemm16 mx vs emulation")
+    true = _act_ref(a.double() @ w.double().T + bias.double(), act) + res.double()
+    e4 = assert_close(c32.cpu(), true.float(), 3e-5, "gemm16 mx vs exact")
+    c1, _, _ = ops.gemm16(a.to(dev), wh.to(dev), bias=bias.to(dev), act=act, residual=res.to(dev), out32=True, passes=1, tile=3)
+    e1 = (c1.cpu().double() - true).abs().max().item() / true.abs().max().item()
+    assert e4 < 0.35 * e1, f"MX correction did not remove the weight-rounding error: {e4:.2e} vs 1-pass {e1:.2e}"
+    assert_close(c16.float().cpu(), true.float(), 1.5e-3, "gemm16 mx c16")
+
+
+def test_gemm16_mx_falls_back_to_two_pass(dev):
+    """Shapes the MX kernel does not cover (K % 128 != 0, small M -> 128-wide tiles) run the f16 2-pass path with w_lo."""
+    ops = _ops()
+    for (M, N, K) in [(600, 256, 136), (100, 768, 768)]:
+        a = _rand((M, K), 41).half()
+        w = _rand((N, K), 42) * 0.05
+        wh, wl = ops.split16_host(w, "f16")
+        packed = ops.mx_pack(w - wh.float())
+        c4, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), w_mx=None if packed is None else packed.to(dev), out32=True, passes=4)
+        c2, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), out32=True, passes=2)
+        torch.cuda.synchronize()
+        assert torch.equal(c4, c2)
+    with pytest.raises(Exception):
+        ops.gemm16(a.to(dev), wh.to(dev), out32=True, passes=4)   # neither plane
