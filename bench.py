@@ -43,9 +43,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
-    ap.add_argument("--precision", default="balanced", choices=["fast", "balanced", "mx", "accurate"],
-                    help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo, default, meets 1e-3 parity), "
-                         "mx=1 + MX-fp4 correction of the weight residual (same parity as balanced), accurate=3")
+    ap.add_argument("--precision", default="mx", choices=["fast", "balanced", "mx", "accurate"],
+                    help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo f16 planes, meets 1e-3 parity), mx=1 + MX-fp4 "
+                         "correction of the weight residual (default: same parity as balanced, cheaper), accurate=3")
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

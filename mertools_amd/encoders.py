@@ -15,9 +15,12 @@ is no torch compute on the forward path and no CPU fallback.
 
 precision (see DESIGN.md §numerics for the measured parity of each):
     "fast"      every GEMM one fp16 MFMA pass (fp32 accumulate): ~1e-3 on the saved features
-    "balanced"  weights carried as hi+lo fp16 planes, two MFMA passes (a*w_hi + a*w_lo): removes the
-                weight-rounding error, the part that is coherent across tokens and survives the
-                utterance mean — default
+    "mx"        default.  One fp16 pass + the weight-rounding residual w - f16(w) as an MX-fp4 plane (e2m1 + E8M0 per 32 k)
+                applied through v_mfma_scale_f32_16x16x128_f8f6f4 against bf8 copies of the activations: removes the
+                weight-rounding error (coherent across tokens, so it survives the utterance mean) like "balanced",
+                at 1/2 f16-pass of extra MFMA work instead of a whole pass.  GEMMs the MX kernel does not cover
+                (< 1024 rows, K % 128 != 0, batched, bf16) run the "balanced" path.
+    "balanced"  weights carried as hi+lo fp16 planes, two MFMA passes (a*w_hi + a*w_lo)
     "accurate"  both operands split, three passes: fp32-grade GEMMs (attention still rounds q/k/v/P to
                 fp16), ~1e-4
     "mixed" / "balanced3"  HuBERT only: conv stack 3-pass with 1- / 2-pass transformer blocks
@@ -166,7 +169,7 @@ class _HipModule:
 class HipHubertModel(_HipModule):
     _destroy = "mer_hubert_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -297,7 +300,7 @@ HipWav2Vec2Model = HipHubertModel
 class HipCLIPModel(_HipModule):
     _destroy = "mer_vit_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -389,7 +392,7 @@ class HipVideoMAEModel(_HipModule):
     """`model(inputs).last_hidden_state` of extract_vision_huggingface.py:155 (VideoMAE branch)."""
     _destroy = "mer_videomae_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -471,7 +474,7 @@ class HipBertModel(_HipModule):
     """BERT / RoBERTa family (post-LN encoder-only text models)."""
     _destroy = "mer_bert_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="balanced"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config

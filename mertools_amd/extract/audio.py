@@ -61,7 +61,7 @@ def save_feature(csv_file, feature, feature_level):
     np.save(csv_file, feature)
 
 
-def load_model(model_name, gpu, precision="balanced"):
+def load_model(model_name, gpu, precision="mx"):
     """AutoModel checkpoint under config.PATH_TO_PRETRAINED_MODELS/transformers/<model_name> -> HIP encoder."""
     from transformers import AutoModel, Wav2Vec2FeatureExtractor
     from .. import config

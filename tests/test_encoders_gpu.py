@@ -18,7 +18,7 @@ def _hf_like_cfg(cfg):
     return cfg
 
 
-@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("balanced", TOL), ("mixed", 2e-3), ("fast", 2e-3)])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("balanced", TOL), ("mx", TOL), ("mixed", 2e-3), ("fast", 2e-3)])
 def test_hubert_tiny_hidden_states(dev, precision, tol):
     from mertools_amd.encoders import HipHubertModel
     cfg = W.hubert_config("tiny")
@@ -84,7 +84,7 @@ def test_hubert_tiny_chunked_clip(dev):
     assert_close(pooled.cpu(), exp, X3, "chunked clip pooling")
 
 
-@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("balanced", TOL), ("fast", 2e-3)])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("balanced", TOL), ("mx", TOL), ("fast", 2e-3)])
 def test_clip_tiny_image_features(dev, precision, tol):
     from mertools_amd.encoders import HipCLIPModel
     cfg = W.clip_config("tiny")
@@ -100,7 +100,7 @@ def test_clip_tiny_image_features(dev, precision, tol):
     assert_close(pooled.cpu(), torch.stack([ref[:2].mean(0), ref[2:].mean(0)]), tol, "clip-tiny frame mean")
 
 
-@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("balanced", TOL), ("fast", 2e-3)])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("balanced", TOL), ("mx", TOL), ("fast", 2e-3)])
 @pytest.mark.parametrize("kind", ["tiny", "tiny-bert"])
 def test_bert_tiny_hidden_states(dev, precision, tol, kind):
     from mertools_amd.encoders import HipBertModel
@@ -159,7 +159,7 @@ def test_videomae_base_16frames(dev):
     px = W.synth_video(1)
     ref = R.videomae_last_hidden_state(sd, vars(cfg), px)
     exp = ref.view(8, 196, -1).mean(1)
-    for prec in ("balanced", "accurate"):
+    for prec in ("balanced", "mx", "accurate"):
         m = HipVideoMAEModel(sd, cfg, device=dev, precision=prec)
         out, seg = m(px.to(dev)).last_hidden_state, m.extract_segments(px.to(dev))
         torch.cuda.synchronize()
@@ -254,7 +254,7 @@ def test_large_trio(dev):
     wav = W.synth_audio(1, 80000)
     hs = R.hubert_hidden_states(sd, vars(cfg), wav)
     utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
-    for prec, dtype in (("balanced", "f16"), ("accurate", "bf16")):
+    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("accurate", "bf16")):
         m = HipHubertModel(sd, cfg, device=dev, precision=prec, dtype=dtype)
         res[f"hubert-large[{prec},{dtype}]"] = rel_err(m.extract_utterance(wav.to(dev)).cpu(), utt)[0]
         del m
@@ -263,7 +263,7 @@ def test_large_trio(dev):
     sd = W.videomae_state_dict(cfg, 0)
     px = W.synth_video(1)
     exp = R.videomae_last_hidden_state(sd, vars(cfg), px).view(8, 196, -1).mean(1)
-    for prec, dtype in (("balanced", "f16"), ("accurate", "bf16")):
+    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("accurate", "bf16")):
         m = HipVideoMAEModel(sd, cfg, device=dev, precision=prec, dtype=dtype)
         res[f"videomae-large[{prec},{dtype}]"] = rel_err(m.extract_segments(px.to(dev)).cpu(), exp)[0]
         del m
