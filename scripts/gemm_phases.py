@@ -24,11 +24,21 @@ for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 
     buf = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
     kw = dict(w_lo=wl if passes >= 2 else None, w_mx=mx, passes=passes, dtype="f16", tile=3, bias=bias, act=act, out16=True)
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
+    WARM = int(os.environ.get("WARM", "0"))   # > 0: stamp a launch that follows WARM back-to-back launches (sustained clocks)
+    wall_us = float("nan")
+    if WARM:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(WARM): ops.gemm16(ah, wh, **kw)
+        e0.record()
+        for _ in range(WARM): ops.gemm16(ah, wh, **kw)
+        e1.record()
     lib.mer_set_debug_buffer(buf.data_ptr())
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
     lib.mer_set_debug_buffer(None)
+    if WARM: wall_us = e0.elapsed_time(e1) / WARM * 1e3
     t = buf.view(nblk, 4).cpu().double()
     pro, loop, epi, tot = (t[:, 1] - t[:, 0]), (t[:, 2] - t[:, 1]), (t[:, 3] - t[:, 2]), (t[:, 3] - t[:, 0])
     span = (t[:, 3].max() - t[:, 0].min()).item()
     print(f"{name:13s} blocks={nblk} median cycles/ticks: prologue {pro.median():.0f}  kloop {loop.median():.0f}  epilogue {epi.median():.0f}  total {tot.median():.0f}"
+          f" | wall {wall_us:.1f} us/launch -> eff. clock {tot.sum().item() / 256 / wall_us / 1e3:.2f} GHz (sum of tile cycles / 256 CUs / wall)"
           f" | per-slab {loop.median() / (K / 32):.0f} | kernel span {span:.0f} ticks; sum(total)/256/span = {tot.sum().item() / 256 / span:.2f}")
