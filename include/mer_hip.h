@@ -304,6 +304,10 @@ int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, int L,
 typedef struct {
   mer_tf_config tf;
   int image_size, patch_size, channels, proj_dim;
+  int variant;   /* 0 = CLIP vision tower (no patch bias, pre_layrnorm, post_layernorm(CLS) -> projection);
+                  * 1 = DINOv2 (HF:dinov2/modeling_dinov2.py): patch bias, no embedding LN, layer scale folded into wo/w2 by
+                  *     the host, image_features = SUM over the 1+P tokens of the last residual stream (the reference's
+                  *     `torch.stack(hidden_states)[-1].sum(dim=1)`, extract_vision_huggingface.py:142); proj_dim == hidden */
 } mer_vit_config;
 typedef struct {
   mer_w16 patch_w;                      /* [D, ceil8(C*P*P)] (no bias; zero-padded columns) */
@@ -312,6 +316,7 @@ typedef struct {
   const float* post_ln_g; const float* post_ln_b;
   mer_w16 proj_w;                       /* [proj_dim, D] (no bias) */
   const mer_tf_layer* layers;
+  const float* patch_b;                 /* variant 1: [D] patch-embedding bias (NULL for CLIP) */
 } mer_vit_weights;
 typedef struct mer_vit mer_vit;
 int mer_vit_create(const mer_vit_config* cfg, const mer_vit_weights* w, mer_vit** out);
@@ -322,6 +327,14 @@ long long mer_vit_workspace_bytes(const mer_vit* h, int N);
 int mer_vit_forward(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
                     float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
                     mer_stream_t stream);
+/* Same, and additionally copies the last residual stream [N, 1+P, D] (the last entry of HF's `hidden_states`) to
+ * `tokens_out` when it is not NULL — what the drop-in `model(..., output_hidden_states=True).hidden_states[-1]` returns. */
+int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
+                           float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                           float* tokens_out, mer_stream_t stream);
+
+/* out[n, :] = scale * sum over t of x[n, t, :]   (x fp32 [N, T, D]; token sum / mean of a hidden state). */
+int mer_token_reduce(const float* x, int N, int T, int D, float scale, float* out, mer_stream_t stream);
 
 /* ---- VideoMAE video encoder ------------------------------------------------------------------
  * Replaces `model(inputs).last_hidden_state` at

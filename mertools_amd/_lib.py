@@ -75,12 +75,14 @@ class HubertWeights(C.Structure):
 
 
 class VitConfig(C.Structure):
-    _fields_ = [("tf", TfConfig), ("image_size", c_int), ("patch_size", c_int), ("channels", c_int), ("proj_dim", c_int)]
+    _fields_ = [("tf", TfConfig), ("image_size", c_int), ("patch_size", c_int), ("channels", c_int), ("proj_dim", c_int),
+                ("variant", c_int)]
 
 
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", W16), ("cls", c_void_p), ("pos", c_void_p), ("pre_ln_g", c_void_p), ("pre_ln_b", c_void_p),
-                ("post_ln_g", c_void_p), ("post_ln_b", c_void_p), ("proj_w", W16), ("layers", C.POINTER(TfLayer))]
+                ("post_ln_g", c_void_p), ("post_ln_b", c_void_p), ("proj_w", W16), ("layers", C.POINTER(TfLayer)),
+                ("patch_b", c_void_p)]
 
 
 class VideoMAEConfig(C.Structure):
@@ -163,6 +165,9 @@ _PROTOS = {
     "mer_vit_workspace_bytes": (c_ll, [c_void_p, c_int]),
     "mer_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_void_p]),
+    "mer_vit_forward_tokens": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
+    "mer_token_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mer_videomae_create": (c_int, [C.POINTER(VideoMAEConfig), C.POINTER(VideoMAEWeights), C.POINTER(c_void_p)]),
     "mer_videomae_destroy": (None, [c_void_p]),
     "mer_videomae_workspace_bytes": (c_ll, [c_void_p, c_int]),

@@ -335,6 +335,12 @@ extern "C" int mer_vit_create(const mer_vit_config* cfg, const mer_vit_weights* 
   MER_REQUIRE(cfg->tf.pre_ln == 1, MER_EUNSUPPORTED, "mer_vit_create: ViT blocks are pre-LN");
   MER_REQUIRE(cfg->image_size % cfg->patch_size == 0, MER_ESHAPE, "mer_vit_create: image/patch size");
   MER_REQUIRE(w->layers && w->patch_w.hi && w->cls && w->pos, MER_EINVAL, "mer_vit_create: missing weights");
+  MER_REQUIRE(cfg->variant == 0 || cfg->variant == 1, MER_EINVAL, "mer_vit_create: variant must be 0 (CLIP) or 1 (DINOv2)");
+  if (cfg->variant == 0) {
+    MER_REQUIRE(w->pre_ln_g && w->post_ln_g && w->proj_w.hi, MER_EINVAL, "mer_vit_create: CLIP needs pre/post LayerNorm and the projection");
+  } else {
+    MER_REQUIRE(cfg->proj_dim == cfg->tf.hidden, MER_ESHAPE, "mer_vit_create: DINOv2 features are hidden-sized (proj_dim == hidden)");
+  }
   mer_vit* h = new mer_vit();
   h->cfg = *cfg;
   h->w = *w;
@@ -378,6 +384,12 @@ extern "C" long long mer_vit_workspace_bytes(const mer_vit* h, int N) {
 extern "C" int mer_vit_forward(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
                                float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
                                mer_stream_t stream) {
+  return mer_vit_forward_tokens(h, pixels, N, workspace, workspace_bytes, image_features, seg_start, seg_len, nseg, pooled, nullptr, stream);
+}
+
+extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
+                                      float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                                      float* tokens_out, mer_stream_t stream) {
   MER_REQUIRE(h && pixels && workspace && N > 0, MER_EINVAL, "mer_vit_forward: bad argument");
   MER_REQUIRE(((uintptr_t)workspace & 255) == 0, MER_EINVAL, "mer_vit_forward: workspace must be 256-byte aligned");
   const mer_vit_config& c = h->cfg;
@@ -392,12 +404,23 @@ extern "C" int mer_vit_forward(const mer_vit* h, const float* pixels, int N, voi
   const P16 none = {nullptr, nullptr};
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
-  MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, nullptr, MER_ACT_NONE, nullptr, 0, p.patch32, D, none, 0));
-  // [CLS] + position embeddings + pre_layrnorm
-  MER_TRY(mer_vit_assemble(p.patch32, w.cls, w.pos, w.pre_ln_g, w.pre_ln_b, c.tf.ln_eps, N, P, D, p.x, nullptr, nullptr, dt, st));
+  MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, c.variant == 1 ? w.patch_b : nullptr, MER_ACT_NONE, nullptr, 0,
+               p.patch32, D, none, 0));
+  // [CLS] + position embeddings (+ pre_layrnorm for CLIP; DINOv2 has no embedding LayerNorm: gamma == NULL stores the plain sum)
+  MER_TRY(mer_vit_assemble(p.patch32, w.cls, w.pos, c.variant == 0 ? w.pre_ln_g : nullptr, c.variant == 0 ? w.pre_ln_b : nullptr,
+                           c.tf.ln_eps, N, P, D, p.x, nullptr, nullptr, dt, st));
   HsMap hs;
   hs.base = p.x; hs.stride = 0; hs.ring = 1;  // pre-LN blocks update the residual stream in place
   MER_TRY(tf_forward(st, c.tf, h->layers.data(), N, P + 1, hs, p.tf, nullptr));
+  if (tokens_out)
+    MER_REQUIRE(hipMemcpyAsync(tokens_out, p.x, (size_t)N * (P + 1) * D * 4, hipMemcpyDeviceToDevice, st) == hipSuccess, MER_ELAUNCH,
+                "mer_vit_forward: copy of the token states failed");
+  if (c.variant == 1) {   // DINOv2: token sum of the last residual stream (extract_vision_huggingface.py:142), then the per-clip mean
+    float* f = image_features ? image_features : p.feats;
+    MER_TRY(mer_token_reduce(p.x, N, P + 1, D, 1.0f, f, stream));
+    if (pooled) MER_TRY(mer_sum_pool(f, nullptr, nullptr, nullptr, N, D, nullptr, seg_start, seg_len, nseg, pooled, st));
+    return MER_OK;
+  }
   // pooled = post_layernorm(x[:, 0]); features = visual_projection(pooled)   (HF:clip/modeling_clip.py:719-748)
   MER_TRY(mer_layernorm(p.x, (long long)(P + 1) * D, w.post_ln_g, w.post_ln_b, c.tf.ln_eps, N, D, MER_ACT_NONE, nullptr, 0,
                         p.cls16.hi, p.cls16.lo, D, dt, st));

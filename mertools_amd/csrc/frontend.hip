@@ -358,6 +358,19 @@ __global__ __launch_bounds__(256) void seg_mean_kernel(const float* h0, const fl
   }
 }
 
+// out[n, col] = scale * sum_t x[n, t, col]: one workgroup per (n, 64 columns), 4 waves stride the tokens
+__global__ __launch_bounds__(256) void token_reduce_kernel(const float* x, int T, int D, float scale, float* out) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + lane;
+  float acc = 0.f;
+  if (col < D)
+    for (int t = wave; t < T; t += 4) acc += x[((long long)n * T + t) * D + col];
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < D) out[(long long)n * D + col] = scale * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long g = cdiv(n, block);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -491,4 +504,11 @@ extern "C" int mer_sum_pool(const float* h0, const float* h1, const float* h2, c
     return check_launch("seg_mean");
   }
   return MER_OK;
+}
+
+extern "C" int mer_token_reduce(const float* x, int N, int T, int D, float scale, float* out, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && out && N > 0 && T > 0 && D > 0, MER_EINVAL, "mer_token_reduce: bad argument");
+  hipLaunchKernelGGL(token_reduce_kernel, dim3(N, (unsigned)cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, x, T, D, scale, out);
+  return check_launch("token_reduce");
 }

@@ -377,6 +377,111 @@ class HipCLIPModel(_HipModule):
 
 
 # =================================================================================================
+class HipDinov2Model(_HipModule):
+    """DINOv2 branch of extract_vision_huggingface.py:133-144: `model(batch, output_hidden_states=True).hidden_states`
+    whose last entry is token-summed.  HF:dinov2/modeling_dinov2.py.  Built for ONE input resolution (`input_size`,
+    224 = the processor's crop): the position table is interpolated to that grid once at load time, and the layer-scale
+    vectors are folded into the attention-output / fc2 weights and biases (y = x + lambda * (h W^T + b) == x + h (lambda*W)^T
+    + lambda*b), so the blocks are the plain pre-LN blocks of the ViT engine.  SwiGLU (dinov2-giant) is not supported."""
+
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx", input_size=224):
+        super().__init__()
+        sd = _sd_of(state_dict)
+        self.config = config
+        self.device = torch.device(device)
+        if getattr(config, "use_swiglu_ffn", False):
+            raise _lib.MerError("HipDinov2Model: SwiGLU feed-forward (dinov2-giant) is not supported")
+        _, tf_passes = _PREC[precision]
+        lo, tmx = tf_passes >= 2, tf_passes == 4
+        hold = self._hold = _Holder(device, dtype)
+        D, Pz = config.hidden_size, config.patch_size
+        ffn = int(D * config.mlp_ratio)
+        assert input_size % Pz == 0, "input size must be a multiple of the patch size"
+        cfg = VitConfig()
+        cfg.tf = _tf_config(D, config.num_attention_heads, ffn, config.num_hidden_layers, True, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+        cfg.image_size, cfg.patch_size, cfg.channels, cfg.proj_dim, cfg.variant = input_size, Pz, config.num_channels, D, 1
+        w = VitWeights()
+        pw = sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
+        pad = (-pw.shape[1]) % 8   # patch 14: 588 -> 592 zero columns
+        if pad:
+            pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
+        w.patch_w = hold.w16(pw, lo, tmx)
+        w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
+        w.cls = hold.f32(sd["embeddings.cls_token"].reshape(D))
+        w.pos = hold.f32(self.interpolate_pos_encoding(sd["embeddings.position_embeddings"], input_size // Pz))
+        layers = (TfLayer * config.num_hidden_layers)()
+        for l in range(config.num_hidden_layers):
+            q = f"encoder.layer.{l}."
+            a = q + "attention.attention."
+            l1, l2 = sd[q + "layer_scale1.lambda1"], sd[q + "layer_scale2.lambda1"]
+            layers[l] = _tf_layer(
+                hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"],
+                sd[a + "value.weight"], sd[a + "value.bias"],
+                sd[q + "attention.output.dense.weight"] * l1[:, None], sd[q + "attention.output.dense.bias"] * l1,
+                (sd[q + "norm1.weight"], sd[q + "norm1.bias"]), sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"],
+                sd[q + "mlp.fc2.weight"] * l2[:, None], sd[q + "mlp.fc2.bias"] * l2,
+                (sd[q + "norm2.weight"], sd[q + "norm2.bias"]), mx=tmx)
+        w.layers = C.cast(layers, C.POINTER(TfLayer))
+        self._layers = layers
+        _lib.check(_lib.lib().mer_vit_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_vit_create")
+        self._cfg = cfg
+        self.tokens = (input_size // Pz) ** 2 + 1
+
+    @staticmethod
+    def interpolate_pos_encoding(pos, grid):
+        """Dinov2Embeddings.interpolate_pos_encoding for a square grid x grid input: [1, 1+n, D] -> [1+grid^2, D]."""
+        n = pos.shape[1] - 1
+        D = pos.shape[-1]
+        if grid * grid == n:
+            return pos[0]
+        s0 = int(n ** 0.5)
+        pp = pos[:, 1:].reshape(1, s0, s0, D).permute(0, 3, 1, 2).float()
+        pp = torch.nn.functional.interpolate(pp, size=(grid, grid), mode="bicubic", align_corners=False)
+        return torch.cat([pos[0, :1], pp.permute(0, 2, 3, 1).reshape(-1, D)], dim=0)
+
+    @classmethod
+    def from_hf(cls, hf_model, **kw):
+        return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def forward_raw(self, pixel_values, *, features=True, tokens=False, seg_start=None, seg_len=None):
+        """-> (frame features [N, D] = token sums, last residual stream [N, 1+P, D] or None, pooled [nseg, D] or None)."""
+        x = pixel_values
+        if not x.is_cuda:
+            x = x.to(self.device)
+        x = x.to(torch.float32).contiguous()
+        N, D = x.shape[0], self.config.hidden_size
+        assert x.shape[1:] == (self._cfg.channels, self._cfg.image_size, self._cfg.image_size), x.shape
+        feats = torch.empty((N, D), dtype=torch.float32, device=self.device) if features else None
+        tok = torch.empty((N, self.tokens, D), dtype=torch.float32, device=self.device) if tokens else None
+        ss, sl, nseg = self._seg(seg_start, seg_len)
+        pooled = torch.empty((nseg, D), dtype=torch.float32, device=self.device) if nseg else None
+        wp, wn = self._workspace(_lib.lib().mer_vit_workspace_bytes(self._handle, N))
+        _lib.check(_lib.lib().mer_vit_forward_tokens(
+            self._handle, x.data_ptr(), N, wp, wn, feats.data_ptr() if features else None,
+            ss.data_ptr() if nseg else None, sl.data_ptr() if nseg else None, nseg, pooled.data_ptr() if nseg else None,
+            tok.data_ptr() if tokens else None, stream()), "mer_vit_forward_tokens")
+        return feats, tok, pooled
+
+    def __call__(self, pixel_values=None, output_hidden_states=False, **_):
+        """Drop-in for the reference's call: `.hidden_states` is a 1-tuple holding the LAST hidden state (the only entry the
+        script reads: `torch.stack(hidden_states)[-1]`), not all L+1 of them."""
+        _, tok, _ = self.forward_raw(pixel_values, features=False, tokens=True)
+        return EncoderOutput(last_hidden_state=None, hidden_states=(tok,) if output_hidden_states else None)
+
+    def extract_frames(self, pixel_values):
+        """Fused `torch.stack(hidden_states)[-1].sum(dim=1)` -> [N, D]."""
+        return self.forward_raw(pixel_values)[0]
+
+    def extract_utterance(self, pixel_values, frames_per_clip):
+        starts, lens, r = [], [], 0
+        for n in frames_per_clip:
+            starts.append(r)
+            lens.append(n)
+            r += n
+        return self.forward_raw(pixel_values, features=False, seg_start=starts, seg_len=lens)[2]
+
+
+# =================================================================================================
 def sinusoid_table(n_position, d_hid):
     """VideoMAE's fixed position table (HF:videomae/modeling_videomae.py:80-91), float64 numpy then float32."""
     import numpy as np

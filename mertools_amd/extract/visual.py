@@ -154,3 +154,59 @@ def extract_videomae(model, face_dir, save_dir, feature_level='UTTERANCE', vids=
         if len(pending) >= videos_per_batch:
             flush()
     flush()
+
+
+# ---- DINOv2 branch (reference :133-144) ---------------------------------------------------------------------------
+def dinov2_preprocess(frames_bgr, size=224, resize_to=256):
+    """func_opencv_to_image + the DINOv2 checkpoints' BitImageProcessor (reference :29-31,135): BGR->RGB, resize shortest
+    edge to 256 (PIL bicubic), centre crop 224, /255, ImageNet normalise.  uint8 [N,h,w,3] -> float32 [N,3,size,size]."""
+    from PIL import Image
+    out = np.empty((len(frames_bgr), 3, size, size), dtype=np.float32)
+    mean = np.array(IMAGENET_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(IMAGENET_STD, dtype=np.float32)[:, None, None]
+    for i, f in enumerate(frames_bgr):
+        img = Image.fromarray(np.ascontiguousarray(f[:, :, ::-1]))
+        w, h = img.size
+        short, long = (w, h) if w <= h else (h, w)
+        nw, nh = (resize_to, int(resize_to * long / short)) if w <= h else (int(resize_to * long / short), resize_to)
+        img = img.resize((nw, nh), resample=Image.BICUBIC)
+        # centre crop (HF center_crop: top = (h - crop) // 2 ...; pads when the image is smaller, which cannot happen here)
+        top, left = (nh - size) // 2, (nw - size) // 2
+        img = img.crop((left, top, left + size, top + size))
+        arr = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+        out[i] = (arr - mean) / std
+    return torch.from_numpy(out)
+
+
+def extract_dinov2(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames, nframe=64):
+    """DINOv2 branch of the reference loop: 64 uniformly resampled frames per video (:134) -> token SUM of the last hidden
+    state per frame (:141-142) -> [64, D] (FRAME) or its mean (UTTERANCE).  `model`: HipDinov2Model; videos share batches."""
+    os.makedirs(save_dir, exist_ok=True)
+    vids = vids if vids is not None else os.listdir(face_dir)
+    embedding_dim = -1
+    pending, nframes = [], 0
+
+    def flush():
+        nonlocal pending, nframes, embedding_dim
+        if not pending:
+            return
+        feats = model.extract_frames(torch.cat([p for _, p in pending], 0)).cpu().numpy()
+        embedding_dim = max(embedding_dim, feats.shape[-1])
+        r = 0
+        for vid, p in pending:
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), feats[r:r + p.shape[0]], feature_level, embedding_dim)
+            r += p.shape[0]
+        pending, nframes = [], 0
+
+    for vid in vids:
+        frames = reader(face_dir, vid)
+        if len(frames) == 0:
+            flush()
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
+            continue
+        px = dinov2_preprocess(resample_frames_uniform(frames, nframe=nframe), model._cfg.image_size)
+        if nframes + len(px) > frames_per_batch:
+            flush()
+        pending.append((vid, px))
+        nframes += len(px)
+    flush()

@@ -109,6 +109,44 @@ def clip_state_dict(cfg, seed=0):
     return sd
 
 
+def dinov2_config(size="base", **over):
+    """Dinov2Config: image_size is the TRAINING resolution (518 -> 37x37 position grid); inputs are 224x224 crops."""
+    base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, mlp_ratio=4, image_size=518, patch_size=14,
+                num_channels=3, layer_norm_eps=1e-6, hidden_act="gelu", qkv_bias=True, layerscale_value=1.0, use_swiglu_ffn=False,
+                model_type="dinov2")
+    if size == "large":
+        base.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16)
+    if size == "tiny":
+        base.update(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, image_size=70)
+    base.update(over)
+    return SimpleNamespace(**base)
+
+
+def dinov2_state_dict(cfg, seed=0):
+    g = _g(seed)
+    D, P, Cn = cfg.hidden_size, cfg.patch_size, cfg.num_channels
+    n = (cfg.image_size // P) ** 2
+    ffn = int(D * cfg.mlp_ratio)
+    sd = {"embeddings.cls_token": torch.randn(1, 1, D, generator=g) * 0.5,
+          "embeddings.mask_token": torch.zeros(1, D),
+          "embeddings.position_embeddings": torch.randn(1, n + 1, D, generator=g) * 0.3,
+          "embeddings.patch_embeddings.projection.weight": torch.randn(D, Cn, P, P, generator=g) / math.sqrt(Cn * P * P),
+          "embeddings.patch_embeddings.projection.bias": torch.randn(D, generator=g) * 0.05}
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        for nme in ("query", "key", "value"):
+            sd[p + f"attention.attention.{nme}.weight"], sd[p + f"attention.attention.{nme}.bias"] = _lin(g, D, D)
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = _lin(g, D, D)
+        sd[p + "norm1.weight"], sd[p + "norm1.bias"] = _ln(g, D)
+        sd[p + "norm2.weight"], sd[p + "norm2.bias"] = _ln(g, D)
+        sd[p + "layer_scale1.lambda1"] = 0.5 + torch.rand(D, generator=g)
+        sd[p + "layer_scale2.lambda1"] = 0.5 + torch.rand(D, generator=g)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = _lin(g, ffn, D)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = _lin(g, D, ffn, std=0.5 / math.sqrt(ffn))
+    sd["layernorm.weight"], sd["layernorm.bias"] = _ln(g, D)
+    return sd
+
+
 def videomae_config(size="base", **over):
     base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, image_size=224,
                 patch_size=16, num_channels=3, num_frames=16, tubelet_size=2, layer_norm_eps=1e-12, use_mean_pooling=False,

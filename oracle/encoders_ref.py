@@ -171,6 +171,55 @@ def clip_cfg_from_hf(c):
 
 
 # ------------------------------------------------------------------------------------------------
+# DINOv2  (HF:dinov2/modeling_dinov2.py; reference branch extract_vision_huggingface.py:133-144)
+# ------------------------------------------------------------------------------------------------
+def dinov2_pos_embed(sd, cfg, height, width):
+    """Dinov2Embeddings.interpolate_pos_encoding (installed HF 5.x form: size-based bicubic, align_corners=False)."""
+    pos = sd["embeddings.position_embeddings"]
+    P = cfg["patch_size"]
+    n_pos = pos.shape[1] - 1
+    gh, gw = height // P, width // P
+    if gh * gw == n_pos and height == width:
+        return pos
+    s0 = int(n_pos ** 0.5)
+    D = pos.shape[-1]
+    pp = pos[:, 1:].reshape(1, s0, s0, D).permute(0, 3, 1, 2)
+    pp = F.interpolate(pp.float(), size=(gh, gw), mode="bicubic", align_corners=False)
+    return torch.cat([pos[:, :1], pp.permute(0, 2, 3, 1).reshape(1, -1, D)], dim=1)
+
+
+def dinov2_hidden_states(sd, cfg, pixel_values):
+    """`model(batch, output_hidden_states=True).hidden_states` (extract_vision_huggingface.py:141): embeddings output + the
+    residual stream after every layer (the final `layernorm` is NOT applied to these).  pixel_values [N,3,H,W]."""
+    eps = cfg.get("layer_norm_eps", 1e-6)
+    P = cfg["patch_size"]
+    x = F.conv2d(pixel_values, sd["embeddings.patch_embeddings.projection.weight"], sd["embeddings.patch_embeddings.projection.bias"], stride=P)
+    N, D = x.shape[0], x.shape[1]
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([sd["embeddings.cls_token"].expand(N, 1, D), x], dim=1)
+    x = x + dinov2_pos_embed(sd, cfg, pixel_values.shape[2], pixel_values.shape[3])
+    H = cfg["num_attention_heads"]
+    hs = [x]
+    for l in range(cfg["num_hidden_layers"]):  # Dinov2Layer: pre-LN, layer scale on both branches
+        p = f"encoder.layer.{l}."
+        a = p + "attention.attention."
+        h = _ln(x, sd, p + "norm1", eps)
+        att = _mhsa(h, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"], sd[a + "value.weight"],
+                    sd[a + "value.bias"], sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"], H)
+        x = x + att * sd[p + "layer_scale1.lambda1"]
+        h = _gelu(F.linear(_ln(x, sd, p + "norm2", eps), sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+        x = x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]) * sd[p + "layer_scale2.lambda1"]
+        hs.append(x)
+    return hs
+
+
+def dinov2_frame_features(sd, cfg, pixel_values):
+    """`torch.stack(hidden_states)[-1].sum(dim=1)` (extract_vision_huggingface.py:142): token SUM (CLS + patches) of the last
+    residual stream -> [N, D]."""
+    return dinov2_hidden_states(sd, cfg, pixel_values)[-1].sum(dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
 # VideoMAE  (HF:videomae/modeling_videomae.py)
 # ------------------------------------------------------------------------------------------------
 def videomae_sinusoid(n_position, d_hid):

@@ -1,0 +1,122 @@
+"""DINOv2 branch (extract_vision_huggingface.py:133-144): oracle pinned against the live HF class, host
+preprocessing pinned against HF's BitImageProcessor (CPU); HIP encoder against the oracle (GPU)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from mertools_amd import synthetic as W
+from oracle import encoders_ref as R
+
+
+def _hf_model(c):
+    from transformers import Dinov2Config, Dinov2Model
+    hc = Dinov2Config(hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                      mlp_ratio=c.mlp_ratio, image_size=c.image_size, patch_size=c.patch_size, layer_norm_eps=c.layer_norm_eps,
+                      attn_implementation="eager")
+    return Dinov2Model(hc).eval()
+
+
+def test_oracle_matches_hf_dinov2():
+    c = W.dinov2_config("tiny")
+    sd = W.dinov2_state_dict(c, 0)
+    m = _hf_model(c)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    g = torch.Generator().manual_seed(1)
+    for size in (70, 42):              # native grid (no interpolation) and a smaller input (bicubic position interpolation)
+        px = torch.randn(2, 3, size, size, generator=g)
+        with torch.no_grad():
+            hs = m(px, output_hidden_states=True).hidden_states
+        ours = R.dinov2_hidden_states(sd, vars(c), px)
+        assert len(hs) == len(ours) == c.num_hidden_layers + 1
+        for a, b in zip(ours, hs):
+            assert torch.allclose(a, b, rtol=0, atol=1e-5)
+        assert torch.allclose(R.dinov2_frame_features(sd, vars(c), px), torch.stack(hs)[-1].sum(dim=1), rtol=0, atol=1e-4)
+
+
+def test_dinov2_preprocess_matches_hf_processor():
+    from PIL import Image
+    from mertools_amd.extract.visual import dinov2_preprocess
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from transformers import BitImageProcessor
+        # facebook/dinov2-*: preprocessor_config.json
+        proc = BitImageProcessor(size={"shortest_edge": 256}, crop_size={"height": 224, "width": 224}, resample=3, do_convert_rgb=True,
+                                 image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225])
+    rng = np.random.default_rng(0)
+    for (h, w) in [(200, 260), (300, 224), (224, 224), (97, 131)]:
+        fr = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        ref = proc(images=[Image.fromarray(f[:, :, ::-1].copy()) for f in fr], return_tensors="pt")["pixel_values"]
+        assert torch.allclose(dinov2_preprocess(fr), ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("accurate", 3e-4), ("mx", 1e-3)])
+def test_dinov2_tiny(dev, precision, tol):
+    from mertools_amd.encoders import HipDinov2Model
+    from util import assert_close
+    c = W.dinov2_config("tiny")
+    sd = W.dinov2_state_dict(c, 0)
+    g = torch.Generator().manual_seed(2)
+    px = torch.randn(6, 3, 42, 42, generator=g)          # 3x3 patches + CLS; position table interpolated 5x5 -> 3x3
+    m = HipDinov2Model(sd, c, device=dev, precision=precision, input_size=42)
+    hs = R.dinov2_hidden_states(sd, vars(c), px)
+    out = m(px.to(dev), output_hidden_states=True).hidden_states
+    feats = m.extract_frames(px.to(dev))
+    utt = m.extract_utterance(px.to(dev), [4, 2])
+    torch.cuda.synchronize()
+    assert_close(torch.stack(out)[-1].cpu(), hs[-1], tol, f"dinov2-tiny[{precision}] last hidden state")
+    ref = hs[-1].sum(dim=1)
+    assert_close(feats.cpu(), ref, tol, f"dinov2-tiny[{precision}] token-sum features")
+    assert_close(utt.cpu(), torch.stack([ref[:4].mean(0), ref[4:].mean(0)]), tol, f"dinov2-tiny[{precision}] UTT")
+
+
+@pytest.mark.gpu
+def test_dinov2_base_224(dev):
+    """dinov2-base architecture (768/12/12, patch 14, 37x37 trained grid) on 224x224 crops: 257 tokens, 6 frames."""
+    from mertools_amd.encoders import HipDinov2Model
+    from util import rel_err
+    c = W.dinov2_config("base", num_hidden_layers=6)      # half depth keeps the CPU oracle at a few seconds
+    sd = W.dinov2_state_dict(c, 0)
+    px = W.synth_frames(6)
+    ref = R.dinov2_frame_features(sd, vars(c), px)
+    for prec in ("mx", "accurate"):
+        m = HipDinov2Model(sd, c, device=dev, precision=prec)
+        out = m.extract_frames(px.to(dev))
+        utt = m.extract_utterance(px.to(dev), [6])
+        torch.cuda.synchronize()
+        e, eu = rel_err(out.cpu(), ref)[0], rel_err(utt.cpu(), ref.mean(0, keepdim=True))[0]
+        print(f"dinov2-base(6 layers)[{prec}]: frames={e:.2e} utt={eu:.2e}")
+        assert eu <= 1e-3 and e <= (1e-3 if prec == "accurate" else 2e-3)
+        del m
+
+
+@pytest.mark.gpu
+def test_dinov2_extract_files(dev, tmp_path):
+    from mertools_amd.encoders import HipDinov2Model
+    from mertools_amd.extract import visual
+    c = W.dinov2_config("tiny")
+    sd = W.dinov2_state_dict(c, 0)
+    m = HipDinov2Model(sd, c, device=dev, input_size=42)
+    rng = np.random.default_rng(3)
+    vids = {"v1": rng.integers(0, 256, (5, 60, 50, 3), dtype=np.uint8), "v2": rng.integers(0, 256, (70, 48, 48, 3), dtype=np.uint8),
+            "v3": np.zeros((0, 48, 48, 3), dtype=np.uint8)}
+    real_pre = visual.dinov2_preprocess
+    visual.dinov2_preprocess = lambda fr, size=224, resize_to=256: real_pre(fr, 42, 48)
+    try:
+        for level, sub in (("UTTERANCE", "utt"), ("FRAME", "fra")):
+            visual.extract_dinov2(m, "unused", str(tmp_path / sub), level, vids=list(vids), reader=lambda d, v: vids[v], nframe=8)
+    finally:
+        visual.dinov2_preprocess = real_pre
+    for vid, fr in vids.items():
+        u, f = np.load(tmp_path / "utt" / f"{vid}.npy"), np.load(tmp_path / "fra" / f"{vid}.npy")
+        if len(fr) == 0:
+            assert f.shape[0] == 1 and not f.any() and not u.any()
+            continue
+        px = real_pre(visual.resample_frames_uniform(fr, 8), 42, 48)
+        ref = R.dinov2_frame_features(sd, vars(c), px).numpy()
+        assert f.shape == (8, c.hidden_size) and u.shape == (c.hidden_size,) and f.dtype == np.float32
+        assert np.abs(f - ref).max() / np.abs(ref).max() < 1e-3
+        assert np.abs(u - ref.mean(0)).max() / np.abs(ref.mean(0)).max() < 1e-3
