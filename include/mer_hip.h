@@ -255,6 +255,7 @@ typedef struct {
  * MERBench/feature_extraction/audio/extract_audio_huggingface.py:97 and the last-4 sum / mean
  * of :98-108. */
 #define MER_MAX_CONV 8
+#define MER_MAX_POS 8
 typedef struct {
   mer_tf_config tf;
   int n_conv; int conv_dim; int conv_kernel[MER_MAX_CONV]; int conv_stride[MER_MAX_CONV];
@@ -264,6 +265,10 @@ typedef struct {
   int pos_k, pos_groups;
   int stable_layer_norm;    /* 1: HubertEncoderStableLayerNorm (large) */
   int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1, 2, 3 or 4 */
+  int pos_layers;           /* 0: HuBERT / wav2vec2 — one weight-normed conv, x + GELU(conv(x));
+                             * n >= 1: data2vec-audio (HF:data2vec/modeling_data2vec_audio.py Data2VecAudioPositionalConvEmbedding) —
+                             * n x [grouped conv (kernel pos_k, padding pos_k/2) -> LayerNorm without affine (eps 1e-5) -> GELU],
+                             * x + that stack; weights in pos_ws / pos_bs */
 } mer_hubert_config;
 
 typedef struct {
@@ -276,6 +281,7 @@ typedef struct {
   mer_w16 pos_w; const float* pos_b;    /* [G, D/G, pos_k * D/G] (weight-norm folded), column kk*Dg + ci */
   const float* enc_ln_g; const float* enc_ln_b;
   const mer_tf_layer* layers;           /* host array of tf.layers entries */
+  mer_w16 pos_ws[MER_MAX_POS]; const float* pos_bs[MER_MAX_POS];   /* pos_layers >= 1: per layer, same layout as pos_w / pos_b */
 } mer_hubert_weights;
 
 typedef struct mer_hubert mer_hubert;

@@ -13,6 +13,7 @@ MER_OK = 0
 MER_DT_F16, MER_DT_BF16 = 0, 1
 MER_ACT_NONE, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_ACT_RELU = 0, 1, 2, 3
 MER_MAX_CONV = 8
+MER_MAX_POS = 8
 
 c_void_p, c_int, c_ll, c_float = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
@@ -62,7 +63,8 @@ class HubertConfig(C.Structure):
     _fields_ = [("tf", TfConfig), ("n_conv", c_int), ("conv_dim", c_int),
                 ("conv_kernel", c_int * MER_MAX_CONV), ("conv_stride", c_int * MER_MAX_CONV),
                 ("feat_norm_group", c_int), ("conv_bias", c_int), ("feat_proj_layer_norm", c_int),
-                ("pos_k", c_int), ("pos_groups", c_int), ("stable_layer_norm", c_int), ("conv_passes", c_int)]
+                ("pos_k", c_int), ("pos_groups", c_int), ("stable_layer_norm", c_int), ("conv_passes", c_int),
+                ("pos_layers", c_int)]
 
 
 class HubertWeights(C.Structure):
@@ -71,7 +73,7 @@ class HubertWeights(C.Structure):
                 ("conv_w", W16 * MER_MAX_CONV), ("conv_b", c_void_p * MER_MAX_CONV),
                 ("fp_ln_g", c_void_p), ("fp_ln_b", c_void_p), ("fp_w", W16), ("fp_b", c_void_p),
                 ("pos_w", W16), ("pos_b", c_void_p), ("enc_ln_g", c_void_p), ("enc_ln_b", c_void_p),
-                ("layers", C.POINTER(TfLayer))]
+                ("layers", C.POINTER(TfLayer)), ("pos_ws", W16 * MER_MAX_POS), ("pos_bs", c_void_p * MER_MAX_POS)]
 
 
 class VitConfig(C.Structure):

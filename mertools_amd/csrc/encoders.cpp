@@ -159,7 +159,10 @@ extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_
   MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 4, MER_EINVAL, "mer_hubert_create: conv_passes must be 1, 2, 3 or 4");
   MER_REQUIRE(cfg->tf.hidden % cfg->pos_groups == 0 && (cfg->tf.hidden / cfg->pos_groups) % 8 == 0, MER_ESHAPE,
               "mer_hubert_create: hidden/pos_groups must be a multiple of 8");
-  MER_REQUIRE(w->layers && w->conv0_w && w->fp_w.hi && w->pos_w.hi, MER_EINVAL, "mer_hubert_create: missing weights");
+  MER_REQUIRE(cfg->pos_layers >= 0 && cfg->pos_layers <= MER_MAX_POS, MER_EINVAL, "mer_hubert_create: pos_layers=%d", cfg->pos_layers);
+  MER_REQUIRE(w->layers && w->conv0_w && w->fp_w.hi && (cfg->pos_layers > 0 || w->pos_w.hi), MER_EINVAL, "mer_hubert_create: missing weights");
+  for (int i = 0; i < cfg->pos_layers; ++i)
+    MER_REQUIRE(w->pos_ws[i].hi && w->pos_bs[i], MER_EINVAL, "mer_hubert_create: missing positional conv layer %d", i);
   mer_hubert* h = new mer_hubert();
   h->cfg = *cfg;
   h->w = *w;
@@ -192,6 +195,7 @@ struct HubertPlan {
   P16 fp16;
   float* hproj;
   P16 pospack;
+  float* posbuf;       // data2vec-audio: output of a positional conv layer (input of the next)
   float* ring;
   TfBufs tf;
   int T[MER_MAX_CONV];
@@ -212,6 +216,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   p.fp16 = take16(ar, M * C, clo);
   p.hproj = (float*)ar.take(M * D * 4);
   p.pospack = take16(ar, (long long)B * (Tn + c.pos_k) * D, clo);
+  p.posbuf = c.pos_layers > 0 ? (float*)ar.take(M * D * 4) : nullptr;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
   tf_plan(ar, c.tf, M, p.tf);
   return ar.off;
@@ -293,21 +298,38 @@ extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, 
   if (hidden_states) { hs.base = hidden_states; hs.ring = 0; } else { hs.base = p.ring; hs.ring = 5; }
   {
     const int G = c.pos_groups, Dg = D / G, K = c.pos_k;
-    MER_TRY(mer_posconv_pack(p.hproj, B, Tn, D, G, K, p.pospack.hi, p.pospack.lo, dt, st));
-    mer_gemm16_args g;
-    memset(&g, 0, sizeof(g));
-    g.M = Tn; g.N = Dg; g.K = K * Dg; g.dtype = dt;
-    g.a_hi = p.pospack.hi; g.a_lo = p.pospack.lo; g.lda = Dg;
-    g.w_hi = w.pos_w.hi; g.w_lo = w.pos_w.lo; g.ldw = g.K;
-    g.bias = w.pos_b; g.act = MER_ACT_GELU;
-    g.residual = p.hproj; g.ldr = D;
-    g.c32 = c.stable_layer_norm ? hs.at(0) : p.tf.t32; g.ldc32 = D;
-    g.nbatch = B * G; g.nb_inner = G;
-    g.a_so = (long long)G * (Tn + K) * Dg; g.a_si = (long long)(Tn + K) * Dg;
-    g.w_si = (long long)Dg * K * Dg; g.bias_si = Dg;
-    g.c_so = (long long)Tn * D; g.c_si = Dg;
-    g.passes = cps;
-    MER_TRY(mer_gemm16(&g, stream));
+    const int nl = c.pos_layers > 0 ? c.pos_layers : 1;
+    const float* src = p.hproj;
+    for (int i = 0; i < nl; ++i) {
+      const bool d2v = c.pos_layers > 0;
+      MER_TRY(mer_posconv_pack(src, B, Tn, D, G, K, p.pospack.hi, p.pospack.lo, dt, st));
+      mer_gemm16_args g;
+      memset(&g, 0, sizeof(g));
+      g.M = Tn; g.N = Dg; g.K = K * Dg; g.dtype = dt;
+      g.a_hi = p.pospack.hi; g.a_lo = p.pospack.lo; g.lda = Dg;
+      const mer_w16& pw = d2v ? w.pos_ws[i] : w.pos_w;
+      g.w_hi = pw.hi; g.w_lo = pw.lo; g.ldw = g.K;
+      g.bias = d2v ? w.pos_bs[i] : w.pos_b;
+      g.nbatch = B * G; g.nb_inner = G;
+      g.a_so = (long long)G * (Tn + K) * Dg; g.a_si = (long long)(Tn + K) * Dg;
+      g.w_si = (long long)Dg * K * Dg; g.bias_si = Dg;
+      g.c_so = (long long)Tn * D; g.c_si = Dg;
+      g.passes = cps == 4 ? 2 : cps;   // batched narrow GEMM: the MX kernel does not cover it, say so up front
+      if (!d2v) {  // HuBERT / wav2vec2: GELU and the residual ride in the epilogue
+        g.act = MER_ACT_GELU;
+        g.residual = p.hproj; g.ldr = D;
+        g.c32 = c.stable_layer_norm ? hs.at(0) : p.tf.t32; g.ldc32 = D;
+        MER_TRY(mer_gemm16(&g, stream));
+      } else {     // data2vec-audio: conv -> LayerNorm(no affine, eps 1e-5) -> GELU, five times; the residual once at the end
+        g.act = MER_ACT_NONE;
+        g.c32 = p.tf.t32; g.ldc32 = D;
+        MER_TRY(mer_gemm16(&g, stream));
+        MER_TRY(mer_layernorm(p.tf.t32, D, nullptr, nullptr, 1e-5f, M, D, MER_ACT_GELU, p.posbuf, D, nullptr, nullptr, 0, dt, st));
+        src = p.posbuf;
+      }
+    }
+    if (c.pos_layers > 0)   // hidden = hidden + pos_conv_embed(hidden)
+      MER_TRY(mer_sum_pool(p.hproj, p.posbuf, nullptr, nullptr, M, D, c.stable_layer_norm ? hs.at(0) : p.tf.t32, nullptr, nullptr, 0, nullptr, st));
   }
   if (!c.stable_layer_norm)
     MER_TRY(mer_layernorm(p.tf.t32, D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(0), D, p.tf.cur16.hi, p.tf.cur16.lo, D, dt, st));

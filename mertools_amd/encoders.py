@@ -191,7 +191,12 @@ class HipHubertModel(_HipModule):
         cfg.feat_norm_group = 1 if config.feat_extract_norm == "group" else 0
         cfg.conv_bias = int(config.conv_bias)
         cfg.feat_proj_layer_norm = int(getattr(config, "feat_proj_layer_norm", True))
-        cfg.pos_k, cfg.pos_groups = config.num_conv_pos_embeddings, config.num_conv_pos_embedding_groups
+        # data2vec-audio (HF:data2vec/modeling_data2vec_audio.py): num_conv_pos_embeddings is the NUMBER of positional conv
+        # layers (5) and conv_pos_kernel_size their kernel (19); HuBERT / wav2vec2: one conv of kernel num_conv_pos_embeddings
+        d2v = "encoder.pos_conv_embed.layers.0.conv.weight" in sd
+        cfg.pos_k = config.conv_pos_kernel_size if d2v else config.num_conv_pos_embeddings
+        cfg.pos_groups = config.num_conv_pos_embedding_groups
+        cfg.pos_layers = config.num_conv_pos_embeddings if d2v else 0
         cfg.stable_layer_norm = int(config.do_stable_layer_norm)
         cfg.conv_passes = conv_passes
         clo, cmx = conv_passes >= 2, conv_passes == 4
@@ -213,18 +218,28 @@ class HipHubertModel(_HipModule):
         w.fp_b = hold.f32(sd["feature_projection.projection.bias"])
         # positional conv: fold weight-norm (dim=2), then [D, Dg, K] -> [G, Dg, K*Dg] with column kk*Dg + ci
         p = "encoder.pos_conv_embed.conv."
-        if p + "weight" in sd:
-            pw = sd[p + "weight"]
-        else:
-            if p + "parametrizations.weight.original0" in sd:
-                g, v = sd[p + "parametrizations.weight.original0"], sd[p + "parametrizations.weight.original1"]
-            else:
-                g, v = sd[p + "weight_g"], sd[p + "weight_v"]
-            pw = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
         G, K = cfg.pos_groups, cfg.pos_k
         Dg = D // G
-        w.pos_w = hold.w16(pw.reshape(G, Dg, Dg, K).permute(0, 1, 3, 2).reshape(G * Dg, K * Dg), clo)
-        w.pos_b = hold.f32(sd[p + "bias"])
+
+        def pos_layout(pw):
+            return pw.reshape(G, Dg, Dg, K).permute(0, 1, 3, 2).reshape(G * Dg, K * Dg)
+
+        if d2v:
+            for i in range(cfg.pos_layers):
+                q = f"encoder.pos_conv_embed.layers.{i}.conv."
+                w.pos_ws[i] = hold.w16(pos_layout(sd[q + "weight"]), clo)
+                w.pos_bs[i] = hold.f32(sd[q + "bias"])
+        else:
+            if p + "weight" in sd:
+                pw = sd[p + "weight"]
+            else:
+                if p + "parametrizations.weight.original0" in sd:
+                    g, v = sd[p + "parametrizations.weight.original0"], sd[p + "parametrizations.weight.original1"]
+                else:
+                    g, v = sd[p + "weight_g"], sd[p + "weight_v"]
+                pw = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+            w.pos_w = hold.w16(pos_layout(pw), clo)
+            w.pos_b = hold.f32(sd[p + "bias"])
         w.enc_ln_g, w.enc_ln_b = hold.f32(sd["encoder.layer_norm.weight"]), hold.f32(sd["encoder.layer_norm.bias"])
         tlo, tmx = tf_passes >= 2, tf_passes == 4
         layers = (TfLayer * config.num_hidden_layers)()
@@ -294,6 +309,9 @@ class HipHubertModel(_HipModule):
 # feature_projection.*, encoder.pos_conv_embed.*, encoder.layers.*): the reference's audio script treats them alike
 # (extract_audio_huggingface.py:92-100), and so does this class.
 HipWav2Vec2Model = HipHubertModel
+# data2vec-audio: same conv stack ("layer" norm) and post-LN blocks, a 5-layer positional conv stack instead of one
+# weight-normed conv (handled by pos_layers); the reference treats it like the others (extract_audio_huggingface.py:22-23,93-100)
+HipData2VecAudioModel = HipHubertModel
 
 
 # =================================================================================================

@@ -40,6 +40,16 @@ def hubert_config(size="base", **over):
     return SimpleNamespace(**base)
 
 
+def data2vec_audio_config(size="base", **over):
+    """Data2VecAudioConfig: every conv layer is followed by LayerNorm, no conv bias, 5 positional conv layers of kernel 19."""
+    c = hubert_config(size if size != "base" else "base", feat_extract_norm="layer", conv_bias=False, do_stable_layer_norm=False,
+                      num_conv_pos_embeddings=5, conv_pos_kernel_size=19, model_type="data2vec-audio")
+    if size == "tiny":
+        vars(c).update(num_conv_pos_embedding_groups=4)
+    vars(c).update(over)
+    return c
+
+
 def hubert_state_dict(cfg, seed=0):
     g = _g(seed)
     sd = {}
@@ -57,9 +67,15 @@ def hubert_state_dict(cfg, seed=0):
         sd["feature_projection.layer_norm.weight"], sd["feature_projection.layer_norm.bias"] = _ln(g, C)
     sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"] = _lin(g, D, C)
     K, G = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
-    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = torch.randn(D, D // G, K, generator=g) * math.sqrt(1.0 / (K * D // G))
-    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = 0.5 + torch.rand(1, 1, K, generator=g)
-    sd["encoder.pos_conv_embed.conv.bias"] = torch.randn(D, generator=g) * 0.05
+    if getattr(cfg, "model_type", "hubert") == "data2vec-audio":
+        Kc = cfg.conv_pos_kernel_size
+        for i in range(K):
+            sd[f"encoder.pos_conv_embed.layers.{i}.conv.weight"] = torch.randn(D, D // G, Kc, generator=g) * math.sqrt(2.0 / (Kc * D // G))
+            sd[f"encoder.pos_conv_embed.layers.{i}.conv.bias"] = torch.randn(D, generator=g) * 0.05
+    else:
+        sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = torch.randn(D, D // G, K, generator=g) * math.sqrt(1.0 / (K * D // G))
+        sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = 0.5 + torch.rand(1, 1, K, generator=g)
+        sd["encoder.pos_conv_embed.conv.bias"] = torch.randn(D, generator=g) * 0.05
     sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"] = _ln(g, D)
     for l in range(cfg.num_hidden_layers):
         p = f"encoder.layers.{l}."

@@ -88,11 +88,24 @@ def hubert_hidden_states(sd, cfg, wav):
     x = F.linear(x, sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"])
     # positional conv embedding: HF:...:45-103
     K = cfg["num_conv_pos_embeddings"]
-    pc = F.conv1d(x.transpose(1, 2), pos_conv_weight(sd), sd["encoder.pos_conv_embed.conv.bias"], padding=K // 2,
-                  groups=cfg["num_conv_pos_embedding_groups"])
-    if K % 2 == 0:
-        pc = pc[:, :, :-1]
-    x = x + _gelu(pc).transpose(1, 2)
+    if cfg.get("model_type") == "data2vec-audio":
+        # Data2VecAudioPositionalConvEmbedding (HF:data2vec/modeling_data2vec_audio.py): num_conv_pos_embeddings layers of
+        # Conv1d(D, D, conv_pos_kernel_size, padding k//2, groups) -> [drop last if k even] -> LayerNorm(no affine) -> GELU
+        Kc = cfg["conv_pos_kernel_size"]
+        pc = x.transpose(1, 2)
+        for i in range(K):
+            q = f"encoder.pos_conv_embed.layers.{i}.conv."
+            pc = F.conv1d(pc, sd[q + "weight"], sd[q + "bias"], padding=Kc // 2, groups=cfg["num_conv_pos_embedding_groups"])
+            if Kc % 2 == 0:
+                pc = pc[:, :, :-1]
+            pc = _gelu(F.layer_norm(pc.transpose(1, 2), (pc.shape[1],), None, None, 1e-5)).transpose(1, 2)
+        x = x + pc.transpose(1, 2)
+    else:
+        pc = F.conv1d(x.transpose(1, 2), pos_conv_weight(sd), sd["encoder.pos_conv_embed.conv.bias"], padding=K // 2,
+                      groups=cfg["num_conv_pos_embedding_groups"])
+        if K % 2 == 0:
+            pc = pc[:, :, :-1]
+        x = x + _gelu(pc).transpose(1, 2)
     stable = cfg.get("do_stable_layer_norm", False)
     if not stable:
         x = _ln(x, sd, "encoder.layer_norm", eps)  # HF:...:439-441

@@ -280,3 +280,40 @@ def test_large_trio(dev):
     print("large trio: " + "  ".join(f"{k}={v:.2e}" for k, v in res.items()))
     for k, v in res.items():
         assert v <= (TOL if ",f16]" in k else 5e-3), (k, v)   # bf16 (8-bit mantissa) even 3-pass is limited by bf16 attention / planes
+
+
+# ---- data2vec-audio: 5-layer positional conv stack on the HuBERT engine ----
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL)])
+def test_data2vec_audio_tiny(dev, precision, tol):
+    from mertools_amd.encoders import HipData2VecAudioModel
+    cfg = W.data2vec_audio_config("tiny")
+    sd = W.hubert_state_dict(cfg, 1)
+    wav = W.synth_audio(3, 16000)
+    hs = R.hubert_hidden_states(sd, vars(cfg), wav)
+    m = HipData2VecAudioModel(sd, cfg, device=dev, precision=precision)
+    out = m(wav.to(dev), output_hidden_states=True).hidden_states
+    pooled = m.extract_utterance(wav.to(dev))
+    torch.cuda.synchronize()
+    assert len(out) == len(hs)
+    for i, (o, r) in enumerate(zip(out, hs)):
+        # raw hidden states of a 128-wide toy model after 5 conv+LayerNorm layers: 2x the feature tolerance outside "accurate"
+        assert_close(o.cpu(), r, tol if precision == "accurate" else 2 * tol, f"data2vec-audio-tiny[{precision}] hidden_states[{i}]")
+    assert_close(pooled.cpu(), torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1), tol, f"data2vec-audio-tiny[{precision}] UTT feature")
+
+
+def test_data2vec_audio_base_5s(dev):
+    from mertools_amd.encoders import HipData2VecAudioModel
+    from util import rel_err
+    cfg = W.data2vec_audio_config("base")
+    sd = W.hubert_state_dict(cfg, 0)
+    wav = W.synth_audio(2, 80000)
+    hs = R.hubert_hidden_states(sd, vars(cfg), wav)
+    utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
+    for prec in ("mx", "accurate"):
+        m = HipData2VecAudioModel(sd, cfg, device=dev, precision=prec)
+        pooled = m.extract_utterance(wav.to(dev))
+        torch.cuda.synchronize()
+        e = rel_err(pooled.cpu(), utt)[0]
+        print(f"data2vec-audio-base[{prec}]: utt={e:.2e}")
+        assert e <= (TOL if prec == "mx" else X3)
+        del m

@@ -135,3 +135,29 @@ def test_host_oracle_matches_reference_goldens_bit_exact():
     folds = HR.random_split_indexes(3373, 5)
     for i, (tr, ev) in enumerate(folds):
         assert np.array_equal(np.array(tr), g[f"fold{i}_train"]) and np.array_equal(np.array(ev), g[f"fold{i}_eval"])
+
+
+def test_data2vec_audio_oracle_matches_hf():
+    """data2vec-audio branch (extract_audio_huggingface.py:22-23): 'layer'-norm conv stack + 5 x [grouped conv k=19 -> LayerNorm
+    without affine -> GELU] positional stack, post-LN blocks — the restatement against the live HF class on a tiny checkpoint."""
+    import torch
+    from transformers import Data2VecAudioConfig, Data2VecAudioModel
+    from mertools_amd import synthetic as W
+    from oracle import encoders_ref as R
+    c = W.data2vec_audio_config("tiny")
+    sd = W.hubert_state_dict(c, 0)
+    hc = Data2VecAudioConfig(hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                             intermediate_size=c.intermediate_size, conv_dim=c.conv_dim, conv_kernel=c.conv_kernel, conv_stride=c.conv_stride,
+                             conv_bias=False, num_conv_pos_embeddings=5, conv_pos_kernel_size=19,
+                             num_conv_pos_embedding_groups=c.num_conv_pos_embedding_groups, layer_norm_eps=c.layer_norm_eps, hidden_dropout=0.0,
+                             attention_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0, attn_implementation="eager")
+    m = Data2VecAudioModel(hc).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    wav = W.synth_audio(2, 16000)
+    with torch.no_grad():
+        hs = m(wav, output_hidden_states=True).hidden_states
+    ours = R.hubert_hidden_states(sd, vars(c), wav)
+    assert len(hs) == len(ours) == c.num_hidden_layers + 1
+    for a, b in zip(ours, hs):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5)
