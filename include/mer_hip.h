@@ -239,6 +239,12 @@ typedef struct {
   mer_w16 w1; const float* b1;
   mer_w16 w2; const float* b2;
   const float* ln2_g; const float* ln2_b;
+  /* optional additive attention-score bias (all NULL for the models above):
+   *   attn_bias  fp32 [H, T, ceil4(T)] baked for a fixed T (BEiT / data2vec-vision relative position bias); when NULL the
+   *              table passed to the forward call is used (WavLM: one table per T shared by every layer);
+   *   gru_w [8,64], gru_b [8], gru_const [H]: WavLM's per-layer gate on that table (mer_wavlm_gate). */
+  const float* attn_bias;
+  const float* gru_w; const float* gru_b; const float* gru_const;
 } mer_tf_layer;
 
 typedef struct {
@@ -248,6 +254,7 @@ typedef struct {
   float ln_eps;
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
   int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split) or 4 (MX-corrected, see mer_gemm16) */
+  int gated_rel_pos;  /* 1: WavLM — every layer carries gru_* and the forward call must be given the position-bias table */
 } mer_tf_config;
 
 /* ---- HuBERT / wav2vec2 audio encoder --------------------------------------------------------
@@ -302,6 +309,14 @@ int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, int L,
                        float* hidden_states, float* frames,
                        const int* seg_start, const int* seg_len, int nseg, float* pooled,
                        mer_stream_t stream);
+/* WavLM (tf.gated_rel_pos = 1): same, plus the relative position bias table fp32 [H, T, ldb] for T = mer_hubert_out_frames(L)
+ * (WavLMAttention.compute_bias of layer 0's rel_attn_embed; rows padded to ldb % 4 == 0).  The table depends only on T and
+ * the checkpoint, so the caller builds it once per input length. */
+int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, int B, int L,
+                            void* workspace, long long workspace_bytes,
+                            float* hidden_states, float* frames,
+                            const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                            const float* pos_bias, long long ldb, mer_stream_t stream);
 
 /* ---- CLIP vision tower ----------------------------------------------------------------------
  * Replaces `model.get_image_features(pixel_values)` at
@@ -338,6 +353,19 @@ int mer_vit_forward(const mer_vit* h, const float* pixels, int N, void* workspac
 int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int N, void* workspace, long long workspace_bytes,
                            float* image_features, const int* seg_start, const int* seg_len, int nseg, float* pooled,
                            float* tokens_out, mer_stream_t stream);
+
+/* mer_attention with an additive score bias: scores = q k^T * scale + gate[b,h,q] * bias[h,q,k].
+ * bias: fp32 [H, T, ldb] (ldb >= T, ldb % 4 == 0, 16-byte aligned; one table for the whole batch); gate: fp32 [B, H, T] or NULL
+ * (= 1).  WavLM's gated relative position bias (HF:wavlm/modeling_wavlm.py WavLMAttention) and, ungated, BEiT /
+ * data2vec-vision's relative position bias.  T <= 512. */
+int mer_attention_bias(const void* q, const void* k, const void* v, long long ld, void* out_hi, void* out_lo,
+                       long long ldo, int B, int T, int H, float scale, const int* kv_len, const float* bias,
+                       long long ldb, const float* gate, int dtype, mer_stream_t stream);
+
+/* WavLM gate: gate[b,h,t] = ga * (gb * cst[h] - 1) + 2 with (ga, gb) = sigmoid of the two 4-sums of W[8,64] x[m, 64h:64h+64] + b[8],
+ * x fp32 [B*T, ldx] = the attention input of the layer (head_dim 64). */
+int mer_wavlm_gate(const float* x, long long ldx, const float* w, const float* b, const float* cst, int B, int T, int H,
+                   float* gate, mer_stream_t stream);
 
 /* out[n, :] = scale * sum over t of x[n, t, :]   (x fp32 [N, T, D]; token sum / mean of a hidden state). */
 int mer_token_reduce(const float* x, int N, int T, int D, float scale, float* out, mer_stream_t stream);

@@ -51,12 +51,13 @@ class TfLayer(C.Structure):
         ("w1", W16), ("b1", c_void_p),
         ("w2", W16), ("b2", c_void_p),
         ("ln2_g", c_void_p), ("ln2_b", c_void_p),
+        ("attn_bias", c_void_p), ("gru_w", c_void_p), ("gru_b", c_void_p), ("gru_const", c_void_p),
     ]
 
 
 class TfConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("layers", c_int), ("pre_ln", c_int),
-                ("act", c_int), ("ln_eps", c_float), ("dtype", c_int), ("passes", c_int)]
+                ("act", c_int), ("ln_eps", c_float), ("dtype", c_int), ("passes", c_int), ("gated_rel_pos", c_int)]
 
 
 class HubertConfig(C.Structure):
@@ -162,6 +163,8 @@ _PROTOS = {
     "mer_hubert_workspace_bytes": (c_ll, [c_void_p, c_int, c_int, c_int]),
     "mer_hubert_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p, c_void_p]),
+    "mer_hubert_forward_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     "mer_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(c_void_p)]),
     "mer_vit_destroy": (None, [c_void_p]),
     "mer_vit_workspace_bytes": (c_ll, [c_void_p, c_int]),
@@ -169,6 +172,9 @@ _PROTOS = {
                                 c_void_p, c_void_p]),
     "mer_vit_forward_tokens": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p]),
+    "mer_attention_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_float,
+                                   c_void_p, c_void_p, c_ll, c_void_p, c_int, c_void_p]),
+    "mer_wavlm_gate": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mer_token_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mer_videomae_create": (c_int, [C.POINTER(VideoMAEConfig), C.POINTER(VideoMAEWeights), C.POINTER(c_void_p)]),
     "mer_videomae_destroy": (None, [c_void_p]),

@@ -20,10 +20,16 @@ namespace mer {
 extern unsigned long long* g_gemm_dbg;
 int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
 
-template <typename T, int NKT>
+// BIAS: scores get an additive term gate[b,h,q] * bias[h,q,k] before the softmax — WavLM's gated relative position bias
+// (HF:wavlm/modeling_wavlm.py WavLMAttention.forward: one [H,T,T] table shared by the batch and by all layers, a per-query
+// gate per layer) and, with gate == NULL, BEiT / data2vec-vision's relative position bias.  A lane owns ONE query row, so
+// its four keys of a tile are 16 contiguous bytes of that row of the table (rows padded to ldb % 4 == 0).
+template <typename T, int NKT, bool BIAS = false>
 __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
-                                                      long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg) {
+                                                      long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg,
+                                                      const float* __restrict__ bias = nullptr, long long ldb = 0,
+                                                      const float* __restrict__ gate = nullptr) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
   constexpr int TP = NKT * 16;
@@ -110,15 +116,24 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
 
   // ---- softmax over keys (fp32, base-2 exponent) ----
   float mx = -INFINITY;
+  const float* brow = nullptr;
+  float gq = 1.4426950408889634f;   // the bias is added in the base-2 domain too
+  if (BIAS) {
+    brow = bias + ((long long)h * Tn + qrow) * ldb;
+    if (gate) gq *= gate[((long long)b * gridDim.y + h) * Tn + qrow];
+  }
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS && kt * 16 + lg * 4 < Tn) bv = *reinterpret_cast<const f32x4*>(brow + kt * 16 + lg * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kt * 16 + lg * 4 + r;
-      const float x = key < klen ? s[kt][r] * scale_log2e : -INFINITY;
+      const float x = key < klen ? (BIAS ? fmaf(gq, bv[r], s[kt][r] * scale_log2e) : s[kt][r] * scale_log2e) : -INFINITY;
       s[kt][r] = x;
       mx = fmaxf(mx, x);
     }
+  }
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   if (!(mx > -INFINITY)) mx = 0.f;  // klen == 0: all keys masked -> zeros out
@@ -318,10 +333,28 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
 
 template <typename T>
 static int launch_attn(const void* q, const void* k, const void* v, long long ld, void* oh, void* ol, long long ldo,
-                       int B, int Tn, int H, float scale, const int* kv_len, int hm, hipStream_t st) {
+                       int B, int Tn, int H, float scale, const int* kv_len, int hm, hipStream_t st,
+                       const float* bias = nullptr, long long ldb = 0, const float* gate = nullptr) {
   const float sl2 = scale * 1.4426950408889634f;
   dim3 grid(1, H, B), block(256);  // one workgroup per (batch, head): K/V staged once
-  ProfScope prof("attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
+  ProfScope prof(bias ? "attention_bias" : "attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
+  if (bias) {
+#define MER_ATTN_BCASE(N)                                                                                            \
+  hipLaunchKernelGGL((attn_sp_kernel<T, N, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
+                     (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate)
+    if (Tn <= 64) MER_ATTN_BCASE(4);
+    else if (Tn <= 128) MER_ATTN_BCASE(8);
+    else if (Tn <= 224) MER_ATTN_BCASE(14);
+    else if (Tn <= 256) MER_ATTN_BCASE(16);
+    else if (Tn <= 288) MER_ATTN_BCASE(18);
+    else if (Tn <= 512) MER_ATTN_BCASE(32);
+    else {
+      set_error("mer_attention_bias: T=%d > 512 is not supported with a score bias", Tn);
+      return MER_EUNSUPPORTED;
+    }
+#undef MER_ATTN_BCASE
+    return check_launch("attention_bias");
+  }
 #define MER_ATTN_CASE(N)                                                                                       \
   hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
                      (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg)
@@ -371,5 +404,22 @@ extern "C" int mer_attention_hm(const void* q, const void* k, const void* v, voi
   if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, 64, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 1, st);
   if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, 64, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 1, st);
   set_error("mer_attention_hm: bad dtype %d", dtype);
+  return MER_EINVAL;
+}
+
+extern "C" int mer_attention_bias(const void* q, const void* k, const void* v, long long ld, void* out_hi, void* out_lo,
+                                  long long ldo, int B, int T, int H, float scale, const int* kv_len, const float* bias,
+                                  long long ldb, const float* gate, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(q && k && v && out_hi && bias, MER_EINVAL, "mer_attention_bias: null pointer");
+  MER_REQUIRE(B > 0 && T > 0 && H > 0, MER_ESHAPE, "mer_attention_bias: bad shape B=%d T=%d H=%d", B, T, H);
+  MER_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, MER_ESHAPE, "mer_attention_bias: ld %% 8 / ldo %% 4 alignment");
+  MER_REQUIRE(ldb >= T && ldb % 4 == 0 && ((uintptr_t)bias & 15) == 0, MER_ESHAPE,
+              "mer_attention_bias: bias rows must be padded to a multiple of 4 floats (ldb=%lld, T=%d) and 16-byte aligned", ldb, T);
+  MER_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, MER_EINVAL, "mer_attention_bias: q/k/v must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 0, st, bias, ldb, gate);
+  if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 0, st, bias, ldb, gate);
+  set_error("mer_attention_bias: bad dtype %d", dtype);
   return MER_EINVAL;
 }

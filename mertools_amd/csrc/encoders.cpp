@@ -69,6 +69,8 @@ struct TfBufs {
   float* t32;
   float* h1_32;
   P16 cur16, qkv16, ctx16, h1_16, f16;
+  float* gate;     // WavLM: [B, H, T] gate of the current layer
+  float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
 };
 
 static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
@@ -81,12 +83,14 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
   b.ctx16 = take16(ar, M * D, lo);
   b.h1_16 = take16(ar, M * D, lo);
   b.f16 = take16(ar, M * F, lo);
+  b.gate = c.gated_rel_pos ? (float*)ar.take(M * c.heads * 4) : nullptr;
+  b.gin32 = (c.gated_rel_pos && c.pre_ln) ? (float*)ar.take(M * D * 4) : nullptr;
 }
 
 // Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
 // input; pre-LN: hs.at(0) holds the raw residual stream.  Writes hs.at(l+1) for every layer.
 static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer* L, int Bseq, int T, const HsMap& hs,
-                      TfBufs& b, const int* kv_len) {
+                      TfBufs& b, const int* kv_len, const float* pos_bias = nullptr, long long ldb = 0) {
   const int M = Bseq * T, D = c.hidden, F = c.ffn, H = c.heads;
   const int dt = c.dtype, ps = c.passes;
   const float scale = 1.0f / sqrtf((float)(D / H));
@@ -96,10 +100,20 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     float* x = hs.at(l);
     float* y = hs.at(l + 1);
     if (c.pre_ln)
-      MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.cur16.hi, b.cur16.lo, D, dt, st));
+      MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.gin32, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
     MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
+    const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
+    if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
+      const float* gate = nullptr;
+      if (w.gru_w) {
+        MER_TRY(mer_wavlm_gate(c.pre_ln ? b.gin32 : x, D, w.gru_w, w.gru_b, w.gru_const, Bseq, T, H, b.gate, (mer_stream_t)st));
+        gate = b.gate;
+      }
+      MER_TRY(mer_attention_bias(b.qkv16.hi, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
+                                 b.ctx16.hi, b.ctx16.lo, D, Bseq, T, H, scale, kv_len, ab, w.attn_bias ? (T + 3) / 4 * 4 : ldb, gate, dt, st));
+    } else
     MER_TRY(mer_attention(b.qkv16.hi, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
                           b.ctx16.hi, b.ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, st));
     MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0));
@@ -123,6 +137,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.hidden % 8 == 0 && c.ffn % 8 == 0, MER_ESHAPE, "%s: hidden/ffn must be multiples of 8", who);
   MER_REQUIRE(c.passes >= 1 && c.passes <= 4, MER_EINVAL, "%s: passes must be 1, 2, 3 or 4 (MX-corrected)", who);
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
+  MER_REQUIRE(c.gated_rel_pos == 0 || c.gated_rel_pos == 1, MER_EINVAL, "%s: gated_rel_pos must be 0 or 1", who);
   MER_REQUIRE(c.dtype == MER_DT_F16 || c.dtype == MER_DT_BF16, MER_EINVAL, "%s: bad dtype", who);
   return MER_OK;
 }
@@ -163,6 +178,10 @@ extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_
   MER_REQUIRE(w->layers && w->conv0_w && w->fp_w.hi && (cfg->pos_layers > 0 || w->pos_w.hi), MER_EINVAL, "mer_hubert_create: missing weights");
   for (int i = 0; i < cfg->pos_layers; ++i)
     MER_REQUIRE(w->pos_ws[i].hi && w->pos_bs[i], MER_EINVAL, "mer_hubert_create: missing positional conv layer %d", i);
+  if (cfg->tf.gated_rel_pos)
+    for (int l = 0; l < cfg->tf.layers; ++l)
+      MER_REQUIRE(w->layers[l].gru_w && w->layers[l].gru_b && w->layers[l].gru_const, MER_EINVAL,
+                  "mer_hubert_create: WavLM layer %d lacks the gru_rel_pos parameters", l);
   mer_hubert* h = new mer_hubert();
   h->cfg = *cfg;
   h->w = *w;
@@ -229,10 +248,20 @@ extern "C" long long mer_hubert_workspace_bytes(const mer_hubert* h, int B, int 
   return hubert_plan(h, ar, B, L, want_hidden_states != 0, p) + 256;
 }
 
-extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, int L, void* workspace,
+extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, int L, void* workspace, long long workspace_bytes,
+                                  float* hidden_states, float* frames, const int* seg_start, const int* seg_len, int nseg,
+                                  float* pooled, mer_stream_t stream) {
+  return mer_hubert_forward_bias(h, wav, B, L, workspace, workspace_bytes, hidden_states, frames, seg_start, seg_len, nseg, pooled,
+                                 nullptr, 0, stream);
+}
+
+extern "C" int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, int B, int L, void* workspace,
                                   long long workspace_bytes, float* hidden_states, float* frames, const int* seg_start,
-                                  const int* seg_len, int nseg, float* pooled, mer_stream_t stream) {
+                                  const int* seg_len, int nseg, float* pooled, const float* pos_bias, long long ldb,
+                                  mer_stream_t stream) {
   MER_REQUIRE(h && wav && workspace, MER_EINVAL, "mer_hubert_forward: null argument");
+  MER_REQUIRE(!h->cfg.tf.gated_rel_pos || pos_bias, MER_EINVAL,
+              "mer_hubert_forward: this is a WavLM handle — call mer_hubert_forward_bias with the relative position bias table");
   MER_REQUIRE(B > 0 && L >= 400, MER_ESHAPE, "mer_hubert_forward: need B>0 and L>=400 samples (B=%d L=%d)", B, L);
   MER_REQUIRE(((uintptr_t)workspace & 255) == 0, MER_EINVAL, "mer_hubert_forward: workspace must be 256-byte aligned");
   const mer_hubert_config& c = h->cfg;
@@ -334,7 +363,7 @@ extern "C" int mer_hubert_forward(const mer_hubert* h, const float* wav, int B, 
   if (!c.stable_layer_norm)
     MER_TRY(mer_layernorm(p.tf.t32, D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(0), D, p.tf.cur16.hi, p.tf.cur16.lo, D, dt, st));
 
-  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, Tn, hs, p.tf, nullptr));
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, Tn, hs, p.tf, nullptr, c.tf.gated_rel_pos ? pos_bias : nullptr, ldb));
 
   if (c.stable_layer_norm)  // final LayerNorm only on the last state (HF:hubert/modeling_hubert.py:612)
     MER_TRY(mer_layernorm(hs.at(c.tf.layers), D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(c.tf.layers), D, nullptr, nullptr, 0, dt, st));

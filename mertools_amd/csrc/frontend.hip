@@ -371,6 +371,28 @@ __global__ __launch_bounds__(256) void token_reduce_kernel(const float* x, int T
   if (wave == 0 && col < D) out[(long long)n * D + col] = scale * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
+// WavLM gate (HF:wavlm/modeling_wavlm.py WavLMAttention.forward steps 1-3): per (row m = (b,t), head h) an 8-way linear on
+// the head's 64-wide slice of the attention input, two groups of four summed, sigmoids, gate_a * (gate_b * const_h - 1) + 2.
+// One wave per (m, h): lane d holds x[m, 64h + d]; the eight dot products are wave reductions.
+__global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, long long ldx, const float* w, const float* bvec,
+                                                         const float* cst, int M, int Tn, int H, float* gate) {
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long long)M * H) return;
+  const int lane = threadIdx.x & 63;
+  const int h = (int)(wid % H);
+  const long long m = wid / H;
+  const float xv = x[m * ldx + h * 64 + lane];
+  float p[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = wave_sum(xv * w[j * 64 + lane]) + bvec[j];
+  if (lane == 0) {
+    const float a = (p[0] + p[1]) + (p[2] + p[3]), c = (p[4] + p[5]) + (p[6] + p[7]);
+    const float ga = 1.f / (1.f + expf(-a)), gb = 1.f / (1.f + expf(-c));
+    const long long bi = m / Tn, t = m % Tn;
+    gate[(bi * H + h) * Tn + t] = ga * (gb * cst[h] - 1.f) + 2.f;
+  }
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long g = cdiv(n, block);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -511,4 +533,13 @@ extern "C" int mer_token_reduce(const float* x, int N, int T, int D, float scale
   MER_REQUIRE(x && out && N > 0 && T > 0 && D > 0, MER_EINVAL, "mer_token_reduce: bad argument");
   hipLaunchKernelGGL(token_reduce_kernel, dim3(N, (unsigned)cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, x, T, D, scale, out);
   return check_launch("token_reduce");
+}
+
+extern "C" int mer_wavlm_gate(const float* x, long long ldx, const float* w, const float* b, const float* cst, int B, int T,
+                              int H, float* gate, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && w && b && cst && gate && B > 0 && T > 0 && H > 0, MER_EINVAL, "mer_wavlm_gate: bad argument");
+  const long long waves = (long long)B * T * H;
+  hipLaunchKernelGGL(wavlm_gate_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, cst, B * T, T, H, gate);
+  return check_launch("wavlm_gate");
 }

@@ -199,6 +199,8 @@ class HipHubertModel(_HipModule):
         cfg.pos_layers = config.num_conv_pos_embeddings if d2v else 0
         cfg.stable_layer_norm = int(config.do_stable_layer_norm)
         cfg.conv_passes = conv_passes
+        wavlm = "encoder.layers.0.attention.rel_attn_embed.weight" in sd
+        cfg.tf.gated_rel_pos = int(wavlm)
         clo, cmx = conv_passes >= 2, conv_passes == 4
         w = HubertWeights()
         fe = "feature_extractor.conv_layers."
@@ -253,6 +255,12 @@ class HipHubertModel(_HipModule):
                 sd[q + "feed_forward.intermediate_dense.weight"], sd[q + "feed_forward.intermediate_dense.bias"],
                 sd[q + "feed_forward.output_dense.weight"], sd[q + "feed_forward.output_dense.bias"],
                 (sd[q + "final_layer_norm.weight"], sd[q + "final_layer_norm.bias"]), mx=tmx)
+            if wavlm:   # gated relative position bias (HF:wavlm/modeling_wavlm.py WavLMAttention)
+                layers[l].gru_w = hold.f32(sd[a + "gru_rel_pos_linear.weight"])
+                layers[l].gru_b = hold.f32(sd[a + "gru_rel_pos_linear.bias"])
+                layers[l].gru_const = hold.f32(sd[a + "gru_rel_pos_const"].reshape(-1))
+        self._rel_embed = sd["encoder.layers.0.attention.rel_attn_embed.weight"] if wavlm else None
+        self._pos_bias = {}
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers
         _lib.check(_lib.lib().mer_hubert_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_hubert_create")
@@ -264,6 +272,29 @@ class HipHubertModel(_HipModule):
 
     def out_frames(self, L):
         return _lib.lib().mer_hubert_out_frames(self._handle, int(L))
+
+    def position_bias(self, T):
+        """WavLM: the [H, T, ceil4(T)] relative position bias table for T frames (WavLMAttention.compute_bias, built once per
+        T with the reference's own torch ops on the host — bucket edges are float-log comparisons — and cached on the device)."""
+        if self._rel_embed is None:
+            return None
+        if T not in self._pos_bias:
+            import math
+            nbk, maxd = getattr(self.config, "num_buckets", 320), getattr(self.config, "max_bucket_distance", 800)
+            rel = torch.arange(T, dtype=torch.long)[None, :] - torch.arange(T, dtype=torch.long)[:, None]
+            nb = nbk // 2
+            buckets = (rel > 0).to(torch.long) * nb
+            rel = torch.abs(rel)
+            max_exact = nb // 2
+            large = torch.log(rel.float() / max_exact) / math.log(maxd / max_exact) * (nb - max_exact)
+            large = torch.min((max_exact + large).to(torch.long), torch.full_like(rel, nb - 1))
+            buckets = buckets + torch.where(rel < max_exact, rel, large)
+            table = torch.nn.functional.embedding(buckets, self._rel_embed).permute(2, 0, 1)     # [H, T, T]
+            ldb = (T + 3) // 4 * 4
+            padded = torch.zeros(table.shape[0], T, ldb)
+            padded[:, :, :T] = table
+            self._pos_bias[T] = padded.contiguous().to(self.device)
+        return self._pos_bias[T]
 
     def forward_raw(self, input_values, *, hidden_states=False, frames=False, seg_start=None, seg_len=None):
         x = input_values
@@ -278,10 +309,12 @@ class HipHubertModel(_HipModule):
         pooled = torch.empty((nseg, D), dtype=torch.float32, device=self.device) if nseg else None
         nbytes = _lib.lib().mer_hubert_workspace_bytes(self._handle, B, L, int(hidden_states))
         wp, wn = self._workspace(nbytes)
-        _lib.check(_lib.lib().mer_hubert_forward(
+        pb = self.position_bias(T)
+        _lib.check(_lib.lib().mer_hubert_forward_bias(
             self._handle, x.data_ptr(), B, L, wp, wn, hs.data_ptr() if hs is not None else None,
             fr.data_ptr() if fr is not None else None, ss.data_ptr() if nseg else None, sl.data_ptr() if nseg else None, nseg,
-            pooled.data_ptr() if nseg else None, stream()), "mer_hubert_forward")
+            pooled.data_ptr() if nseg else None, pb.data_ptr() if pb is not None else None, pb.shape[2] if pb is not None else 0,
+            stream()), "mer_hubert_forward")
         return hs, fr, pooled
 
     def __call__(self, input_values, attention_mask=None, output_hidden_states=False, **_):
@@ -312,6 +345,9 @@ HipWav2Vec2Model = HipHubertModel
 # data2vec-audio: same conv stack ("layer" norm) and post-LN blocks, a 5-layer positional conv stack instead of one
 # weight-normed conv (handled by pos_layers); the reference treats it like the others (extract_audio_huggingface.py:22-23,93-100)
 HipData2VecAudioModel = HipHubertModel
+# WavLM: HuBERT wiring + a gated relative position bias in every attention (state-dict keys encoder.layers.*.attention.
+# gru_rel_pos_* / rel_attn_embed switch it on); extract_audio_huggingface.py:33-34
+HipWavLMModel = HipHubertModel
 
 
 # =================================================================================================

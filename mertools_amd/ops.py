@@ -127,6 +127,25 @@ def attention(qkv, B, T, H, scale, *, kv_len=None, out_lo=False):
     return oh, ol
 
 
+def attention_bias(qkv, B, T, H, scale, bias, *, gate=None, kv_len=None):
+    """attention() with scores += gate[b,h,q] * bias[h,q,k].  bias: fp32 [H, T, ldb] (ldb % 4 == 0), gate: fp32 [B,H,T] or None."""
+    D = H * 64
+    assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous() and bias.is_contiguous() and bias.shape[:2] == (H, T)
+    oh = torch.empty((B * T, D), dtype=qkv.dtype, device=qkv.device)
+    es = qkv.element_size()
+    _lib.check(_lib.lib().mer_attention_bias(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, 3 * D,
+                                             _p(oh), None, D, B, T, H, float(scale), _p(kv_len), _p(bias), bias.shape[2], _p(gate),
+                                             dt_code(qkv.dtype), stream()), "mer_attention_bias")
+    return oh
+
+
+def wavlm_gate(x, w, b, const, B, T, H):
+    """gate [B,H,T] from the attention input x fp32 [B*T, H*64] (mer_wavlm_gate)."""
+    gate = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mer_wavlm_gate(_p(x), x.stride(0), _p(w), _p(b), _p(const), B, T, H, _p(gate), stream()), "mer_wavlm_gate")
+    return gate
+
+
 def attention_hm(qkv_hm, B, T, H, scale, *, kv_len=None, out_lo=False):
     """qkv_hm: 16-bit [3, B, H, T, 64] (head-major, as written by gemm16(headmajor=(T, H))) -> ctx [B*T, H*64]."""
     D = H * 64

@@ -50,6 +50,13 @@ def data2vec_audio_config(size="base", **over):
     return c
 
 
+def wavlm_config(size="base", **over):
+    """WavLMConfig: HuBERT/wav2vec2 wiring + gated relative position bias (320 buckets, max distance 800) in every layer."""
+    c = hubert_config(size, model_type="wavlm", num_buckets=320, max_bucket_distance=800)
+    vars(c).update(over)
+    return c
+
+
 def hubert_state_dict(cfg, seed=0):
     g = _g(seed)
     sd = {}
@@ -85,6 +92,13 @@ def hubert_state_dict(cfg, seed=0):
         sd[p + "feed_forward.intermediate_dense.weight"], sd[p + "feed_forward.intermediate_dense.bias"] = _lin(g, cfg.intermediate_size, D)
         sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"] = _lin(g, D, cfg.intermediate_size)
         sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = _ln(g, D)
+        if getattr(cfg, "model_type", "hubert") == "wavlm":
+            dh = D // cfg.num_attention_heads
+            sd[p + "attention.gru_rel_pos_const"] = 0.5 + torch.rand(1, cfg.num_attention_heads, 1, 1, generator=g)
+            sd[p + "attention.gru_rel_pos_linear.weight"] = torch.randn(8, dh, generator=g) / math.sqrt(dh)
+            sd[p + "attention.gru_rel_pos_linear.bias"] = torch.randn(8, generator=g) * 0.1
+            if l == 0:
+                sd[p + "attention.rel_attn_embed.weight"] = torch.randn(cfg.num_buckets, cfg.num_attention_heads, generator=g) * 0.5
     return sd
 
 

@@ -33,7 +33,7 @@ def _quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)  # HF QuickGELUActivation
 
 
-def _mhsa(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, key_mask=None):
+def _mhsa(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, key_mask=None, bias=None):
     """softmax((x Wq^T + bq)(x Wk^T + bk)^T / sqrt(d)) (x Wv^T + bv) Wo^T + bo  — HF eager_attention_forward
     (HF:hubert/modeling_hubert.py:236-259; same in clip/roberta).  key_mask: bool [B,T], True = keep."""
     B, T, D = x.shape
@@ -42,6 +42,8 @@ def _mhsa(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, key_mask=None):
     k = F.linear(x, wk, bk).view(B, T, heads, d).transpose(1, 2)
     v = F.linear(x, wv, bv).view(B, T, heads, d).transpose(1, 2)
     s = torch.matmul(q, k.transpose(2, 3)) * (d ** -0.5)
+    if bias is not None:      # additive score bias [B or 1, H, T, T] (WavLM gated relative position bias, BEiT relative position bias)
+        s = s + bias
     if key_mask is not None:
         s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
@@ -64,6 +66,38 @@ def pos_conv_weight(sd):
         g, v = sd[p + "weight_g"], sd[p + "weight_v"]
     norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
     return v * (g / norm)
+
+
+def wavlm_position_bias(rel_attn_embed, T, num_buckets=320, max_distance=800):
+    """WavLMAttention.compute_bias / _relative_positions_bucket (HF:wavlm/modeling_wavlm.py): T5-style bidirectional log
+    buckets of (key - query), embedded per head -> [H, T, T].  Same torch ops in the same order as HF (bucket edges are
+    float-log comparisons)."""
+    import math
+    ctx = torch.arange(T, dtype=torch.long)[:, None]
+    mem = torch.arange(T, dtype=torch.long)[None, :]
+    rel = mem - ctx
+    nb = num_buckets // 2
+    buckets = (rel > 0).to(torch.long) * nb
+    rel = torch.abs(rel)
+    max_exact = nb // 2
+    is_small = rel < max_exact
+    large = torch.log(rel.float() / max_exact)
+    large = large / math.log(max_distance / max_exact)
+    large = large * (nb - max_exact)
+    large = (max_exact + large).to(torch.long)
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    buckets = buckets + torch.where(is_small, rel, large)
+    return F.embedding(buckets, rel_attn_embed).permute(2, 0, 1)
+
+
+def wavlm_gate(x, w, b, const, heads):
+    """gate[b,h,t] of WavLMAttention.forward steps 1-3: 8-way linear on each head's 64-wide slice of the attention input, two
+    groups of four summed, sigmoids, gate_a * (gate_b * const - 1) + 2."""
+    B, T, D = x.shape
+    g = x.view(B, T, heads, D // heads).permute(0, 2, 1, 3)
+    proj = F.linear(g, w, b).view(B, heads, T, 2, 4).sum(-1)
+    ga, gb = torch.sigmoid(proj).chunk(2, dim=-1)
+    return ga * (gb * const - 1.0) + 2.0          # [B, H, T, 1]
 
 
 def hubert_hidden_states(sd, cfg, wav):
@@ -111,14 +145,22 @@ def hubert_hidden_states(sd, cfg, wav):
         x = _ln(x, sd, "encoder.layer_norm", eps)  # HF:...:439-441
     hs = []
     H = cfg["num_attention_heads"]
+    wavlm = cfg.get("model_type") == "wavlm"
+    pos_bias = None
+    if wavlm:  # layer 0 owns the bucket embedding; every layer gates the same table (HF:wavlm/modeling_wavlm.py WavLMEncoder)
+        pos_bias = wavlm_position_bias(sd["encoder.layers.0.attention.rel_attn_embed.weight"], x.shape[1],
+                                       cfg.get("num_buckets", 320), cfg.get("max_bucket_distance", 800))
     for l in range(cfg["num_hidden_layers"]):
         hs.append(x)
         p = f"encoder.layers.{l}."
         a = p + "attention."
 
         def attn(inp):
+            bias = None
+            if wavlm:
+                bias = wavlm_gate(inp, sd[a + "gru_rel_pos_linear.weight"], sd[a + "gru_rel_pos_linear.bias"], sd[a + "gru_rel_pos_const"], H) * pos_bias[None]
             return _mhsa(inp, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"], sd[a + "k_proj.weight"], sd[a + "k_proj.bias"],
-                         sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], H)
+                         sd[a + "v_proj.weight"], sd[a + "v_proj.bias"], sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], H, bias=bias)
 
         def ffn(inp):
             h1 = _gelu(F.linear(inp, sd[p + "feed_forward.intermediate_dense.weight"], sd[p + "feed_forward.intermediate_dense.bias"]))

@@ -317,3 +317,40 @@ def test_data2vec_audio_base_5s(dev):
         print(f"data2vec-audio-base[{prec}]: utt={e:.2e}")
         assert e <= (TOL if prec == "mx" else X3)
         del m
+
+
+# ---- WavLM: gated relative position bias in every attention ----
+@pytest.mark.parametrize("style", ["base", "large"])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL)])
+def test_wavlm_tiny(dev, precision, tol, style):
+    from mertools_amd.encoders import HipWavLMModel
+    over = {} if style == "base" else dict(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
+    cfg = W.wavlm_config("tiny", **over)
+    sd = W.hubert_state_dict(cfg, 2)
+    wav = W.synth_audio(3, 16000)
+    hs = R.hubert_hidden_states(sd, vars(cfg), wav)
+    m = HipWavLMModel(sd, cfg, device=dev, precision=precision)
+    out = m(wav.to(dev), output_hidden_states=True).hidden_states
+    pooled = m.extract_utterance(wav.to(dev))
+    torch.cuda.synchronize()
+    for i, (o, r) in enumerate(zip(out, hs)):
+        assert_close(o.cpu(), r, tol if precision == "accurate" else 2 * tol, f"wavlm-tiny-{style}[{precision}] hidden_states[{i}]")
+    assert_close(pooled.cpu(), torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1), tol, f"wavlm-tiny-{style}[{precision}] UTT feature")
+
+
+def test_wavlm_base_5s(dev):
+    from mertools_amd.encoders import HipWavLMModel
+    from util import rel_err
+    cfg = W.wavlm_config("base")
+    sd = W.hubert_state_dict(cfg, 0)
+    wav = W.synth_audio(2, 80000)
+    hs = R.hubert_hidden_states(sd, vars(cfg), wav)
+    utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
+    for prec in ("mx", "accurate"):
+        m = HipWavLMModel(sd, cfg, device=dev, precision=prec)
+        pooled = m.extract_utterance(wav.to(dev))
+        torch.cuda.synchronize()
+        e = rel_err(pooled.cpu(), utt)[0]
+        print(f"wavlm-base[{prec}]: utt={e:.2e}")
+        assert e <= (TOL if prec == "mx" else X3)
+        del m

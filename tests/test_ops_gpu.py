@@ -363,3 +363,33 @@ def test_gemm16_mx_falls_back_to_two_pass(dev):
         assert torch.equal(c4, c2)
     with pytest.raises(Exception):
         ops.gemm16(a.to(dev), wh.to(dev), out32=True, passes=4)   # neither plane
+
+
+@pytest.mark.parametrize("B,T,H,gated", [(2, 50, 2, True), (3, 197, 3, False), (2, 249, 4, True), (1, 499, 2, True)])
+def test_attention_with_score_bias(dev, B, T, H, gated):
+    """mer_attention_bias: scores += gate[b,h,q] * bias[h,q,k] (WavLM gated relative position bias / BEiT bias)."""
+    ops = _ops()
+    D = H * 64
+    qkv = (_rand((B * T, 3 * D), 51) * 0.5).half()
+    ldb = (T + 3) // 4 * 4
+    bias = torch.zeros(H, T, ldb)
+    bias[:, :, :T] = _rand((H, T, T), 52)
+    gate = (1.0 + _rand((B, H, T), 53).abs()) if gated else None
+    out = ops.attention_bias(qkv.to(dev), B, T, H, 0.125, bias.to(dev), gate=gate.to(dev) if gated else None)
+    torch.cuda.synchronize()
+    q, k, v = [t.double().view(B, T, H, 64).transpose(1, 2) for t in qkv.split(D, dim=1)]
+    s = q @ k.transpose(2, 3) * 0.125 + (gate.double()[..., None] if gated else 1.0) * bias[None, :, :, :T].double()
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    assert_close(out.float().cpu(), ref.float(), 2e-3, "attention with score bias")
+
+
+def test_wavlm_gate(dev):
+    ops = _ops()
+    B, T, H = 2, 37, 3
+    x = _rand((B * T, H * 64), 61)
+    w, b, cst = _rand((8, 64), 62) * 0.2, _rand((8,), 63) * 0.1, 0.5 + _rand((H,), 64).abs()
+    g = ops.wavlm_gate(x.to(dev), w.to(dev), b.to(dev), cst.to(dev), B, T, H)
+    torch.cuda.synchronize()
+    from oracle.encoders_ref import wavlm_gate
+    ref = wavlm_gate(x.view(B, T, H * 64), w, b, cst.view(1, H, 1, 1), H)[..., 0]
+    assert_close(g.cpu(), ref, 1e-5, "wavlm gate")

@@ -161,3 +161,37 @@ def test_data2vec_audio_oracle_matches_hf():
     assert len(hs) == len(ours) == c.num_hidden_layers + 1
     for a, b in zip(ours, hs):
         assert torch.allclose(a, b, rtol=0, atol=2e-5)
+
+
+def test_wavlm_oracle_matches_hf():
+    """WavLM branch (extract_audio_huggingface.py:33-34): gated relative position bias — bucket table, per-layer gate, additive
+    score bias — in both the post-LN (base) and stable-LayerNorm (large) wirings, against the live HF class."""
+    import torch
+    from transformers import WavLMConfig, WavLMModel
+    from mertools_amd import synthetic as W
+    from oracle import encoders_ref as R
+    for over in ({}, dict(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)):
+        c = W.wavlm_config("tiny", **over)
+        sd = W.hubert_state_dict(c, 0)
+        hc = WavLMConfig(hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                         intermediate_size=c.intermediate_size, conv_dim=c.conv_dim, conv_kernel=c.conv_kernel, conv_stride=c.conv_stride,
+                         conv_bias=c.conv_bias, feat_extract_norm=c.feat_extract_norm, do_stable_layer_norm=c.do_stable_layer_norm,
+                         num_conv_pos_embeddings=c.num_conv_pos_embeddings, num_conv_pos_embedding_groups=c.num_conv_pos_embedding_groups,
+                         layer_norm_eps=c.layer_norm_eps, hidden_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0,
+                         mask_time_prob=0.0, num_buckets=320, max_bucket_distance=800)
+        m = WavLMModel(hc).eval()
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected
+        wav = W.synth_audio(2, 16000)
+        with torch.no_grad():
+            hs = m(wav, output_hidden_states=True).hidden_states
+        ours = R.hubert_hidden_states(sd, vars(c), wav)
+        assert len(hs) == len(ours)
+        for a, b in zip(ours, hs):
+            assert torch.allclose(a, b, rtol=0, atol=2e-5)
+    # the bucket table itself, at a length that reaches the logarithmic buckets (|distance| >= 80)
+    emb = torch.randn(320, 4)
+    att = m.encoder.layers[0].attention
+    att.rel_attn_embed.weight.data = emb[:, :att.num_heads].clone()
+    ref = att.compute_bias(499, 499)
+    assert torch.equal(R.wavlm_position_bias(emb[:, :att.num_heads], 499), ref)
