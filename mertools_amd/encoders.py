@@ -536,6 +536,94 @@ class HipDinov2Model(_HipModule):
 
 
 # =================================================================================================
+class HipData2VecVisionModel(HipDinov2Model):
+    """data2vec-vision (BEiT wiring) branch of extract_vision_huggingface.py:123-131: hidden_states[-1] token-summed.
+    HF:data2vec/modeling_data2vec_vision.py.  Same engine variant as DINOv2 (patch bias, no embedding LN, token-sum output);
+    differences handled at load time: optional absolute position table (zeros when the checkpoint has none), key projection
+    without bias, lambda_1 / lambda_2 folded into the output projections, and the relative position bias — the per-layer
+    table and/or the shared one, expanded to [H, T, ceil4(T)] and baked into each layer (`mer_tf_layer.attn_bias`), added to
+    the scores by mer_attention_bias.  Native resolution only (config.image_size)."""
+
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
+        _HipModule.__init__(self)
+        sd = _sd_of(state_dict)
+        self.config = config
+        self.device = torch.device(device)
+        _, tf_passes = _PREC[precision]
+        lo, tmx = tf_passes >= 2, tf_passes == 4
+        hold = self._hold = _Holder(device, dtype)
+        D, Pz, Hn = config.hidden_size, config.patch_size, config.num_attention_heads
+        win = config.image_size // Pz
+        T = win * win + 1
+        cfg = VitConfig()
+        cfg.tf = _tf_config(D, Hn, config.intermediate_size, config.num_hidden_layers, True, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+        cfg.image_size, cfg.patch_size, cfg.channels, cfg.proj_dim, cfg.variant = config.image_size, Pz, config.num_channels, D, 1
+        w = VitWeights()
+        pw = sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
+        pad = (-pw.shape[1]) % 8
+        if pad:
+            pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
+        w.patch_w = hold.w16(pw, lo, tmx)
+        w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
+        w.cls = hold.f32(sd["embeddings.cls_token"].reshape(D))
+        pos = sd.get("embeddings.position_embeddings")
+        w.pos = hold.f32(pos[0] if pos is not None else torch.zeros(T, D))
+        shared = sd.get("encoder.relative_position_bias.relative_position_bias_table")
+        shared = self.relative_position_bias(shared, win) if shared is not None else None
+        ldb = (T + 3) // 4 * 4
+        layers = (TfLayer * config.num_hidden_layers)()
+        shared_ptr = None
+        for l in range(config.num_hidden_layers):
+            q = f"encoder.layer.{l}."
+            a = q + "attention.attention."
+            l1 = sd.get(q + "lambda_1", torch.ones(D))
+            l2 = sd.get(q + "lambda_2", torch.ones(D))
+            layers[l] = _tf_layer(
+                hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], None, sd[a + "value.weight"], sd[a + "value.bias"],
+                sd[q + "attention.output.dense.weight"] * l1[:, None], sd[q + "attention.output.dense.bias"] * l1,
+                (sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"]), sd[q + "intermediate.dense.weight"],
+                sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"] * l2[:, None], sd[q + "output.dense.bias"] * l2,
+                (sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"]), mx=tmx)
+            own = sd.get(a + "relative_position_bias.relative_position_bias_table")
+            bias = self.relative_position_bias(own, win) if own is not None else None
+            if shared is not None:
+                bias = shared if bias is None else bias + shared
+            if bias is not None:
+                if own is None and shared_ptr is not None:
+                    layers[l].attn_bias = shared_ptr        # shared table only: one device copy for all layers
+                else:
+                    padded = torch.zeros(Hn, T, ldb)
+                    padded[:, :, :T] = bias
+                    layers[l].attn_bias = hold.f32(padded)
+                    if own is None:
+                        shared_ptr = layers[l].attn_bias
+        w.layers = C.cast(layers, C.POINTER(TfLayer))
+        self._layers = layers
+        _lib.check(_lib.lib().mer_vit_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_vit_create")
+        self._cfg = cfg
+        self.tokens = T
+
+    @staticmethod
+    def relative_position_bias(table, w):
+        """Data2VecVisionRelativePositionBias at the native window: [(2w-1)^2 + 3, H] -> [H, 1+w*w, 1+w*w]."""
+        nrel = (2 * w - 1) * (2 * w - 1) + 3
+        coords = torch.stack(torch.meshgrid(torch.arange(w), torch.arange(w), indexing="ij")).flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += w - 1
+        rel[:, :, 1] += w - 1
+        rel[:, :, 0] *= 2 * w - 1
+        idx = torch.zeros((w * w + 1,) * 2, dtype=rel.dtype)
+        idx[1:, 1:] = rel.sum(-1)
+        idx[0, 0:] = nrel - 3
+        idx[0:, 0] = nrel - 2
+        idx[0, 0] = nrel - 1
+        return table[idx.view(-1)].view(w * w + 1, w * w + 1, -1).permute(2, 0, 1).contiguous()
+
+
+HipBeitModel = HipData2VecVisionModel   # same module structure and state-dict keys (HF:beit/modeling_beit.py)
+
+
+# =================================================================================================
 def sinusoid_table(n_position, d_hid):
     """VideoMAE's fixed position table (HF:videomae/modeling_videomae.py:80-91), float64 numpy then float32."""
     import numpy as np

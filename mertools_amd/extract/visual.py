@@ -210,3 +210,51 @@ def extract_dinov2(model, face_dir, save_dir, feature_level='UTTERANCE', vids=No
         pending.append((vid, px))
         nframes += len(px)
     flush()
+
+
+# ---- data2vec-vision branch (reference :123-131) ------------------------------------------------------------------
+def data2vec_vision_preprocess(frames_bgr, size=224):
+    """func_opencv_to_image + BeitImageProcessor of facebook/data2vec-vision-base (reference :29-31,125): BGR->RGB, resize to
+    size x size (PIL bicubic, no aspect preservation, no crop), /255, normalise with mean = std = 0.5."""
+    from PIL import Image
+    out = np.empty((len(frames_bgr), 3, size, size), dtype=np.float32)
+    for i, f in enumerate(frames_bgr):
+        img = Image.fromarray(np.ascontiguousarray(f[:, :, ::-1]))
+        if img.size != (size, size):
+            img = img.resize((size, size), resample=Image.BICUBIC)
+        arr = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+        out[i] = (arr - np.float32(0.5)) / np.float32(0.5)
+    return torch.from_numpy(out)
+
+
+def extract_data2vec_vision(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames):
+    """data2vec-vision branch: ALL frames of a video (no resampling) -> token sum of the last hidden state per frame (:130-131)."""
+    os.makedirs(save_dir, exist_ok=True)
+    vids = vids if vids is not None else os.listdir(face_dir)
+    embedding_dim = -1
+    pending, nframes = [], 0
+
+    def flush():
+        nonlocal pending, nframes, embedding_dim
+        if not pending:
+            return
+        feats = model.extract_frames(torch.cat([p for _, p in pending], 0)).cpu().numpy()
+        embedding_dim = max(embedding_dim, feats.shape[-1])
+        r = 0
+        for vid, p in pending:
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), feats[r:r + p.shape[0]], feature_level, embedding_dim)
+            r += p.shape[0]
+        pending, nframes = [], 0
+
+    for vid in vids:
+        frames = reader(face_dir, vid)
+        if len(frames) == 0:
+            flush()
+            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
+            continue
+        px = data2vec_vision_preprocess(frames, model._cfg.image_size)
+        if nframes + len(px) > frames_per_batch:
+            flush()
+        pending.append((vid, px))
+        nframes += len(px)
+    flush()

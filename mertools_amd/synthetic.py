@@ -177,6 +177,55 @@ def dinov2_state_dict(cfg, seed=0):
     return sd
 
 
+def data2vec_vision_config(size="base", **over):
+    """Data2VecVisionConfig (BEiT wiring): no absolute position table, relative position bias per layer and/or shared, layer scale."""
+    base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, image_size=224, patch_size=16,
+                num_channels=3, layer_norm_eps=1e-12, hidden_act="gelu", use_absolute_position_embeddings=False,
+                use_relative_position_bias=False, use_shared_relative_position_bias=True, layer_scale_init_value=0.1,
+                use_mean_pooling=True, use_mask_token=False, model_type="data2vec-vision")
+    if size == "large":
+        base.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    if size == "tiny":
+        base.update(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256, image_size=64)
+    base.update(over)
+    return SimpleNamespace(**base)
+
+
+def data2vec_vision_state_dict(cfg, seed=0):
+    g = _g(seed)
+    D, P, Cn, H = cfg.hidden_size, cfg.patch_size, cfg.num_channels, cfg.num_attention_heads
+    w = cfg.image_size // P
+    nrel = (2 * w - 1) * (2 * w - 1) + 3
+    sd = {"embeddings.cls_token": torch.randn(1, 1, D, generator=g) * 0.5,
+          "embeddings.patch_embeddings.projection.weight": torch.randn(D, Cn, P, P, generator=g) / math.sqrt(Cn * P * P),
+          "embeddings.patch_embeddings.projection.bias": torch.randn(D, generator=g) * 0.05}
+    if cfg.use_absolute_position_embeddings:
+        sd["embeddings.position_embeddings"] = torch.randn(1, w * w + 1, D, generator=g) * 0.3
+    if cfg.use_shared_relative_position_bias:
+        sd["encoder.relative_position_bias.relative_position_bias_table"] = torch.randn(nrel, H, generator=g) * 0.5
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        a = p + "attention.attention."
+        sd[a + "query.weight"], sd[a + "query.bias"] = _lin(g, D, D)
+        sd[a + "key.weight"], _ = _lin(g, D, D)
+        sd[a + "value.weight"], sd[a + "value.bias"] = _lin(g, D, D)
+        if cfg.use_relative_position_bias:
+            sd[a + "relative_position_bias.relative_position_bias_table"] = torch.randn(nrel, H, generator=g) * 0.5
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = _lin(g, D, D)
+        sd[p + "layernorm_before.weight"], sd[p + "layernorm_before.bias"] = _ln(g, D)
+        sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"] = _ln(g, D)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = _lin(g, cfg.intermediate_size, D)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = _lin(g, D, cfg.intermediate_size, std=0.5 / math.sqrt(cfg.intermediate_size))
+        if cfg.layer_scale_init_value > 0:
+            sd[p + "lambda_1"] = 0.5 + torch.rand(D, generator=g)
+            sd[p + "lambda_2"] = 0.5 + torch.rand(D, generator=g)
+    if cfg.use_mean_pooling:
+        sd["pooler.layernorm.weight"], sd["pooler.layernorm.bias"] = _ln(g, D)
+    else:
+        sd["layernorm.weight"], sd["layernorm.bias"] = _ln(g, D)
+    return sd
+
+
 def videomae_config(size="base", **over):
     base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, image_size=224,
                 patch_size=16, num_channels=3, num_frames=16, tubelet_size=2, layer_norm_eps=1e-12, use_mean_pooling=False,

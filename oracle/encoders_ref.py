@@ -275,6 +275,67 @@ def dinov2_frame_features(sd, cfg, pixel_values):
 
 
 # ------------------------------------------------------------------------------------------------
+# data2vec-vision / BEiT  (HF:data2vec/modeling_data2vec_vision.py; reference branch extract_vision_huggingface.py:123-131)
+# ------------------------------------------------------------------------------------------------
+def beit_relative_position_bias(table, window):
+    """Data2VecVisionRelativePositionBias at the native window size: [(2w-1)^2 + 3, H] table -> [H, 1+w*w, 1+w*w] (the three
+    extra rows are cls->token, token->cls, cls->cls)."""
+    w = window
+    nrel = (2 * w - 1) * (2 * w - 1) + 3
+    coords = torch.stack(torch.meshgrid(torch.arange(w), torch.arange(w), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += w - 1
+    rel[:, :, 1] += w - 1
+    rel[:, :, 0] *= 2 * w - 1
+    idx = torch.zeros((w * w + 1,) * 2, dtype=rel.dtype)
+    idx[1:, 1:] = rel.sum(-1)
+    idx[0, 0:] = nrel - 3
+    idx[0:, 0] = nrel - 2
+    idx[0, 0] = nrel - 1
+    return table[idx.view(-1)].view(w * w + 1, w * w + 1, -1).permute(2, 0, 1).contiguous()
+
+
+def data2vec_vision_hidden_states(sd, cfg, pixel_values):
+    """`model(batch, output_hidden_states=True).hidden_states` (extract_vision_huggingface.py:130) at the native resolution:
+    embeddings output + the residual stream after every layer."""
+    eps = cfg.get("layer_norm_eps", 1e-12)
+    P = cfg["patch_size"]
+    x = F.conv2d(pixel_values, sd["embeddings.patch_embeddings.projection.weight"], sd["embeddings.patch_embeddings.projection.bias"], stride=P)
+    N, D = x.shape[0], x.shape[1]
+    w = pixel_values.shape[2] // P
+    x = torch.cat([sd["embeddings.cls_token"].expand(N, 1, D), x.flatten(2).transpose(1, 2)], dim=1)
+    if "embeddings.position_embeddings" in sd:
+        x = x + sd["embeddings.position_embeddings"]
+    H = cfg["num_attention_heads"]
+    shared = sd.get("encoder.relative_position_bias.relative_position_bias_table")
+    shared = beit_relative_position_bias(shared, w) if shared is not None else None
+    hs = [x]
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{l}."
+        a = p + "attention.attention."
+        bias = None
+        own = sd.get(a + "relative_position_bias.relative_position_bias_table")
+        if own is not None:
+            bias = beit_relative_position_bias(own, w)[None]
+        if shared is not None:
+            bias = shared[None] if bias is None else bias + shared[None]
+        h = _ln(x, sd, p + "layernorm_before", eps)
+        att = _mhsa(h, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], None, sd[a + "value.weight"], sd[a + "value.bias"],
+                    sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"], H, bias=bias)
+        x = x + (att * sd[p + "lambda_1"] if p + "lambda_1" in sd else att)
+        h = F.linear(_gelu(F.linear(_ln(x, sd, p + "layernorm_after", eps), sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"])),
+                     sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        x = x + (h * sd[p + "lambda_2"] if p + "lambda_2" in sd else h)
+        hs.append(x)
+    return hs
+
+
+def data2vec_vision_frame_features(sd, cfg, pixel_values):
+    """`torch.stack(hidden_states)[-1].sum(dim=1)` (extract_vision_huggingface.py:131) -> [N, D]."""
+    return data2vec_vision_hidden_states(sd, cfg, pixel_values)[-1].sum(dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
 # VideoMAE  (HF:videomae/modeling_videomae.py)
 # ------------------------------------------------------------------------------------------------
 def videomae_sinusoid(n_position, d_hid):

@@ -120,3 +120,87 @@ def test_dinov2_extract_files(dev, tmp_path):
         assert f.shape == (8, c.hidden_size) and u.shape == (c.hidden_size,) and f.dtype == np.float32
         assert np.abs(f - ref).max() / np.abs(ref).max() < 1e-3
         assert np.abs(u - ref.mean(0)).max() / np.abs(ref.mean(0)).max() < 1e-3
+
+
+# ---- data2vec-vision / BEiT (extract_vision_huggingface.py:123-131) on the same engine variant ----
+def test_oracle_matches_hf_data2vec_vision():
+    from transformers import Data2VecVisionConfig, Data2VecVisionModel
+    for over in (dict(), dict(use_relative_position_bias=True, use_shared_relative_position_bias=False),
+                 dict(use_relative_position_bias=True, use_absolute_position_embeddings=True, layer_scale_init_value=0.0)):
+        c = W.data2vec_vision_config("tiny", **over)
+        sd = {k: v for k, v in W.data2vec_vision_state_dict(c, 0).items() if not k.startswith("pooler.")}
+        hc = Data2VecVisionConfig(hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                                  intermediate_size=c.intermediate_size, image_size=c.image_size, patch_size=c.patch_size,
+                                  layer_norm_eps=c.layer_norm_eps, use_absolute_position_embeddings=c.use_absolute_position_embeddings,
+                                  use_relative_position_bias=c.use_relative_position_bias,
+                                  use_shared_relative_position_bias=c.use_shared_relative_position_bias,
+                                  layer_scale_init_value=c.layer_scale_init_value, use_mean_pooling=True, use_mask_token=False,
+                                  drop_path_rate=0.0, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
+        m = Data2VecVisionModel(hc).eval()
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not [k for k in missing if not k.startswith("pooler.")] and not unexpected
+        px = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+        with torch.no_grad():
+            hs = m(px, output_hidden_states=True).hidden_states
+        ours = R.data2vec_vision_hidden_states(sd, vars(c), px)
+        assert len(hs) == len(ours)
+        for a, b in zip(ours, hs):
+            assert torch.allclose(a, b, rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("over", [dict(), dict(use_relative_position_bias=True, use_shared_relative_position_bias=False),
+                                  dict(use_relative_position_bias=True, use_absolute_position_embeddings=True, layer_scale_init_value=0.0)],
+                         ids=["shared-bias", "per-layer-bias", "both-abs-pos-no-scale"])
+def test_data2vec_vision_tiny(dev, over):
+    from mertools_amd.encoders import HipData2VecVisionModel
+    from util import assert_close
+    c = W.data2vec_vision_config("tiny", **over)
+    sd = W.data2vec_vision_state_dict(c, 0)
+    px = torch.randn(5, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    hs = R.data2vec_vision_hidden_states(sd, vars(c), px)
+    ref = hs[-1].sum(dim=1)
+    for prec, tol in (("accurate", 5e-4), ("mx", 1e-3)):   # "accurate" is bounded by attention rounding q/k/v/P to f16 once
+        m = HipData2VecVisionModel(sd, c, device=dev, precision=prec)
+        out = m(px.to(dev), output_hidden_states=True).hidden_states
+        feats = m.extract_frames(px.to(dev))
+        torch.cuda.synchronize()
+        assert_close(torch.stack(out)[-1].cpu(), hs[-1], tol, f"data2vec-vision-tiny[{prec}] last hidden state")
+        assert_close(feats.cpu(), ref, tol, f"data2vec-vision-tiny[{prec}] token-sum features")
+        del m
+
+
+@pytest.mark.gpu
+def test_data2vec_vision_base_224(dev):
+    """data2vec-vision-base architecture (768/12/12, patch 16, 197 tokens, shared relative position bias), half depth."""
+    from mertools_amd.encoders import HipData2VecVisionModel
+    from util import rel_err
+    c = W.data2vec_vision_config("base", num_hidden_layers=6)
+    sd = W.data2vec_vision_state_dict(c, 0)
+    px = W.synth_frames(6)
+    ref = R.data2vec_vision_frame_features(sd, vars(c), px)
+    for prec in ("mx", "accurate"):
+        m = HipData2VecVisionModel(sd, c, device=dev, precision=prec)
+        out = m.extract_frames(px.to(dev))
+        utt = m.extract_utterance(px.to(dev), [6])
+        torch.cuda.synchronize()
+        e, eu = rel_err(out.cpu(), ref)[0], rel_err(utt.cpu(), ref.mean(0, keepdim=True))[0]
+        print(f"data2vec-vision-base(6 layers)[{prec}]: frames={e:.2e} utt={eu:.2e}")
+        assert eu <= 1e-3 and e <= (1e-3 if prec == "accurate" else 2e-3)
+        del m
+
+
+def test_data2vec_vision_preprocess_matches_hf_processor():
+    """BeitImageProcessor as configured by facebook/data2vec-vision-base: square bicubic resize, no crop, mean = std = 0.5."""
+    from PIL import Image
+    from mertools_amd.extract.visual import data2vec_vision_preprocess
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from transformers import BeitImageProcessor
+        proc = BeitImageProcessor(do_resize=True, size={"height": 224, "width": 224}, resample=3, do_center_crop=False, do_normalize=True,
+                                  image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+    rng = np.random.default_rng(0)
+    for (h, w) in [(200, 260), (224, 224), (97, 131)]:
+        fr = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        ref = proc(images=[Image.fromarray(f[:, :, ::-1].copy()) for f in fr], return_tensors="pt")["pixel_values"]
+        assert torch.allclose(data2vec_vision_preprocess(fr), ref, rtol=0, atol=2e-6)
