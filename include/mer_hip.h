@@ -35,7 +35,8 @@ typedef void* mer_stream_t; /* hipStream_t */
 
 enum { MER_OK = 0, MER_EINVAL = -1, MER_ESHAPE = -2, MER_ELAUNCH = -3, MER_ENOMEM = -4, MER_EUNSUPPORTED = -5 };
 enum { MER_DT_F16 = 0, MER_DT_BF16 = 1 };
-enum { MER_ACT_NONE = 0, MER_ACT_GELU = 1, MER_ACT_QUICK_GELU = 2, MER_ACT_RELU = 3 };
+enum { MER_ACT_NONE = 0, MER_ACT_GELU = 1, MER_ACT_QUICK_GELU = 2, MER_ACT_RELU = 3,
+       MER_ACT_GELU_TANH = 4 /* HF "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) — ALBERT */ };
 
 const char* mer_version(void);
 const char* mer_last_error(void);
@@ -402,11 +403,15 @@ typedef struct {
   mer_tf_config tf;
   int vocab, max_pos, type_vocab, pad_id, pos_mode;
   float emb_ln_eps;
+  int emb_dim;   /* 0 or == tf.hidden: embeddings are hidden-sized (BERT, RoBERTa).  Otherwise the embedding tables and their
+                  * LayerNorm are emb_dim wide and emb_proj maps them to tf.hidden before the first block: ELECTRA-small's
+                  * `embeddings_project`, ALBERT's `embedding_hidden_mapping_in`; hidden_states[0] is the projected tensor. */
 } mer_bert_config;
 typedef struct {
   const float* word; const float* pos; const float* type;
   const float* emb_ln_g; const float* emb_ln_b;
-  const mer_tf_layer* layers;
+  const mer_tf_layer* layers;              /* ALBERT: every entry points at the one shared block */
+  mer_w16 emb_proj_w; const float* emb_proj_b;   /* [hidden, emb_dim], [hidden] when emb_dim != hidden */
 } mer_bert_weights;
 typedef struct mer_bert mer_bert;
 int mer_bert_create(const mer_bert_config* cfg, const mer_bert_weights* w, mer_bert** out);

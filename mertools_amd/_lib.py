@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmer_hip.so")
 
 MER_OK = 0
 MER_DT_F16, MER_DT_BF16 = 0, 1
-MER_ACT_NONE, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_ACT_RELU = 0, 1, 2, 3
+MER_ACT_NONE, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_ACT_RELU, MER_ACT_GELU_TANH = 0, 1, 2, 3, 4
 MER_MAX_CONV = 8
 MER_MAX_POS = 8
 
@@ -100,12 +100,12 @@ class VideoMAEWeights(C.Structure):
 
 class BertConfig(C.Structure):
     _fields_ = [("tf", TfConfig), ("vocab", c_int), ("max_pos", c_int), ("type_vocab", c_int), ("pad_id", c_int),
-                ("pos_mode", c_int), ("emb_ln_eps", c_float)]
+                ("pos_mode", c_int), ("emb_ln_eps", c_float), ("emb_dim", c_int)]
 
 
 class BertWeights(C.Structure):
     _fields_ = [("word", c_void_p), ("pos", c_void_p), ("type", c_void_p), ("emb_ln_g", c_void_p), ("emb_ln_b", c_void_p),
-                ("layers", C.POINTER(TfLayer))]
+                ("layers", C.POINTER(TfLayer)), ("emb_proj_w", W16), ("emb_proj_b", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/mer_hip.h declares must appear here.

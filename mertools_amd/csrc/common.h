@@ -69,6 +69,10 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     case MER_ACT_GELU: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
     case MER_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     case MER_ACT_RELU: return x > 0.f ? x : 0.f;
+    case MER_ACT_GELU_TANH: {   // tanh(u) = 1 - 2 / (exp(2u) + 1); exp overflow -> inf -> tanh = 1, underflow -> -1
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      return 0.5f * x * (2.0f - 2.0f / (__expf(2.0f * u) + 1.0f));
+    }
     default: return x;
   }
 }

@@ -572,6 +572,9 @@ extern "C" int mer_bert_create(const mer_bert_config* cfg, const mer_bert_weight
   MER_TRY(check_tf(cfg->tf, "mer_bert_create"));
   MER_REQUIRE(cfg->tf.pre_ln == 0, MER_EUNSUPPORTED, "mer_bert_create: BERT blocks are post-LN");
   MER_REQUIRE(w->layers && w->word && w->pos, MER_EINVAL, "mer_bert_create: missing weights");
+  if (cfg->emb_dim > 0 && cfg->emb_dim != cfg->tf.hidden)
+    MER_REQUIRE(cfg->emb_dim % 8 == 0 && w->emb_proj_w.hi && w->emb_proj_b, MER_EINVAL,
+                "mer_bert_create: emb_dim=%d needs emb_proj_w / emb_proj_b (and emb_dim %% 8 == 0)", cfg->emb_dim);
   mer_bert* h = new mer_bert();
   h->cfg = *cfg;
   h->w = *w;
@@ -584,11 +587,14 @@ extern "C" void mer_bert_destroy(mer_bert* h) { delete h; }
 
 struct BertPlan {
   float* ring;
+  P16 emb16;   // emb_dim != hidden: the LayerNorm-ed embeddings awaiting their projection
   TfBufs tf;
 };
 static long long bert_plan(const mer_bert* h, Arena& ar, int B, int T, bool want_hs, BertPlan& p) {
   const long long M = (long long)B * T, D = h->cfg.tf.hidden;
+  const int E = h->cfg.emb_dim;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
+  p.emb16 = (E > 0 && E != D) ? take16(ar, M * E, h->cfg.tf.passes == 3) : P16{nullptr, nullptr};
   tf_plan(ar, h->cfg.tf, M, p.tf);
   return ar.off;
 }
@@ -619,6 +625,12 @@ extern "C" int mer_bert_forward(const mer_bert* h, const int64_t* ids, const int
   HsMap hs;
   hs.stride = M * D;
   if (hidden_states) { hs.base = hidden_states; hs.ring = 0; } else { hs.base = p.ring; hs.ring = 5; }
+  if (c.emb_dim > 0 && c.emb_dim != D) {   // factorised embeddings: E-wide tables + LayerNorm, then Linear(E -> D) = hidden_states[0]
+    MER_TRY(mer_bert_embed(ids, token_type, B, T, c.emb_dim, w.word, w.pos, w.type, c.pos_mode, c.pad_id, w.emb_ln_g, w.emb_ln_b,
+                           c.emb_ln_eps, nullptr, p.emb16.hi, p.emb16.lo, dt, st));
+    MER_TRY(gemm(st, dt, c.tf.passes, (int)M, D, c.emb_dim, p.emb16, c.emb_dim, w.emb_proj_w, w.emb_proj_b, MER_ACT_NONE, nullptr, 0,
+                 hs.at(0), D, p.tf.cur16, D));
+  } else
   MER_TRY(mer_bert_embed(ids, token_type, B, T, D, w.word, w.pos, w.type, c.pos_mode, c.pad_id, w.emb_ln_g, w.emb_ln_b,
                          c.emb_ln_eps, hs.at(0), p.tf.cur16.hi, p.tf.cur16.lo, dt, st));
   MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, T, hs, p.tf, lengths));

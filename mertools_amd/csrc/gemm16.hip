@@ -597,6 +597,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     case MER_ACT_GELU: epilogue(std::integral_constant<int, MER_ACT_GELU>{}); break;
     case MER_ACT_QUICK_GELU: epilogue(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
     case MER_ACT_RELU: epilogue(std::integral_constant<int, MER_ACT_RELU>{}); break;
+    case MER_ACT_GELU_TANH: epilogue(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
     default: epilogue(std::integral_constant<int, MER_ACT_NONE>{}); break;
   }
   if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();

@@ -31,7 +31,7 @@ import torch
 
 from . import _lib
 from .ops import torch16
-from ._lib import (BertConfig, BertWeights, HubertConfig, HubertWeights, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_MAX_CONV,
+from ._lib import (BertConfig, BertWeights, HubertConfig, HubertWeights, MER_ACT_GELU, MER_ACT_GELU_TANH, MER_ACT_QUICK_GELU, MER_MAX_CONV,
                    TfConfig, TfLayer, VideoMAEConfig, VideoMAEWeights, VitConfig, VitWeights, W16)
 from .ops import dt_code, split16_host, stream
 
@@ -718,7 +718,10 @@ class HipVideoMAEModel(_HipModule):
 
 # =================================================================================================
 class HipBertModel(_HipModule):
-    """BERT / RoBERTa family (post-LN encoder-only text models)."""
+    """BERT / RoBERTa family (post-LN encoder-only text models): BERT, RoBERTa, MacBERT / PERT / LERT / Chinese-RoBERTa-wwm
+    (BERT keys), ELECTRA (+ `embeddings_project` for electra-small) and ALBERT (factorised embeddings, one block shared by
+    all layers, gelu_new) — the encoder-only entries of extract_text_huggingface.py:20-58 with standard attention.
+    Not covered: DeBERTa (disentangled attention), XLNet / T5 / MPNet (relative attention), the decoder-only LLMs."""
     _destroy = "mer_bert_destroy"
 
     def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
@@ -729,12 +732,14 @@ class HipBertModel(_HipModule):
         _, tf_passes = _PREC[precision]
         lo, tmx = tf_passes >= 2, tf_passes == 4
         hold = self._hold = _Holder(device, dtype)
-        if config.hidden_act != "gelu":
+        acts = {"gelu": MER_ACT_GELU, "gelu_new": MER_ACT_GELU_TANH}
+        if config.hidden_act not in acts:
             raise _lib.MerError(f"hidden_act={config.hidden_act} unsupported")
         roberta = config.model_type in ("roberta", "xlm-roberta")
+        albert = "encoder.embedding_hidden_mapping_in.weight" in sd        # ALBERT: factorised embeddings + ONE shared block
         cfg = BertConfig()
         cfg.tf = _tf_config(config.hidden_size, config.num_attention_heads, config.intermediate_size, config.num_hidden_layers,
-                            False, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+                            False, acts[config.hidden_act], config.layer_norm_eps, dtype, tf_passes)
         cfg.vocab, cfg.max_pos, cfg.type_vocab = config.vocab_size, config.max_position_embeddings, config.type_vocab_size
         cfg.pad_id = config.pad_token_id if config.pad_token_id is not None else 0
         cfg.pos_mode = 1 if roberta else 0
@@ -744,17 +749,38 @@ class HipBertModel(_HipModule):
         w.pos = hold.f32(sd["embeddings.position_embeddings.weight"])
         w.type = hold.f32(sd["embeddings.token_type_embeddings.weight"])
         w.emb_ln_g, w.emb_ln_b = hold.f32(sd["embeddings.LayerNorm.weight"]), hold.f32(sd["embeddings.LayerNorm.bias"])
+        # factorised embeddings: ELECTRA `embeddings_project` (electra-small), ALBERT `encoder.embedding_hidden_mapping_in`
+        proj = "encoder.embedding_hidden_mapping_in." if albert else "embeddings_project."
+        cfg.emb_dim = sd["embeddings.word_embeddings.weight"].shape[1]
+        if proj + "weight" in sd:
+            w.emb_proj_w = hold.w16(sd[proj + "weight"], lo, tmx)
+            w.emb_proj_b = hold.f32(sd[proj + "bias"])
+        elif cfg.emb_dim != config.hidden_size:
+            raise _lib.MerError("embedding size differs from the hidden size but the checkpoint has no embedding projection")
         layers = (TfLayer * config.num_hidden_layers)()
-        for l in range(config.num_hidden_layers):
-            q = f"encoder.layer.{l}."
-            a = q + "attention.self."
-            layers[l] = _tf_layer(
-                hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"],
-                sd[a + "value.weight"], sd[a + "value.bias"], sd[q + "attention.output.dense.weight"],
-                sd[q + "attention.output.dense.bias"],
-                (sd[q + "attention.output.LayerNorm.weight"], sd[q + "attention.output.LayerNorm.bias"]),
-                sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"],
-                sd[q + "output.dense.bias"], (sd[q + "output.LayerNorm.weight"], sd[q + "output.LayerNorm.bias"]), mx=tmx)
+        if albert:
+            if getattr(config, "num_hidden_groups", 1) != 1 or getattr(config, "inner_group_num", 1) != 1:
+                raise _lib.MerError("ALBERT with more than one layer group / inner group is not supported")
+            q = "encoder.albert_layer_groups.0.albert_layers.0."
+            a = q + "attention."
+            shared = _tf_layer(
+                hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"], sd[a + "value.weight"],
+                sd[a + "value.bias"], sd[a + "dense.weight"], sd[a + "dense.bias"], (sd[a + "LayerNorm.weight"], sd[a + "LayerNorm.bias"]),
+                sd[q + "ffn.weight"], sd[q + "ffn.bias"], sd[q + "ffn_output.weight"], sd[q + "ffn_output.bias"],
+                (sd[q + "full_layer_layer_norm.weight"], sd[q + "full_layer_layer_norm.bias"]), mx=tmx)
+            for l in range(config.num_hidden_layers):
+                layers[l] = shared
+        else:
+            for l in range(config.num_hidden_layers):
+                q = f"encoder.layer.{l}."
+                a = q + "attention.self."
+                layers[l] = _tf_layer(
+                    hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"],
+                    sd[a + "value.weight"], sd[a + "value.bias"], sd[q + "attention.output.dense.weight"],
+                    sd[q + "attention.output.dense.bias"],
+                    (sd[q + "attention.output.LayerNorm.weight"], sd[q + "attention.output.LayerNorm.bias"]),
+                    sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"], sd[q + "output.dense.weight"],
+                    sd[q + "output.dense.bias"], (sd[q + "output.LayerNorm.weight"], sd[q + "output.LayerNorm.bias"]), mx=tmx)
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers
         _lib.check(_lib.lib().mer_bert_create(C.byref(cfg), C.byref(w), C.byref(self._handle)), "mer_bert_create")

@@ -7,9 +7,10 @@ encoders; they validate devices/dtypes and otherwise pass raw pointers through.
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, MER_DT_F16, MER_DT_BF16, MER_ACT_NONE, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_ACT_RELU  # noqa: F401
+from ._lib import GemmArgs, MER_DT_F16, MER_DT_BF16, MER_ACT_NONE, MER_ACT_GELU, MER_ACT_QUICK_GELU, MER_ACT_RELU, MER_ACT_GELU_TANH  # noqa: F401
 
-ACT = {None: MER_ACT_NONE, "none": MER_ACT_NONE, "gelu": MER_ACT_GELU, "quick_gelu": MER_ACT_QUICK_GELU, "relu": MER_ACT_RELU}
+ACT = {None: MER_ACT_NONE, "none": MER_ACT_NONE, "gelu": MER_ACT_GELU, "quick_gelu": MER_ACT_QUICK_GELU, "relu": MER_ACT_RELU,
+       "gelu_new": MER_ACT_GELU_TANH, "gelu_tanh": MER_ACT_GELU_TANH}
 _TORCH16 = {MER_DT_F16: torch.float16, MER_DT_BF16: torch.bfloat16}
 _DT = {"f16": MER_DT_F16, "bf16": MER_DT_BF16, MER_DT_F16: MER_DT_F16, MER_DT_BF16: MER_DT_BF16,
        torch.float16: MER_DT_F16, torch.bfloat16: MER_DT_BF16}

@@ -279,13 +279,56 @@ def bert_config(size="roberta-base", **over):
     return SimpleNamespace(**base)
 
 
+def electra_config(size="tiny", **over):
+    """ElectraConfig: BERT blocks; embedding_size != hidden_size (electra-small: 128 -> 256) adds `embeddings_project`."""
+    c = bert_config("bert-base", model_type="electra", embedding_size=128, hidden_size=256, num_hidden_layers=12, num_attention_heads=4,
+                    intermediate_size=1024, vocab_size=21128)
+    if size == "tiny":
+        vars(c).update(embedding_size=64, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, vocab_size=300,
+                       max_position_embeddings=70)
+    vars(c).update(over)
+    return c
+
+
+def albert_config(size="tiny", **over):
+    """AlbertConfig: 128-wide embeddings mapped to the hidden size, ONE block shared by all layers, gelu_new."""
+    c = bert_config("bert-base", model_type="albert", embedding_size=128, hidden_act="gelu_new", vocab_size=30000, type_vocab_size=2,
+                    num_hidden_groups=1, inner_group_num=1)
+    if size == "tiny":
+        vars(c).update(embedding_size=64, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256, vocab_size=300,
+                       max_position_embeddings=70)
+    vars(c).update(over)
+    return c
+
+
+def albert_state_dict(cfg, seed=0):
+    g = _g(seed)
+    D, E = cfg.hidden_size, cfg.embedding_size
+    sd = {"embeddings.word_embeddings.weight": torch.randn(cfg.vocab_size, E, generator=g) * 0.5,
+          "embeddings.position_embeddings.weight": torch.randn(cfg.max_position_embeddings, E, generator=g) * 0.3,
+          "embeddings.token_type_embeddings.weight": torch.randn(cfg.type_vocab_size, E, generator=g) * 0.3}
+    sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"] = _ln(g, E)
+    sd["encoder.embedding_hidden_mapping_in.weight"], sd["encoder.embedding_hidden_mapping_in.bias"] = _lin(g, D, E)
+    p = "encoder.albert_layer_groups.0.albert_layers.0."
+    for nme in ("query", "key", "value", "dense"):
+        sd[p + f"attention.{nme}.weight"], sd[p + f"attention.{nme}.bias"] = _lin(g, D, D)
+    sd[p + "attention.LayerNorm.weight"], sd[p + "attention.LayerNorm.bias"] = _ln(g, D)
+    sd[p + "ffn.weight"], sd[p + "ffn.bias"] = _lin(g, cfg.intermediate_size, D)
+    sd[p + "ffn_output.weight"], sd[p + "ffn_output.bias"] = _lin(g, D, cfg.intermediate_size)
+    sd[p + "full_layer_layer_norm.weight"], sd[p + "full_layer_layer_norm.bias"] = _ln(g, D)
+    return sd
+
+
 def bert_state_dict(cfg, seed=0):
     g = _g(seed)
     D = cfg.hidden_size
-    sd = {"embeddings.word_embeddings.weight": torch.randn(cfg.vocab_size, D, generator=g) * 0.5,
-          "embeddings.position_embeddings.weight": torch.randn(cfg.max_position_embeddings, D, generator=g) * 0.3,
-          "embeddings.token_type_embeddings.weight": torch.randn(cfg.type_vocab_size, D, generator=g) * 0.3}
-    sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"] = _ln(g, D)
+    E = getattr(cfg, "embedding_size", D)     # ELECTRA: embedding_size may differ from hidden_size
+    sd = {"embeddings.word_embeddings.weight": torch.randn(cfg.vocab_size, E, generator=g) * 0.5,
+          "embeddings.position_embeddings.weight": torch.randn(cfg.max_position_embeddings, E, generator=g) * 0.3,
+          "embeddings.token_type_embeddings.weight": torch.randn(cfg.type_vocab_size, E, generator=g) * 0.3}
+    sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"] = _ln(g, E)
+    if E != D:
+        sd["embeddings_project.weight"], sd["embeddings_project.bias"] = _lin(g, D, E)
     for l in range(cfg.num_hidden_layers):
         p = f"encoder.layer.{l}."
         for nme in ("query", "key", "value"):

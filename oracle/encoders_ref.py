@@ -29,6 +29,12 @@ def _gelu(x):
     return F.gelu(x)  # exact erf form (HF ACT2FN["gelu"])
 
 
+def _gelu_new(x):
+    """HF ACT2FN["gelu_new"] (NewGELUActivation): the tanh approximation."""
+    import math
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
 def _quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)  # HF QuickGELUActivation
 
@@ -389,6 +395,24 @@ def bert_hidden_states(sd, cfg, input_ids, attention_mask=None, token_type_ids=N
     x = _ln(x, sd, "embeddings.LayerNorm", eps)
     key_mask = attention_mask.bool() if attention_mask is not None else None
     H = cfg["num_attention_heads"]
+    act = _gelu_new if cfg.get("hidden_act", "gelu") == "gelu_new" else _gelu
+    if "encoder.embedding_hidden_mapping_in.weight" in sd:
+        # ALBERT (HF:albert/modeling_albert.py): factorised embeddings, then ONE block applied num_hidden_layers times;
+        # hidden_states[0] is the projected embedding
+        x = F.linear(x, sd["encoder.embedding_hidden_mapping_in.weight"], sd["encoder.embedding_hidden_mapping_in.bias"])
+        hs = [x]
+        p = "encoder.albert_layer_groups.0.albert_layers.0."
+        a = p + "attention."
+        for _ in range(cfg["num_hidden_layers"]):
+            att = _mhsa(x, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"], sd[a + "value.weight"],
+                        sd[a + "value.bias"], sd[a + "dense.weight"], sd[a + "dense.bias"], H, key_mask)
+            x = _ln(x + att, sd, a + "LayerNorm", eps)
+            h = act(F.linear(x, sd[p + "ffn.weight"], sd[p + "ffn.bias"]))
+            x = _ln(x + F.linear(h, sd[p + "ffn_output.weight"], sd[p + "ffn_output.bias"]), sd, p + "full_layer_layer_norm", eps)
+            hs.append(x)
+        return hs
+    if "embeddings_project.weight" in sd:  # ELECTRA with embedding_size != hidden_size (HF:electra/modeling_electra.py ElectraModel.forward)
+        x = F.linear(x, sd["embeddings_project.weight"], sd["embeddings_project.bias"])
     hs = [x]
     for l in range(cfg["num_hidden_layers"]):  # HF:roberta/modeling_roberta.py:186-464 (post-LN)
         p = f"encoder.layer.{l}."
@@ -397,7 +421,7 @@ def bert_hidden_states(sd, cfg, input_ids, attention_mask=None, token_type_ids=N
                     sd[a + "value.weight"], sd[a + "value.bias"], sd[p + "attention.output.dense.weight"],
                     sd[p + "attention.output.dense.bias"], H, key_mask)
         x = _ln(x + att, sd, p + "attention.output.LayerNorm", eps)
-        h = _gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        h = act(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
         x = _ln(x + F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]), sd, p + "output.LayerNorm", eps)
         hs.append(x)
     return hs

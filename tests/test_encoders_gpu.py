@@ -354,3 +354,26 @@ def test_wavlm_base_5s(dev):
         print(f"wavlm-base[{prec}]: utt={e:.2e}")
         assert e <= (TOL if prec == "mx" else X3)
         del m
+
+
+# ---- ELECTRA (embedding projection) and ALBERT (shared block, gelu_new) on the BERT engine ----
+@pytest.mark.parametrize("kind", ["electra", "albert"])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL)])
+def test_electra_albert_tiny(dev, precision, tol, kind):
+    from mertools_amd.encoders import HipBertModel
+    if kind == "electra":
+        cfg = W.electra_config("tiny")
+        sd = W.bert_state_dict(cfg, 5)
+    else:
+        cfg = W.albert_config("tiny")
+        sd = W.albert_state_dict(cfg, 5)
+    ids = W.synth_tokens(4, 24) % cfg.vocab_size
+    ref = R.bert_hidden_states(sd, vars(cfg), ids, torch.ones_like(ids))
+    m = HipBertModel(sd, cfg, device=dev, precision=precision)
+    out = m(input_ids=ids.to(dev), attention_mask=torch.ones_like(ids).to(dev), output_hidden_states=True).hidden_states
+    pooled = m.extract_utterance(ids.to(dev), [24] * 4, 1, -1)
+    torch.cuda.synchronize()
+    assert len(out) == len(ref)
+    for i, (o, r) in enumerate(zip(out, ref)):
+        assert_close(o.cpu(), r, tol if precision == "accurate" else 2 * tol, f"{kind}-tiny[{precision}] hs[{i}]")
+    assert_close(pooled.cpu(), torch.stack(ref)[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1), tol, f"{kind}-tiny[{precision}] UTT feature")

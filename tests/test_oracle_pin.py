@@ -195,3 +195,39 @@ def test_wavlm_oracle_matches_hf():
     att.rel_attn_embed.weight.data = emb[:, :att.num_heads].clone()
     ref = att.compute_bias(499, 499)
     assert torch.equal(R.wavlm_position_bias(emb[:, :att.num_heads], 499), ref)
+
+
+def test_electra_and_albert_oracle_match_hf():
+    """ELECTRA with embedding_size != hidden_size (`embeddings_project`) and ALBERT (factorised embeddings, one shared block,
+    gelu_new) — extract_text_huggingface.py:22-28,46-48 — against the live HF classes."""
+    import torch
+    from transformers import AlbertConfig, AlbertModel, ElectraConfig, ElectraModel
+    from mertools_amd import synthetic as W
+    from oracle import encoders_ref as R
+    common = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, pad_token_id=0, attn_implementation="eager")
+    c = W.electra_config("tiny")
+    sd = W.bert_state_dict(c, 0)
+    m = ElectraModel(ElectraConfig(vocab_size=c.vocab_size, embedding_size=c.embedding_size, hidden_size=c.hidden_size,
+                                   num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                                   intermediate_size=c.intermediate_size, max_position_embeddings=c.max_position_embeddings,
+                                   type_vocab_size=c.type_vocab_size, layer_norm_eps=c.layer_norm_eps, **common)).eval()
+    m.load_state_dict(sd, strict=True)
+    ids = W.synth_tokens(3, 20) % c.vocab_size
+    with torch.no_grad():
+        hs = m(ids, attention_mask=torch.ones_like(ids), output_hidden_states=True).hidden_states
+    for a, b in zip(R.bert_hidden_states(sd, vars(c), ids, torch.ones_like(ids)), hs):
+        assert torch.allclose(a, b, rtol=0, atol=1e-5)
+    c = W.albert_config("tiny")
+    sd = W.albert_state_dict(c, 0)
+    m = AlbertModel(AlbertConfig(vocab_size=c.vocab_size, embedding_size=c.embedding_size, hidden_size=c.hidden_size,
+                                 num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                                 intermediate_size=c.intermediate_size, max_position_embeddings=c.max_position_embeddings,
+                                 type_vocab_size=c.type_vocab_size, layer_norm_eps=c.layer_norm_eps, hidden_act="gelu_new", **common),
+                    add_pooling_layer=False).eval()
+    m.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        hs = m(ids, attention_mask=torch.ones_like(ids), output_hidden_states=True).hidden_states
+    ours = R.bert_hidden_states(sd, vars(c), ids, torch.ones_like(ids))
+    assert len(ours) == len(hs) == c.num_hidden_layers + 1
+    for a, b in zip(ours, hs):
+        assert torch.allclose(a, b, rtol=0, atol=1e-5)
