@@ -368,6 +368,17 @@ int mer_attention_bias(const void* q, const void* k, const void* v, long long ld
 int mer_wavlm_gate(const float* x, long long ldx, const float* w, const float* b, const float* cst, int B, int T, int H,
                    float* gate, mer_stream_t stream);
 
+/* ---- host pre-processing on the GPU (what the reference does on the CPU before the H2D copy) ----
+ * mer_wave_normalize: Wav2Vec2FeatureExtractor's per-utterance (x - mean) / sqrt(var + 1e-7) (do_normalize != 0) or a plain
+ * conversion, from device int16 PCM (x = pcm / 32768, is_int16 != 0) or device fp32; one row per utterance / chunk.
+ * mer_image_normalize_u8: device uint8 frames [N,H,W,3] (bgr != 0: OpenCV channel order) -> fp32 [N,3,H,W] RGB,
+ * (v / 255 - mean[c]) / std[c]; mean3 / std3 are HOST arrays of three floats (RGB order).  Frames must already have the
+ * model's resolution (the resize of CLIPImageProcessor stays on the host: PIL's fixed-point bicubic is not reproduced). */
+int mer_wave_normalize(const void* x, int is_int16, long long ldx, int B, int L, int do_normalize, float* out,
+                       long long ldo, mer_stream_t stream);
+int mer_image_normalize_u8(const unsigned char* frames, int N, int H, int W, int bgr, const float* mean3,
+                           const float* std3, float* out, mer_stream_t stream);
+
 /* out[n, :] = scale * sum over t of x[n, t, :]   (x fp32 [N, T, D]; token sum / mean of a hidden state). */
 int mer_token_reduce(const float* x, int N, int T, int D, float scale, float* out, mer_stream_t stream);
 

@@ -7,6 +7,7 @@
 //                        (extract_audio_huggingface.py:98-108, extract_text_huggingface.py:226-249)
 // All HBM-bound; each element is read once with the widest load the layout allows.
 #include "common.h"
+#include <type_traits>
 
 namespace mer {
 
@@ -393,6 +394,62 @@ __global__ __launch_bounds__(256) void wavlm_gate_kernel(const float* x, long lo
   }
 }
 
+// ---- host pre-processing moved to the GPU ----
+// Wav2Vec2FeatureExtractor's zero-mean / unit-variance normalisation (reference extract_audio_huggingface.py:94;
+// HF:wav2vec2/feature_extraction_wav2vec2.py:78-97) straight from 16-bit PCM (x = pcm / 32768, what soundfile returns) or
+// fp32: one workgroup per row, two passes (mean, then centred variance), fp32 with per-thread fp64 partials.
+template <typename IN>
+__global__ __launch_bounds__(1024) void wave_normalize_kernel(const IN* x, long long ldx, int L, int do_norm, float* out, long long ldo) {
+  __shared__ double red[16];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const IN* xr = x + (long long)row * ldx;
+  float* o = out + (long long)row * ldo;
+  const float sc = std::is_same<IN, short>::value ? 1.0f / 32768.0f : 1.0f;
+  auto block_sum = [&](double v) -> double {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+  };
+  if (!do_norm) {
+    for (int i = tid; i < L; i += 1024) o[i] = (float)xr[i] * sc;
+    return;
+  }
+  double s = 0.0;
+  for (int i = tid; i < L; i += 1024) s += (double)((float)xr[i] * sc);
+  const float mean = (float)(block_sum(s) / L);
+  double q = 0.0;
+  for (int i = tid; i < L; i += 1024) {
+    const float d = (float)xr[i] * sc - mean;
+    q += (double)d * d;
+  }
+  const float rstd = 1.0f / sqrtf((float)(block_sum(q) / L) + 1e-7f);
+  for (int i = tid; i < L; i += 1024) o[i] = ((float)xr[i] * sc - mean) * rstd;
+}
+
+// uint8 frames [N, H, W, 3] (BGR as cv2 / the reference's frame files give them, or RGB) -> fp32 [N, 3, H, W] RGB planes,
+// (v / 255 - mean[c]) / std[c]: the rescale + normalise half of CLIPImageProcessor / BitImageProcessor (reference
+// extract_vision_huggingface.py:29-31,116) for frames that already have the model's resolution.
+__global__ void image_normalize_u8_kernel(const unsigned char* in, long long npix, int bgr, float m0, float m1, float m2,
+                                          float s0, float s1, float s2, float* out) {
+  const long long hw = npix;   // pixels per image
+  const long long total = hw * gridDim.y;
+  (void)total;
+  const long long n = blockIdx.y;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < hw; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned char* p = in + (n * hw + i) * 3;
+    const float c0 = (float)p[bgr ? 2 : 0], c1 = (float)p[1], c2 = (float)p[bgr ? 0 : 2];
+    float* o = out + n * 3 * hw + i;
+    o[0] = (c0 * (1.0f / 255.0f) - m0) / s0;
+    o[hw] = (c1 * (1.0f / 255.0f) - m1) / s1;
+    o[2 * hw] = (c2 * (1.0f / 255.0f) - m2) / s2;
+  }
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long g = cdiv(n, block);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -542,4 +599,26 @@ extern "C" int mer_wavlm_gate(const float* x, long long ldx, const float* w, con
   const long long waves = (long long)B * T * H;
   hipLaunchKernelGGL(wavlm_gate_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, b, cst, B * T, T, H, gate);
   return check_launch("wavlm_gate");
+}
+
+extern "C" int mer_wave_normalize(const void* x, int is_int16, long long ldx, int B, int L, int do_normalize, float* out,
+                                  long long ldo, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(x && out && B > 0 && L > 0 && ldx >= L && ldo >= L, MER_EINVAL, "mer_wave_normalize: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (is_int16)
+    hipLaunchKernelGGL((wave_normalize_kernel<short>), dim3(B), dim3(1024), 0, st, (const short*)x, ldx, L, do_normalize, out, ldo);
+  else
+    hipLaunchKernelGGL((wave_normalize_kernel<float>), dim3(B), dim3(1024), 0, st, (const float*)x, ldx, L, do_normalize, out, ldo);
+  return check_launch("wave_normalize");
+}
+
+extern "C" int mer_image_normalize_u8(const unsigned char* frames, int N, int H, int W, int bgr, const float* mean3,
+                                      const float* std3, float* out, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(frames && out && mean3 && std3 && N > 0 && H > 0 && W > 0, MER_EINVAL, "mer_image_normalize_u8: bad argument");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(image_normalize_u8_kernel, dim3(grid_for(hw, 256) > 1024 ? 1024 : grid_for(hw, 256), N), dim3(256), 0,
+                     (hipStream_t)stream, frames, hw, bgr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
+  return check_launch("image_normalize_u8");
 }

@@ -72,8 +72,22 @@ def load_model(model_name, gpu, precision="mx"):
     return HipHubertModel.from_hf(hf, device=f'cuda:{max(gpu, 0)}', precision=precision), fe.do_normalize
 
 
+def device_normalize(samples, do_normalize, device):
+    """wav2vec2_normalize on the GPU: the utterance goes up as 16-bit PCM when it is exactly representable (what a PCM16 file
+    holds: half the H2D bytes of fp32, a quarter of the float64 the reference moves), else as fp32; mer_wave_normalize."""
+    from .. import ops
+    x = np.asarray(samples, dtype=np.float64)
+    pcm = np.round(x * 32768.0)
+    if np.array_equal(pcm / 32768.0, x) and pcm.min() >= -32768 and pcm.max() <= 32767:
+        t = torch.from_numpy(pcm.astype(np.int16))[None].to(device)
+    else:
+        t = torch.from_numpy(x.astype(np.float32))[None].to(device)
+    return ops.wave_normalize(t, do_normalize).cpu()
+
+
 def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
-            reader=read_audio):
+            reader=read_audio, device_preprocess=False):
+    """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy."""
     start_time = time.time()
     if model is None:
         model, do_normalize = load_model(model_name, gpu)
@@ -84,7 +98,10 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
     for audio_file in audio_files:
         samples, sr = reader(audio_file)
         assert sr == 16000, 'currently, we only test on 16k audio'
-        iv = split_into_batch(wav2vec2_normalize(samples, do_normalize))
+        if device_preprocess:
+            iv = split_into_batch(device_normalize(samples, do_normalize, model.device))
+        else:
+            iv = split_into_batch(wav2vec2_normalize(samples, do_normalize))
         buckets.setdefault(tuple(iv.shape), []).append((os.path.basename(audio_file)[:-4], iv))
 
     def flush(items):

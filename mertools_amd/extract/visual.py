@@ -71,8 +71,11 @@ def save_embeddings(save_file, embeddings, feature_level, embedding_dim):
     np.save(save_file, embeddings)
 
 
-def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames):
-    """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video."""
+def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
+            device_preprocess=False):
+    """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video.
+    device_preprocess: frames that already have the model's resolution go to the GPU as uint8 (a quarter of the fp32 bytes)
+    and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path."""
     os.makedirs(save_dir, exist_ok=True)
     vids = vids if vids is not None else os.listdir(face_dir)
     embedding_dim = -1
@@ -82,7 +85,7 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
         nonlocal pending, nframes, embedding_dim
         if not pending:
             return
-        px = torch.cat([p for _, p in pending], 0)
+        px = torch.cat([p.to(model.device) for _, p in pending], 0)
         counts = [p.shape[0] for _, p in pending]
         feats = model.get_image_features(px).cpu().numpy()  # [sum(frames), P]
         embedding_dim = max(embedding_dim, feats.shape[-1])
@@ -98,7 +101,12 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             flush()
             save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
             continue
-        px = clip_preprocess(frames, model.config.vision_config.image_size)
+        size = model.config.vision_config.image_size
+        if device_preprocess and frames.shape[1:3] == (size, size) and frames.dtype == np.uint8:
+            from .. import ops
+            px = ops.image_normalize_u8(torch.from_numpy(np.ascontiguousarray(frames)).to(model.device), CLIP_MEAN, CLIP_STD, bgr=True)
+        else:
+            px = clip_preprocess(frames, size)
         if nframes + len(px) > frames_per_batch:
             flush()
         pending.append((vid, px))

@@ -128,6 +128,26 @@ def attention(qkv, B, T, H, scale, *, kv_len=None, out_lo=False):
     return oh, ol
 
 
+def wave_normalize(x, do_normalize=True):
+    """Device int16 PCM or fp32 [B, L] -> fp32 [B, L], zero-mean / unit-variance per row (mer_wave_normalize)."""
+    assert x.is_cuda and x.dim() == 2 and x.dtype in (torch.int16, torch.float32) and x.stride(1) == 1
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mer_wave_normalize(x.data_ptr(), int(x.dtype == torch.int16), x.stride(0), x.shape[0], x.shape[1],
+                                             int(do_normalize), out.data_ptr(), out.stride(0), stream()), "mer_wave_normalize")
+    return out
+
+
+def image_normalize_u8(frames, mean, std, bgr=True):
+    """Device uint8 [N, H, W, 3] -> fp32 [N, 3, H, W] RGB, (v / 255 - mean) / std (mer_image_normalize_u8)."""
+    import ctypes
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
+    N, H, W, _ = frames.shape
+    out = torch.empty((N, 3, H, W), dtype=torch.float32, device=frames.device)
+    m, s_ = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    _lib.check(_lib.lib().mer_image_normalize_u8(frames.data_ptr(), N, H, W, int(bgr), m, s_, out.data_ptr(), stream()), "mer_image_normalize_u8")
+    return out
+
+
 def attention_bias(qkv, B, T, H, scale, bias, *, gate=None, kv_len=None):
     """attention() with scores += gate[b,h,q] * bias[h,q,k].  bias: fp32 [H, T, ldb] (ldb % 4 == 0), gate: fp32 [B,H,T] or None."""
     D = H * 64

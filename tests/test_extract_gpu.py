@@ -113,3 +113,31 @@ def test_text_extract_files(dev, tmp_path):
             ref = emb.mean(0) if level == "UTTERANCE" else emb
             assert out.shape == ref.shape and out.dtype == np.float32, (name, out.shape, ref.shape)
             assert rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0] < TOL, (name, level)
+
+
+def test_device_preprocessing_matches_host_path(dev, tmp_path):
+    """normalisation on the GPU (int16 PCM / uint8 frames over PCIe) gives the same files as the host path."""
+    from mertools_amd.encoders import HipCLIPModel, HipHubertModel
+    from mertools_amd.extract import audio, visual
+    cfg = W.hubert_config("tiny")
+    model = HipHubertModel(W.hubert_state_dict(cfg, 1), cfg, device=dev, precision="accurate")
+    rng = np.random.RandomState(0)
+    files = []
+    for i, L in enumerate([6000, 9000, 6000]):
+        p = str(tmp_path / f"clip{i}.wav")
+        _write_wav(p, rng.randn(L) * 0.1)
+        files.append(p)
+    audio.extract("hubert-tiny", files, str(tmp_path / "a_host"), "UTTERANCE", 0, model=model)
+    audio.extract("hubert-tiny", files, str(tmp_path / "a_dev"), "UTTERANCE", 0, model=model, device_preprocess=True)
+    for i in range(3):
+        a, b = np.load(tmp_path / "a_host" / f"clip{i}.npy"), np.load(tmp_path / "a_dev" / f"clip{i}.npy")
+        assert np.abs(a - b).max() / np.abs(a).max() < 2e-4, i   # 1e-7 input differences flip fp16 roundings inside the encoder
+    ccfg = W.clip_config("tiny")
+    cmodel = HipCLIPModel(W.clip_state_dict(ccfg, 2), ccfg, device=dev, precision="accurate")
+    size = ccfg.vision_config.image_size
+    vids = {"v1": rng.randint(0, 256, (5, size, size, 3)).astype(np.uint8), "v2": rng.randint(0, 256, (3, size + 10, size, 3)).astype(np.uint8)}
+    for sub, flag in (("v_host", False), ("v_dev", True)):
+        visual.extract(cmodel, "unused", str(tmp_path / sub), "FRAME", vids=list(vids), reader=lambda d, v: vids[v], device_preprocess=flag)
+    for v in vids:
+        a, b = np.load(tmp_path / "v_host" / f"{v}.npy"), np.load(tmp_path / "v_dev" / f"{v}.npy")
+        assert a.shape == b.shape and np.abs(a - b).max() / np.abs(a).max() < 2e-4, v

@@ -393,3 +393,31 @@ def test_wavlm_gate(dev):
     from oracle.encoders_ref import wavlm_gate
     ref = wavlm_gate(x.view(B, T, H * 64), w, b, cst.view(1, H, 1, 1), H)[..., 0]
     assert_close(g.cpu(), ref, 1e-5, "wavlm gate")
+
+
+def test_wave_normalize_matches_feature_extractor(dev):
+    """GPU version of Wav2Vec2FeatureExtractor's normalisation, from int16 PCM and from fp32."""
+    import numpy as np
+    from mertools_amd.extract.audio import wav2vec2_normalize
+    ops = _ops()
+    rng = np.random.default_rng(0)
+    pcm = (rng.standard_normal((3, 80000)) * 3000 + 200).clip(-32768, 32767).astype(np.int16)
+    ref = torch.cat([wav2vec2_normalize(row.astype(np.float64) / 32768.0) for row in pcm], 0)      # what soundfile -> HF computes
+    out = ops.wave_normalize(torch.from_numpy(pcm).to(dev))
+    outf = ops.wave_normalize(torch.from_numpy(pcm.astype(np.float32) / 32768.0).to(dev))
+    plain = ops.wave_normalize(torch.from_numpy(pcm).to(dev), do_normalize=False)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, 2e-6, "wave_normalize int16")
+    assert_close(outf.cpu(), ref, 2e-6, "wave_normalize fp32")
+    assert torch.equal(plain.cpu(), torch.from_numpy(pcm.astype(np.float32) / 32768.0))
+
+
+def test_image_normalize_u8_matches_clip_preprocess(dev):
+    import numpy as np
+    from mertools_amd.extract.visual import CLIP_MEAN, CLIP_STD, clip_preprocess
+    ops = _ops()
+    frames = np.random.default_rng(1).integers(0, 256, (5, 224, 224, 3), dtype=np.uint8)      # BGR, already model-sized
+    ref = clip_preprocess(frames, 224)
+    out = ops.image_normalize_u8(torch.from_numpy(frames).to(dev), CLIP_MEAN, CLIP_STD, bgr=True)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, 2e-6, "image_normalize_u8")
