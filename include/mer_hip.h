@@ -368,6 +368,17 @@ int mer_attention_bias(const void* q, const void* k, const void* v, long long ld
 int mer_wavlm_gate(const float* x, long long ldx, const float* w, const float* b, const float* cst, int B, int T, int H,
                    float* gate, mer_stream_t stream);
 
+/* ---- LSTM recurrence for the frame-level fusion encoders (MERBench/toolkit/models/modules/encoder.py:45-72: nn.LSTM, one
+ * layer, unidirectional, batch_first; only the final hidden state is used).  All fp32, gate order i,f,g,o as in torch.
+ * mer_lstm_fwd: gx [B,T,4H] = X W_ih^T + b_ih + b_hh (one mer_gemm32), w_hh_t [H,4H] = W_hh^T  ->  gates [B,T,4H] (post-
+ *   activation), cs [B,T,H], hs [B,T,H] (h_T = hs[:, T-1]).
+ * mer_lstm_bwd: dh_last [B,H] = dL/dh_T, w_hh [4H,H]  ->  dA [B,T,4H] = dL/d(pre-activations); then dW_ih = dA^T X,
+ *   dW_hh = dA^T [0, hs[:, :-1]], db_ih = db_hh = column sums of dA.   H <= 256, H % 16 == 0. */
+int mer_lstm_fwd(const float* gx, const float* w_hh_t, int B, int T, int H, float* gates, float* cs, float* hs,
+                 mer_stream_t stream);
+int mer_lstm_bwd(const float* dh_last, const float* gates, const float* cs, const float* w_hh, int B, int T, int H,
+                 float* dA, mer_stream_t stream);
+
 /* ---- host pre-processing on the GPU (what the reference does on the CPU before the H2D copy) ----
  * mer_wave_normalize: Wav2Vec2FeatureExtractor's per-utterance (x - mean) / sqrt(var + 1e-7) (do_normalize != 0) or a plain
  * conversion, from device int16 PCM (x = pcm / 32768, is_int16 != 0) or device fp32; one row per utterance / chunk.

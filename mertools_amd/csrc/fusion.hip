@@ -211,3 +211,101 @@ extern "C" int mer_inc_i32(int* x, mer_stream_t stream) {
   inc_kernel<<<1, 64, 0, (hipStream_t)stream>>>(x);
   return check_launch("inc_i32");
 }
+
+// =============================================================================================
+// LSTM recurrence (frame-level fusion: MERBench/toolkit/models/modules/encoder.py:45-72, nn.LSTM single layer,
+// unidirectional, batch_first).  The input projection X W_ih^T + b_ih + b_hh for ALL time steps is one mer_gemm32; these
+// kernels run the sequential part, one workgroup per batch row with one thread per gate row (block = 4H <= 1024):
+//   forward : a_t = gx_t + h_{t-1} W_hh^T  -> (i, f, g, o) -> c_t = f c_{t-1} + i g, h_t = o tanh(c_t)      (torch gate order i,f,g,o)
+//   backward: BPTT from dL/dh_T (the encoder only uses the final state), emitting dL/da_t for every step; the weight
+//             gradients are then plain GEMMs over [B*T] rows (dW_ih = dA^T X, dW_hh = dA^T H_prev, db = colsum dA).
+// W_hh is streamed from L2 every step (transposed copy for the forward so that both directions read it coalesced); all fp32.
+// =============================================================================================
+namespace mer {
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void lstm_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ wt /* [H, 4H] = W_hh^T */,
+                                                        int T, int H, float* __restrict__ gates, float* __restrict__ cs,
+                                                        float* __restrict__ hs) {
+  __shared__ float h_s[256];
+  __shared__ float g_s[1024];
+  const int j = threadIdx.x, b = blockIdx.x, G = 4 * H;
+  float c = 0.f;
+  if (j < H) h_s[j] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const long long row = (long long)b * T + t;
+    float a = gx[row * G + j];
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) a = fmaf(h_s[k], wt[(long long)k * G + j], a);
+    g_s[j] = a;
+    __syncthreads();
+    if (j < H) {
+      const float ig = sigmoidf_(g_s[j]), fg = sigmoidf_(g_s[H + j]), gg = tanhf(g_s[2 * H + j]), og = sigmoidf_(g_s[3 * H + j]);
+      c = fg * c + ig * gg;
+      const float h = og * tanhf(c);
+      gates[row * G + j] = ig;
+      gates[row * G + H + j] = fg;
+      gates[row * G + 2 * H + j] = gg;
+      gates[row * G + 3 * H + j] = og;
+      cs[row * H + j] = c;
+      hs[row * H + j] = h;
+      h_s[j] = h;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void lstm_bwd_kernel(const float* __restrict__ dh_last, const float* __restrict__ gates,
+                                                        const float* __restrict__ cs, const float* __restrict__ whh /* [4H, H] */,
+                                                        int T, int H, float* __restrict__ dA) {
+  __shared__ float da_s[1024];
+  __shared__ float part[4][256];
+  const int j = threadIdx.x, b = blockIdx.x, G = 4 * H;
+  const int q = j / H, k = j % H;
+  float dh = 0.f, dc = 0.f;
+  if (j < H) dh = dh_last[(long long)b * H + j];
+  for (int t = T - 1; t >= 0; --t) {
+    const long long row = (long long)b * T + t;
+    if (j < H) {
+      const float ig = gates[row * G + j], fg = gates[row * G + H + j], gg = gates[row * G + 2 * H + j], og = gates[row * G + 3 * H + j];
+      const float ct = cs[row * H + j], cprev = t > 0 ? cs[(row - 1) * H + j] : 0.f;
+      const float tc = tanhf(ct);
+      const float dcur = dc + dh * og * (1.f - tc * tc);
+      const float dai = dcur * gg * ig * (1.f - ig), daf = dcur * cprev * fg * (1.f - fg);
+      const float dag = dcur * ig * (1.f - gg * gg), dao = dh * tc * og * (1.f - og);
+      dc = dcur * fg;
+      da_s[j] = dai; da_s[H + j] = daf; da_s[2 * H + j] = dag; da_s[3 * H + j] = dao;
+      dA[row * G + j] = dai; dA[row * G + H + j] = daf; dA[row * G + 2 * H + j] = dag; dA[row * G + 3 * H + j] = dao;
+    }
+    __syncthreads();
+    // dh_{t-1}[k] = sum_j dA[j] W_hh[j][k]; thread (q, k) takes gate rows [qH, (q+1)H)
+    float p = 0.f;
+#pragma unroll 8
+    for (int jj = 0; jj < H; ++jj) p = fmaf(da_s[q * H + jj], whh[(long long)(q * H + jj) * H + k], p);
+    part[q][k] = p;
+    __syncthreads();
+    if (j < H) dh = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+    __syncthreads();
+  }
+}
+
+}  // namespace mer
+
+extern "C" int mer_lstm_fwd(const float* gx, const float* w_hh_t, int B, int T, int H, float* gates, float* cs, float* hs,
+                            mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(gx && w_hh_t && gates && cs && hs, MER_EINVAL, "mer_lstm_fwd: null pointer");
+  MER_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 256 && (4 * H) % 64 == 0, MER_ESHAPE, "mer_lstm_fwd: need 0 < H <= 256, H %% 16 == 0 (H=%d)", H);
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B), dim3(4 * H), 0, (hipStream_t)stream, gx, w_hh_t, T, H, gates, cs, hs);
+  return check_launch("lstm_fwd");
+}
+
+extern "C" int mer_lstm_bwd(const float* dh_last, const float* gates, const float* cs, const float* w_hh, int B, int T, int H,
+                            float* dA, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(dh_last && gates && cs && w_hh && dA, MER_EINVAL, "mer_lstm_bwd: null pointer");
+  MER_REQUIRE(B > 0 && T > 0 && H > 0 && H <= 256 && (4 * H) % 64 == 0, MER_ESHAPE, "mer_lstm_bwd: need 0 < H <= 256, H %% 16 == 0 (H=%d)", H);
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(4 * H), 0, (hipStream_t)stream, dh_last, gates, cs, w_hh, T, H, dA);
+  return check_launch("lstm_bwd");
+}

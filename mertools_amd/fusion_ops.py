@@ -54,6 +54,48 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class LSTMLastFn(torch.autograd.Function):
+    """h_T of a single-layer unidirectional batch_first nn.LSTM started from zeros (LSTMEncoder: encoder.py:63-72 uses
+    final_states[0] only).  x [B,T,D]; w_ih [4H,D], w_hh [4H,H], b_ih, b_hh [4H] (nn.LSTM parameter layouts)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        x, w_ih, w_hh = _c(x), _c(w_ih), _c(w_hh)
+        B, T, D = x.shape
+        H = w_hh.shape[1]
+        x2 = x.reshape(B * T, D)
+        gx = gemm32(x2, w_ih, _c(b_ih + b_hh))                       # [B*T, 4H]
+        gates = torch.empty((B, T, 4 * H), dtype=torch.float32, device=x.device)
+        cs = torch.empty((B, T, H), dtype=torch.float32, device=x.device)
+        hs = torch.empty((B, T, H), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().mer_lstm_fwd(_p(gx), _p(w_hh.t().contiguous()), B, T, H, _p(gates), _p(cs), _p(hs), stream()), "mer_lstm_fwd")
+        ctx.save_for_backward(x2, w_ih, w_hh, gates, cs, hs)
+        ctx.dims = (B, T, D, H)
+        return hs[:, T - 1].contiguous()
+
+    @staticmethod
+    def backward(ctx, dh):
+        x2, w_ih, w_hh, gates, cs, hs = ctx.saved_tensors
+        B, T, D, H = ctx.dims
+        dA = torch.empty((B, T, 4 * H), dtype=torch.float32, device=dh.device)
+        _lib.check(_lib.lib().mer_lstm_bwd(_p(_c(dh)), _p(gates), _p(cs), _p(w_hh), B, T, H, _p(dA), stream()), "mer_lstm_bwd")
+        dA2 = dA.reshape(B * T, 4 * H)
+        dx = gemm32(dA2, w_ih, trans_w=True).reshape(B, T, D) if ctx.needs_input_grad[0] else None
+        dw_ih = gemm32(dA2, x2, trans_a=True, trans_w=True)            # dA^T [4H, B*T] @ X [B*T, D]
+        hprev = torch.zeros_like(hs)
+        hprev[:, 1:] = hs[:, :-1]
+        dw_hh = gemm32(dA2, hprev.reshape(B * T, H), trans_a=True, trans_w=True)
+        db = colsum(dA2)
+        return dx, dw_ih, dw_hh, db, db.clone()
+
+
+def lstm_last(x, rnn):
+    """Final hidden state of `rnn` (an nn.LSTM container holding the parameters) on the HIP kernels."""
+    if rnn.num_layers != 1 or rnn.bidirectional or not rnn.batch_first:
+        raise _lib.MerError("only the reference's configuration is built: one unidirectional batch_first LSTM layer")
+    return LSTMLastFn.apply(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+
+
 class FuseFn(torch.autograd.Function):
     """fused[b,:] = sum_e h[b, e*H:(e+1)*H] * att[b,e]  (attention.py:45-50; weights are not softmaxed)."""
 

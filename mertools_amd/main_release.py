@@ -138,6 +138,7 @@ def main(argv=None):
         model_config = func_random_select(model_config)
     config.dataset = args.dataset
     args = merge_args_config(args, model_config)
+    args.lr = float(args.lr)   # a user-supplied yaml may spell it 1e-3, which PyYAML hands over as a string
     print('args: ', args)
     save_resroot, save_modelroot = os.path.join(args.save_root, 'result'), os.path.join(args.save_root, 'model')
     os.makedirs(save_resroot, exist_ok=True)

@@ -3,7 +3,7 @@ Parameters live in nn.Linear containers so state_dict keys (linear_{1,2,3}.{weig
 (nn.Linear's kaiming-uniform) are the reference's; forward = relu(L3(relu(L2(relu(L1(dropout(x)))))))."""
 import torch.nn as nn
 
-from ....fusion_ops import dropout, linear
+from ....fusion_ops import dropout, linear, lstm_last
 
 
 class MLPEncoder(nn.Module):
@@ -22,8 +22,19 @@ class MLPEncoder(nn.Module):
 
 
 class LSTMEncoder(nn.Module):
-    """frm_align / frm_unalign feature types (encoder.py:45-72) are outside this round's hot-path scope."""
+    """Mirror of MERBench/toolkit/models/modules/encoder.py:45-72 (frm_align / frm_unalign feature types): single-layer
+    nn.LSTM (the container keeps the reference's parameter names rnn.weight_ih_l0 ... and default init), final hidden state
+    -> dropout -> linear_1.  The recurrence, its BPTT and the projections run in libmer_hip.so (mer_lstm_fwd / mer_lstm_bwd /
+    mer_gemm32).  Features are padded in FRONT (read_data.func_mapping_feature), which is why the final state is the summary."""
 
-    def __init__(self, *a, **k):
+    def __init__(self, in_size, hidden_size, dropout, num_layers=1, bidirectional=False):  # noqa: A002
         super().__init__()
-        raise NotImplementedError("LSTMEncoder (frame-level fusion) is not built; use feat_type='utt'")
+        if num_layers != 1 or bidirectional:
+            raise NotImplementedError("LSTMEncoder: only num_layers=1, bidirectional=False (the reference's call sites) is built")
+        self.rnn = nn.LSTM(in_size, hidden_size, num_layers=1, dropout=0.0, bidirectional=False, batch_first=True)
+        self.drop = nn.Dropout(p=dropout)
+        self.linear_1 = nn.Linear(hidden_size, hidden_size)
+
+    def forward(self, x):
+        h = lstm_last(x, self.rnn)
+        return linear(dropout(h, self.drop.p, self.training), self.linear_1, relu=False)

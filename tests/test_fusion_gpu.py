@@ -135,3 +135,132 @@ def test_graph_trainer_matches_reference(dev, use_graph):
     for k, p in m.model.state_dict().items():
         assert_close(p.cpu(), torch.from_numpy(g["final_" + k]), 1e-4, f"final {k} (graph={use_graph})")
     assert sorted(m.model.state_dict()) == sorted(k[5:] for k in g.files if k.startswith("init_"))
+
+
+# ---- frame-level fusion: LSTMEncoder on the HIP LSTM kernels ----
+@pytest.mark.parametrize("B,T,D,H", [(5, 7, 24, 16), (32, 40, 768, 128), (3, 130, 100, 256)])
+def test_lstm_last_matches_torch_lstm(dev, B, T, D, H):
+    """mer_lstm_fwd / mer_lstm_bwd + the GEMMs around them against torch.nn.LSTM (the reference's own op) on the CPU:
+    final hidden state and the gradients of every parameter and of the input."""
+    import torch.nn as nn
+    from mertools_amd.fusion_ops import lstm_last
+    torch.manual_seed(0)
+    ref = nn.LSTM(D, H, num_layers=1, batch_first=True)
+    x = torch.randn(B, T, D)
+    x[: B // 2, : T // 3] = 0.0                        # front padding, as func_mapping_feature produces
+    xr = x.clone().requires_grad_(True)
+    _, (hn, _) = ref(xr)
+    wgt = torch.randn(B, H)
+    (hn[0] * wgt).sum().backward()
+    dev_rnn = nn.LSTM(D, H, num_layers=1, batch_first=True)
+    dev_rnn.load_state_dict(ref.state_dict())
+    dev_rnn = dev_rnn.to(dev)
+    xd = x.clone().to(dev).requires_grad_(True)
+    h = lstm_last(xd, dev_rnn)
+    (h * wgt.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(h.detach().cpu(), hn[0].detach(), 2e-5, "lstm h_T")
+    assert_close(xd.grad.cpu(), xr.grad, 2e-4, "lstm dX")
+    for name in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+        assert_close(getattr(dev_rnn, name).grad.cpu(), getattr(ref, name).grad, 2e-4, f"lstm d{name}")
+
+
+def test_attention_model_frame_level_matches_reference_modules(dev):
+    """toolkit.models.Attention with feat_type='frm_align' (LSTMEncoder x3) against the same wiring built from torch modules on
+    the CPU (the reference's attention.py:22-57 / encoder.py:45-72), same parameters: outputs and a full backward."""
+    import torch.nn as nn
+    from types import SimpleNamespace
+    from mertools_amd.toolkit.models import get_models
+    args = SimpleNamespace(model="attention", feat_type="frm_align", audio_dim=48, text_dim=40, video_dim=32, output_dim1=6, output_dim2=1,
+                           dropout=0.0, hidden_dim=64, grad_clip=-1.0)
+    torch.manual_seed(1)
+    model = get_models(args)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    B, T = 6, 9
+    batch = {"audios": torch.randn(B, T, 48), "texts": torch.randn(B, T, 40), "videos": torch.randn(B, T, 32)}
+    feats, emos, vals, inter = model({k: v.to(dev) for k, v in batch.items()})
+    (emos.square().sum() + vals.sum()).backward()
+    torch.cuda.synchronize()
+
+    class RefLSTMEnc(nn.Module):               # encoder.py:45-72
+        def __init__(self, d, h):
+            super().__init__()
+            self.rnn = nn.LSTM(d, h, num_layers=1, batch_first=True)
+            self.linear_1 = nn.Linear(h, h)
+
+        def forward(self, x):
+            return self.linear_1(self.rnn(x)[1][0].squeeze(0))
+
+    class RefMLP(nn.Module):                   # encoder.py:9-41 (dropout 0)
+        def __init__(self, d, h):
+            super().__init__()
+            self.linear_1, self.linear_2, self.linear_3 = nn.Linear(d, h), nn.Linear(h, h), nn.Linear(h, h)
+
+        def forward(self, x):
+            return torch.relu(self.linear_3(torch.relu(self.linear_2(torch.relu(self.linear_1(x))))))
+
+    class RefAttention(nn.Module):             # attention.py:22-57
+        def __init__(self):
+            super().__init__()
+            self.audio_encoder, self.text_encoder, self.video_encoder = RefLSTMEnc(48, 64), RefLSTMEnc(40, 64), RefLSTMEnc(32, 64)
+            self.attention_mlp = RefMLP(192, 64)
+            self.fc_att, self.fc_out_1, self.fc_out_2 = nn.Linear(64, 3), nn.Linear(64, 6), nn.Linear(64, 1)
+
+        def forward(self, b):
+            hs = [self.audio_encoder(b["audios"]), self.text_encoder(b["texts"]), self.video_encoder(b["videos"])]
+            att = self.fc_att(self.attention_mlp(torch.cat(hs, dim=1))).unsqueeze(2)
+            fused = torch.matmul(torch.stack(hs, dim=2), att).squeeze(2)
+            return fused, self.fc_out_1(fused), self.fc_out_2(fused)
+
+    ref = RefAttention()
+    missing, unexpected = ref.load_state_dict({k.replace("model.", "", 1) if k.startswith("model.") else k: v for k, v in sd.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    rf, re, rv = ref(batch)
+    (re.square().sum() + rv.sum()).backward()
+    assert_close(feats.detach().cpu(), rf.detach(), 2e-5, "frame-level fused features")
+    assert_close(emos.detach().cpu(), re.detach(), 2e-5, "frame-level emos_out")
+    got = dict(model.named_parameters())
+    for k, p in ref.named_parameters():
+        g = got.get(k, got.get("model." + k))
+        assert_close(g.grad.cpu(), p.grad, 5e-4, f"grad {k}")
+
+
+@pytest.mark.parametrize("feat_type", ["utt", "frm_align", "frm_unalign"])
+def test_main_release_end_to_end_on_synthetic_features(dev, tmp_path, feat_type):
+    """python -m mertools_amd.main_release on a small synthetic MER2023-shaped corpus (label npz + per-clip FRAME .npy files),
+    all three feature types of main-release.py:157-166: reads, pools / pads (read_data.py), trains 2 epochs x 5 folds on the
+    GPU (MLPEncoder or LSTMEncoder), writes the result files; losses must be finite and the run deterministic under --seed."""
+    from mertools_amd import main_release
+    root = tmp_path / "data" / "mer2023-dataset-process"
+    rng = np.random.RandomState(0)
+    names = {"train": [f"tr_{i:03d}" for i in range(40)], "test1": [f"t1_{i:02d}" for i in range(8)],
+             "test2": [f"t2_{i:02d}" for i in range(8)], "test3": [f"t3_{i:02d}" for i in range(8)]}
+    emos = ['neutral', 'angry', 'happy', 'sad', 'worried', 'surprise']
+    corp = {}
+    for split, ns in names.items():
+        corp[f"{split}_corpus"] = {n: {"emo": emos[rng.randint(6)], "val": float(rng.uniform(-3, 3))} for n in ns}
+        if split == "test3":
+            for n in ns:
+                del corp[f"{split}_corpus"][n]["val"]            # test3 has no valence labels (mer2023.py:95-98 -> -10 sentinel)
+    os.makedirs(root / "features", exist_ok=True)
+    np.savez_compressed(root / "label-6way.npz", **{k: np.array(v, dtype=object) for k, v in corp.items()})
+    dims = {"audio-FRA": 24, "text-FRA": 16, "video-FRA": 20}
+    for feat, d in dims.items():
+        os.makedirs(root / "features" / feat, exist_ok=True)
+        for ns in names.values():
+            for n in ns:
+                np.save(root / "features" / feat / f"{n}.npy", rng.randn(rng.randint(3, 30), d).astype(np.float32))
+    argv = ["--model", "attention", "--feat_type", feat_type, "--dataset", "MER2023", "--audio_feature", "audio-FRA", "--text_feature", "text-FRA",
+            "--video_feature", "video-FRA", "--epochs", "2", "--batch_size", "16", "--gpu", "0", "--seed", "7", "--data_root", str(tmp_path / "data"),
+            "--save_root", str(tmp_path / f"saved-{feat_type}")]
+    res1 = main_release.main(argv)
+    res2 = main_release.main(argv)
+    assert len(res1) == 5
+    for a, b in zip(res1, res2):
+        for k in a:
+            if isinstance(a[k], np.ndarray) and a[k].dtype.kind == "f":
+                assert np.isfinite(a[k]).all(), k
+                assert np.array_equal(a[k], b[k]), f"{feat_type}: {k} differs between two seeded runs"
+    saved = os.listdir(tmp_path / f"saved-{feat_type}-trimodal" / "result")
+    assert sum(f.startswith("cv_") for f in saved) == 2 and sum(f.startswith("test1_") for f in saved) == 2
