@@ -100,7 +100,10 @@ __device__ __forceinline__ f32x4 mx_mfma(i32x8 a, i32x8 b, f32x4 c, int sb) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 1 /*A bf8*/, 4 /*B fp4*/, 0, 0x7f7f7f7f, OPS, sb);
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false>
+// STAMP (tuning builds of the 8-wave kernels, mer_set_option("gemm_stamp", 1)): waves 0 and NW/2 accumulate, per K-loop
+// iteration, the cycles spent in LOAD work / waiting at the mid barrier / MATH work / waiting at the end barrier, split
+// into the MX-burst slabs and the others, into p.dbg[4 * nblk + (blk * 2 + group) * 8 ..].
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false, bool STAMP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
   constexpr int NT = WM * WN * 64;
@@ -355,7 +358,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     i32x8 aq[MX ? TM : 1];
 #pragma unroll
     for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto iter = [&](int kt) {
+      unsigned long long t0 = 0, tL = 0, tB1 = 0, tM = 0;
+      if (STAMP) t0 = __builtin_amdgcn_s_memtime();
       const bool more = kt + D < nk;
       if (more) glds_issue((kt + D) * BK, nxt);
       load_frags(smem + cur * STAGE, 0);
@@ -372,7 +378,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       if (more) wait_vmcnt<LPS*(D - 1)>();
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (STAMP) tL = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
+      if (STAMP) tB1 = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_setprio(1);
       math();
       if constexpr (MX) {
@@ -419,11 +427,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      if (STAMP) tM = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
+      if (STAMP) {
+        const unsigned long long tB2 = __builtin_amdgcn_s_memtime();
+        const bool mxs = MX && (kt & 3) == 3;   // (static indices only: a dynamically indexed array would live in scratch)
+        const unsigned long long d0 = tL - t0, d1 = tB1 - tL, d2 = tM - tB1, d3 = tB2 - tM;
+        acc_t[0] += mxs ? 0 : d0; acc_t[1] += mxs ? 0 : d1; acc_t[2] += mxs ? 0 : d2; acc_t[3] += mxs ? 0 : d3;
+        acc_t[4] += mxs ? d0 : 0; acc_t[5] += mxs ? d1 : 0; acc_t[6] += mxs ? d2 : 0; acc_t[7] += mxs ? d3 : 0;
+      }
       cur = cur + 1 == NS ? 0 : cur + 1;
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
     };
     for (int kt = 0; kt < nk; ++kt) iter(kt);   // MX: K % 128 == 0 (checked by the launcher)
+    if (STAMP && p.dbg && lane == 0 && (wave == 0 || wave == WM * WN / 2)) {
+      unsigned long long* d = p.dbg + 4ll * gridDim.x * gridDim.y + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = acc_t[i];
+    }
     if (!g1) __builtin_amdgcn_s_barrier();
     __syncthreads();
     if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -605,6 +626,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 int g_gemm_skip = 0;
+int g_gemm_stamp = 0;
 int g_gemm_glds = 1;
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
@@ -622,9 +644,16 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
                      mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.c16_lo ? 2 : 0) + (p.residual ? 4 : 0)),
                  st);
   if constexpr (MX) {
-    hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, true>), grid, block, 0, st, p);
+    if (g_gemm_stamp) hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, true, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, true>), grid, block, 0, st, p);
     return check_launch("gemm16_mx");
   } else {
+    if constexpr (WM * WN == 8 && AP == 1 && std::is_same<T, f16>::value) {
+      if (g_gemm_stamp && g_gemm_glds == 1 && p.K % BK == 0) {
+        hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, false, true>), grid, block, 0, st, p);
+        return check_launch("gemm16");
+      }
+    }
     if (g_gemm_glds == 2 && p.K % BK == 0)  // A/B: LDS-DMA loader, plain double buffering
       hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, 2>), grid, block, 0, st, p);
     else if (g_gemm_glds && p.K % BK == 0)
@@ -669,6 +698,7 @@ namespace mer { extern int g_attn_force_nkt; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;

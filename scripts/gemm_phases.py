@@ -21,7 +21,8 @@ for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 
     mx = ops.mx_pack(w.cpu() - wh.cpu().float()).to(dev) if passes == 4 else None
     bias = torch.randn(N, device=dev)
     nblk = ((M + 255) // 256) * ((N + 255) // 256)
-    buf = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
+    STAMP = int(os.environ.get("STAMP", "0"))
+    buf = torch.zeros(nblk * 4 + nblk * 16, dtype=torch.int64, device=dev)
     kw = dict(w_lo=wl if passes >= 2 else None, w_mx=mx, passes=passes, dtype="f16", tile=3, bias=bias, act=act, out16=True)
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
     WARM = int(os.environ.get("WARM", "0"))   # > 0: stamp a launch that follows WARM back-to-back launches (sustained clocks)
@@ -33,10 +34,23 @@ for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 
         for _ in range(WARM): ops.gemm16(ah, wh, **kw)
         e1.record()
     lib.mer_set_debug_buffer(buf.data_ptr())
+    lib.mer_set_option(b"gemm_stamp", STAMP)
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
+    lib.mer_set_option(b"gemm_stamp", 0)
     lib.mer_set_debug_buffer(None)
     if WARM: wall_us = e0.elapsed_time(e1) / WARM * 1e3
-    t = buf.view(nblk, 4).cpu().double()
+    if STAMP:
+        ph = buf[nblk * 4:].view(nblk, 2, 8).cpu().double()
+        nsl = K // 32
+        for gi in range(2):
+            m = ph[:, gi].median(0).values
+            n_mx = nsl // 4 if passes == 4 else 0
+            n_other = nsl - n_mx
+            line = f"   group {gi}: per plain slab  LOAD {m[0] / n_other:.0f} | wait {m[1] / n_other:.0f} | MATH {m[2] / n_other:.0f} | wait {m[3] / n_other:.0f}"
+            if n_mx:
+                line += f"   || per MX slab  LOAD {m[4] / n_mx:.0f} | wait {m[5] / n_mx:.0f} | MATH {m[6] / n_mx:.0f} | wait {m[7] / n_mx:.0f}"
+            print(line)
+    t = buf[:nblk * 4].view(nblk, 4).cpu().double()
     pro, loop, epi, tot = (t[:, 1] - t[:, 0]), (t[:, 2] - t[:, 1]), (t[:, 3] - t[:, 2]), (t[:, 3] - t[:, 0])
     span = (t[:, 3].max() - t[:, 0].min()).item()
     print(f"{name:13s} blocks={nblk} median cycles/ticks: prologue {pro.median():.0f}  kloop {loop.median():.0f}  epilogue {epi.median():.0f}  total {tot.median():.0f}"
