@@ -186,12 +186,14 @@ def main():
         dom = max(recs.values(), key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic = None  # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc) and dom["name"] == "gemm16_w2":
-            k = json.load(open(pmc)).get("gemm16<DF16_Li256>")
+        pmc_file, pmc_key = {"gemm16_w2": ("r01_pmc_hbm_traffic.json", "gemm16<DF16_Li256>"),
+                             "gemm16_mx": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,4,2,1,1,1,3,1,0>")}.get(dom["name"], (None, None))
+        pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
+        if pmc_file and os.path.exists(pmc):
+            k = json.load(open(pmc)).get(pmc_key)
             if k:
                 traffic = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
-                           "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/r01_pmc_hbm_traffic.txt"}
+                           "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/" + pmc_file.replace(".json", ".txt")}
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     # the default 2-pass (weights hi+lo) kernel issues 2x the algorithmic MFMA work; 3-pass 3x

@@ -18,7 +18,12 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row["Kernel_Name"]
-                short = "gemm16<" + ",".join(name.split("gemm16_kernelI")[1].split("E")[0:1]) + ">" if "gemm16_kernel" in name else name.split("(")[0][-60:]
+                if "gemm16_kernel" in name:   # keep every template argument: <dtype,BM,BN,BK,WM,WN,AP,WP,GLDS,NS,MX[,STAMP]>
+                    import re
+                    targs = name.split("gemm16_kernelI")[1].split("EEvNS")[0]
+                    short = "gemm16<" + ",".join([("f16" if targs.startswith("DF16_") else "bf16")] + re.findall(r"L[ib](\d+)E", targs)) + ">"
+                else:
+                    short = name.split("(")[0][-60:]
                 agg[short][counter].append(float(row["Counter_Value"]))
 out = {}
 print(f"{'kernel':70s} {'launches':>8s} {'fetch MB/launch':>16s} {'x2 (gfx950)':>12s} {'write MB/launch':>16s}")
