@@ -355,9 +355,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     if (g1) __builtin_amdgcn_s_barrier();
     int cur = 0, nxt = D;
     // MX: bf8 copies of this wave's A fragments of the current 128-k group
-    i32x8 aq[MX ? TM : 1];
+    i64x4 aq[MX ? TM : 1];
 #pragma unroll
-    for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i64x4{0, 0, 0, 0};
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto iter = [&](int kt) {
       unsigned long long t0 = 0, tL = 0, tB1 = 0, tM = 0;
@@ -392,13 +392,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
           for (int mt = 0; mt < TM; ++mt) {
             const v8 a = af[0][mt];
-            i16x2 r0 = __builtin_bit_cast(i16x2, aq[mt][0]), r1 = __builtin_bit_cast(i16x2, aq[mt][1]);   // fully overwritten
+            i16x2 r0, r1;   // both halves get written below (deliberately uninitialised: no false dependency on the window)
+            asm volatile("" : "=v"(r0), "=v"(r1));
             r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[0], a[1]}, 1.0f, false);
             r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[2], a[3]}, 1.0f, true);
             r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[4], a[5]}, 1.0f, false);
             r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[6], a[7]}, 1.0f, true);
-            aq[mt] = i32x8{aq[mt][2], aq[mt][3], aq[mt][4], aq[mt][5], aq[mt][6], aq[mt][7],
-                           __builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)};
+            // 64-bit window elements: the shift is three v_mov_b64 per tile instead of six v_mov_b32
+            aq[mt] = i64x4{aq[mt][1], aq[mt][2], aq[mt][3],
+                           __builtin_bit_cast(long long, i32x2{__builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)})};
           }
         }
         if (mx_slab) {   // the group's fp4 residual fragments straight from the group buffer, one column tile at a time
@@ -415,10 +417,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
               switch (nt & 3) {
-                case 0: acc[mt][nt] = mx_mfma<0>(aq[mt], wb, acc[mt][nt], sc); break;
-                case 1: acc[mt][nt] = mx_mfma<1>(aq[mt], wb, acc[mt][nt], sc); break;
-                case 2: acc[mt][nt] = mx_mfma<2>(aq[mt], wb, acc[mt][nt], sc); break;
-                default: acc[mt][nt] = mx_mfma<3>(aq[mt], wb, acc[mt][nt], sc); break;
+                case 0: acc[mt][nt] = mx_mfma<0>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+                case 1: acc[mt][nt] = mx_mfma<1>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+                case 2: acc[mt][nt] = mx_mfma<2>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+                default: acc[mt][nt] = mx_mfma<3>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
               }
             }
             wcur = wnx1;
