@@ -187,7 +187,8 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic = None  # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh)
         pmc_file, pmc_key = {"gemm16_w2": ("r01_pmc_hbm_traffic.json", "gemm16<DF16_Li256>"),
-                             "gemm16_mx": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,4,2,1,1,1,3,1,0>")}.get(dom["name"], (None, None))
+                             "gemm16_mx": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,4,2,1,1,1,3,1,0>"),
+                             "gemm16": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,2,4,1,1,1,4,0,0>")}.get(dom["name"], (None, None))
         pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
         if pmc_file and os.path.exists(pmc):
             k = json.load(open(pmc)).get(pmc_key)

@@ -93,6 +93,8 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                       TfBufs& b, const int* kv_len, const float* pos_bias = nullptr, long long ldb = 0) {
   const int M = Bseq * T, D = c.hidden, F = c.ffn, H = c.heads;
   const int dt = c.dtype, ps = c.passes;
+  const int ps1 = (ps == 4 && (c.mx_skip & 2)) ? 1 : ps;   // fc1 without the correction
+  const int ps2 = (ps == 4 && (c.mx_skip & 4)) ? 1 : ps;   // fc2 without the correction
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
   for (int l = 0; l < c.layers; ++l) {
@@ -103,6 +105,17 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
       MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.gin32, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
+    if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx) {
+      // Q | K columns: one f16 pass (weight rounding there only perturbs softmax logits: no measurable effect on the features);
+      // V columns: MX-corrected.  The MX plane is stored per 256-column tile, so the V block starts at tile 2D/256.
+      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr};
+      MER_TRY(gemm(st, dt, 1, M, 2 * D, D, b.cur16, D, wqk, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
+      const long long woff = (long long)2 * D * D * 2;   // bytes into the 16-bit planes
+      const mer_w16 wv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
+                          (const char*)w.wqkv.mx + (long long)(2 * D / 256) * (D / 32) * 5120};
+      const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
+      MER_TRY(gemm(st, dt, 4, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D));
+    } else
     MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
     const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
     if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
@@ -119,12 +132,12 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0));
     if (c.pre_ln) {
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.h1_16.hi, b.h1_16.lo, D, dt, st));
-      MER_TRY(gemm(st, dt, ps, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
-      MER_TRY(gemm(st, dt, ps, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0));
     } else {
       MER_TRY(mer_layernorm(b.t32, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.h1_32, D, b.h1_16.hi, b.h1_16.lo, D, dt, st));
-      MER_TRY(gemm(st, dt, ps, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
-      MER_TRY(gemm(st, dt, ps, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0));
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, y, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     }
   }
@@ -138,6 +151,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.passes >= 1 && c.passes <= 4, MER_EINVAL, "%s: passes must be 1, 2, 3 or 4 (MX-corrected)", who);
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
   MER_REQUIRE(c.gated_rel_pos == 0 || c.gated_rel_pos == 1, MER_EINVAL, "%s: gated_rel_pos must be 0 or 1", who);
+  MER_REQUIRE(c.mx_skip >= 0 && c.mx_skip <= 7, MER_EINVAL, "%s: mx_skip must be a 3-bit mask", who);
   MER_REQUIRE(c.dtype == MER_DT_F16 || c.dtype == MER_DT_BF16, MER_EINVAL, "%s: bad dtype", who);
   return MER_OK;
 }

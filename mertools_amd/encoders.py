@@ -26,6 +26,7 @@ precision (see DESIGN.md §numerics for the measured parity of each):
     "mixed" / "balanced3"  HuBERT only: conv stack 3-pass with 1- / 2-pass transformer blocks
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -109,8 +110,21 @@ def _tf_layer(hold, lo, wq, bq, wk, bk, wv, bv, wo, bo, ln1, w1, b1, w2, b2, ln2
     return L
 
 
-def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes):
+def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes, mx_skip=None):
+    """mx_skip (passes == 4): which block GEMMs run without the weight-residual correction (bit 0: Q/K, bit 1: fc1, bit 2: fc2).
+    From the emulated encoders (scripts/probes/mx_selective.py) and the GPU parity tests: dropping it for Q/K changes nothing
+    anywhere (their rounding only perturbs softmax logits); in PRE-LN blocks (CLIP, VideoMAE, DINOv2, data2vec-vision, the
+    stable-LayerNorm HuBERT / WavLM large) the FFN weights do not need it either (CLIP-B/16 UTT 2.4e-4 / frames 4.1e-4 with
+    or without, large models 1.8e-4 - 3.3e-4) — only V and the attention output projection carry the error that reaches the
+    features; in POST-LN blocks (HuBERT / wav2vec2 / WavLM base, BERT family) dropping it for the FFN triples the error
+    (HuBERT-base UTT 6.3e-4), so those keep everything but Q/K corrected.  Default: 7 for pre-LN, 1 for post-LN; the
+    MER_MX_SKIP environment variable overrides it (tuning)."""
     c = TfConfig()
+    if mx_skip is None:
+        mx_skip = int(os.environ.get("MER_MX_SKIP", "-1"))
+        if mx_skip < 0:
+            mx_skip = 7 if pre_ln else 1
+    c.mx_skip = mx_skip
     c.hidden, c.heads, c.ffn, c.layers, c.pre_ln = hidden, heads, ffn, layers, int(pre_ln)
     c.act, c.ln_eps, c.dtype, c.passes = act, eps, dt_code(dtype), passes
     return c
