@@ -11,8 +11,11 @@
 //                 lane, a valid MFMA B fragment when the 32-key k-slice is enumerated as
 //                 (tile 2c: keys 4g..4g+3 | tile 2c+1: keys 4g..4g+3); V^T is read from LDS with the
 //                 same enumeration (two ds_read_b64), so P never leaves registers.
-// K rows are padded to 144 B and V^T rows to (TP+4)*2 B, which makes both fragment reads
-// bank-conflict free.  Scores, softmax and the 1/sum normalisation are fp32.
+// K and V are both staged ROW-major (rows padded to 144 B, 16-byte LDS writes); the V^T fragments of the second MFMA are
+// produced by the LDS transpose read of gfx950, ds_read_b64_tr_b16: within each 16-lane block the lanes hand in the
+// addresses of a 4-row x 16-column patch (lane j: row j/4, columns 4*(j%4)..+3) and lane j' receives column j' of the four
+// rows (measured: scripts/probes/tr_probe.py) — exactly "feature d = li, keys 4*lg .. 4*lg+3" of the fragment.  (Writing V^T
+// with eight 2-byte LDS stores per 16-byte load was a third of this kernel.)  Scores, softmax and 1/sum are fp32.
 #include "common.h"
 
 namespace mer {
@@ -24,6 +27,14 @@ int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (
 // (HF:wavlm/modeling_wavlm.py WavLMAttention.forward: one [H,T,T] table shared by the batch and by all layers, a per-query
 // gate per layer) and, with gate == NULL, BEiT / data2vec-vision's relative position bias.  A lane owns ONE query row, so
 // its four keys of a tile are 16 contiguous bytes of that row of the table (rows padded to ldb % 4 == 0).
+// LDS transpose read (ds_read_b64_tr_b16): four 16-bit values, see the header comment
+typedef short i16x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ typename T16<T>::v4 tr_read4(const T* lds_ptr) {
+  const i16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)lds_ptr);
+  return __builtin_bit_cast(typename T16<T>::v4, r);
+}
+
 template <typename T, int NKT, bool BIAS = false>
 __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
@@ -34,9 +45,8 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
   typedef typename T16<T>::v4 v4;
   constexpr int TP = NKT * 16;
   constexpr int KS = 72;       // K row stride in elements (144 B)
-  constexpr int VS = TP + 4;   // V^T row stride in elements
   __shared__ __attribute__((aligned(16))) T Ks[TP * KS];
-  __shared__ __attribute__((aligned(16))) T Vt[64 * VS];
+  __shared__ __attribute__((aligned(16))) T Vs[TP * KS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -78,9 +88,7 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
         const int c = tid + (g0 + it) * 256;
         const int row = c >> 3, ch = c & 7;
         *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kreg[it];
-        const v8 vh = __builtin_bit_cast(v8, vreg[it]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
+        *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vreg[it];
       }
     }
   }
@@ -164,9 +172,11 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const T* vr = Vt + (dt * 16 + li) * VS + lg * 4;
-      const v4 v0 = *reinterpret_cast<const v4*>(vr + (2 * c) * 16);
-      const v4 v1 = *reinterpret_cast<const v4*>(vr + (2 * c + 1) * 16);
+      // transpose read: this lane's address = row (key) 32c + 4*lg + li/4, columns 16*dt + 4*(li%4) .. +3;
+      // it receives V[32c + 4*lg + i][16*dt + li], i = 0..3 (and the same 16 keys further for the second half)
+      const T* vr = Vs + ((2 * c) * 16 + lg * 4 + (li >> 2)) * KS + dt * 16 + (li & 3) * 4;
+      const v4 v0 = tr_read4<T>(vr);
+      const v4 v1 = tr_read4<T>(vr + 16 * KS);
       v8 vf;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -208,9 +218,9 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
                                                           long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
-  constexpr int KB = 64, KS = 72, VS = KB + 4;
+  constexpr int KB = 64, KS = 72;
   __shared__ __attribute__((aligned(16))) T Ks[KB * KS];
-  __shared__ __attribute__((aligned(16))) T Vt[64 * VS];
+  __shared__ __attribute__((aligned(16))) T Vs[KB * KS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
@@ -245,9 +255,7 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
         vv = *reinterpret_cast<const u32x4*>(vb + (long long)(k0 + row) * ld + ch * 8);
       }
       *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kv;
-      const v8 vh = __builtin_bit_cast(v8, vv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VS + row] = vh[j];
+      *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vv;
     }
     __syncthreads();
     f32x4 s[4];
@@ -297,9 +305,9 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const T* vr = Vt + (dt * 16 + li) * VS + lg * 4;
-        const v4 v0 = *reinterpret_cast<const v4*>(vr + (2 * c) * 16);
-        const v4 v1 = *reinterpret_cast<const v4*>(vr + (2 * c + 1) * 16);
+        const T* vr = Vs + ((2 * c) * 16 + lg * 4 + (li >> 2)) * KS + dt * 16 + (li & 3) * 4;
+        const v4 v0 = tr_read4<T>(vr);
+        const v4 v1 = tr_read4<T>(vr + 16 * KS);
         v8 vf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
