@@ -257,7 +257,7 @@ typedef struct {
   int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split) or 4 (MX-corrected, see mer_gemm16) */
   int gated_rel_pos;  /* 1: WavLM — every layer carries gru_* and the forward call must be given the position-bias table */
   int mx_skip;        /* passes == 4 only: GEMMs that run WITHOUT the weight-residual correction (plain one-pass f16) because
-                       * their rounding error does not reach the saved features (scripts/probes/mx_selective.py):
+                       * their rounding error does not reach the saved features (tests/studies/mx_selective.py):
                        * bit 0 = the Q and K projections (their error only perturbs softmax logits), bit 1 = FFN fc1, bit 2 = FFN fc2 */
 } mer_tf_config;
 

@@ -112,7 +112,7 @@ def _tf_layer(hold, lo, wq, bq, wk, bk, wv, bv, wo, bo, ln1, w1, b1, w2, b2, ln2
 
 def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes, mx_skip=None):
     """mx_skip (passes == 4): which block GEMMs run without the weight-residual correction (bit 0: Q/K, bit 1: fc1, bit 2: fc2).
-    From the emulated encoders (scripts/probes/mx_selective.py) and the GPU parity tests: dropping it for Q/K changes nothing
+    From the emulated encoders (tests/studies/mx_selective.py) and the GPU parity tests: dropping it for Q/K changes nothing
     anywhere (their rounding only perturbs softmax logits); in PRE-LN blocks (CLIP, VideoMAE, DINOv2, data2vec-vision, the
     stable-LayerNorm HuBERT / WavLM large) the FFN weights do not need it either (CLIP-B/16 UTT 2.4e-4 / frames 4.1e-4 with
     or without, large models 1.8e-4 - 3.3e-4) — only V and the attention output projection carry the error that reaches the

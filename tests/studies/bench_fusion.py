@@ -11,7 +11,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mertools_amd.fusion_trainer import FusionGraphTrainer  # noqa: E402
 from mertools_amd.toolkit.models import get_models  # noqa: E402
 from mertools_amd.toolkit.utils.loss import CELoss, MSELoss  # noqa: E402
