@@ -43,3 +43,16 @@ def test_rounding_residual_error_bound(ops):
     assert (back - res.double()).abs().max() <= res.abs().max().item()   # never worse than dropping the residual
     # zero input -> zero plane
     assert mx_decode(ops.mx_pack(torch.zeros(32, 128)), 32, 128).abs().max() == 0
+
+
+def test_column_tile_blocks_are_independent(ops):
+    """The engine splits the fused QKV GEMM into a one-pass [Q|K] launch and an MX-corrected V launch by offsetting into the
+    packed plane at tile 2D/256 (csrc/encoders.cpp tf_forward): the plane of W[3D, D] from byte (2D/256)*(D/32)*5120 on must be
+    byte-identical to the plane of the V rows packed alone."""
+    g = torch.Generator().manual_seed(3)
+    for D in (128, 768):
+        w = torch.randn(3 * D, D, generator=g) * 1e-5
+        full = ops.mx_pack(w)
+        v_only = ops.mx_pack(w[2 * D:].contiguous())
+        off = (2 * D // 256) * (D // 32) * 5120
+        assert torch.equal(full[off:], v_only)
