@@ -377,3 +377,23 @@ def test_electra_albert_tiny(dev, precision, tol, kind):
     for i, (o, r) in enumerate(zip(out, ref)):
         assert_close(o.cpu(), r, tol if precision == "accurate" else 2 * tol, f"{kind}-tiny[{precision}] hs[{i}]")
     assert_close(pooled.cpu(), torch.stack(ref)[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1), tol, f"{kind}-tiny[{precision}] UTT feature")
+
+
+def test_clip_large14_frames(dev):
+    """CLIP-ViT-L/14 (the AffectGPT visual front-end): 24 pre-LN layers, patch 14 (588 -> 592 padded columns), 257 tokens,
+    1024 -> 768 projection; the default preset runs Q/K and the FFN without the weight-residual correction here."""
+    from mertools_amd.encoders import HipCLIPModel
+    from util import rel_err
+    cfg = W.clip_config("large14")
+    sd = W.clip_state_dict(cfg, 0)
+    px = W.synth_frames(5)
+    ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
+    for prec in ("mx", "accurate"):
+        m = HipCLIPModel(sd, cfg, device=dev, precision=prec)
+        out = m.get_image_features(px.to(dev))
+        torch.cuda.synchronize()
+        e, eu = rel_err(out.cpu(), ref)[0], rel_err(out.cpu().mean(0), ref.mean(0))[0]
+        print(f"clip-L/14[{prec}]: frames={e:.2e} utt={eu:.2e}")
+        assert out.shape == (5, 768)
+        assert eu <= TOL and e <= TOL
+        del m
