@@ -103,7 +103,10 @@ __device__ __forceinline__ f32x4 mx_mfma(i32x8 a, i32x8 b, f32x4 c, int sb) {
 // STAMP (tuning builds of the 8-wave kernels, mer_set_option("gemm_stamp", 1)): waves 0 and NW/2 accumulate, per K-loop
 // iteration, the cycles spent in LOAD work / waiting at the mid barrier / MATH work / waiting at the end barrier, split
 // into the MX-burst slabs and the others, into p.dbg[4 * nblk + (blk * 2 + group) * 8 ..].
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false, bool STAMP = false>
+// PERSIST (8-wave non-MX kernels, mer_set_option("gemm_persist", 1)): one workgroup per CU walks tiles L = blockIdx.x + i*gridDim.x;
+// the first PF slabs of the next tile are DMA'd into stages 0..PF-1 while the epilogue of the current tile runs out of a
+// staging area placed behind them, so the next tile starts without the ~6-8k-cycle prologue.
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false, bool STAMP = false, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
   constexpr int NT = WM * WN * 64;
@@ -124,7 +127,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   constexpr int EROWS = SN > 64 ? 16 : (SM > 64 ? 32 : SM);   // rows of the wave tile staged per epilogue chunk
   constexpr int CSTAGE = WM * WN * EROWS * CLD * 4;
   constexpr int RING = NS * STAGE + (MX ? MX_LDS : 0);
-  constexpr int SMEM = (RING > CSTAGE) ? RING : CSTAGE;
+  constexpr int PF_FIT = (163840 - CSTAGE) / STAGE;                           // stages that fit below the C staging area
+  constexpr int PF = PERSIST ? ((NS - 1) < PF_FIT ? (NS - 1) : PF_FIT) : 0;   // slabs of the next tile prefetched during the epilogue
+  constexpr int CT_OFF = PF * STAGE;                                           // byte offset of the C staging area
+  static_assert(!PERSIST || (PF >= 1 && !MX && GLDS && STAGGER), "persistent tiles: 8-wave LDS-DMA kernels only");
+  constexpr int SMEM = (RING > CT_OFF + CSTAGE) ? RING : CT_OFF + CSTAGE;
   static_assert(NS >= 2 && (GLDS || NS == 2), "register-staged loader is double-buffered only");
   static_assert(NT % C == 0 && (BM * C) % NT == 0 && (BN * C) % NT == 0, "bad tile/thread split");
 
@@ -136,18 +143,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, lg = lane >> 4;
 
-  // ---- XCD-aware, bijective block -> tile map ----
+  // ---- XCD-aware, bijective block -> tile map (L = linear workgroup / tile index) ----
   const int nblk = p.tiles_m * p.tiles_n;
-  int tile_m, tile_n;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
+  auto tile_of = [&](int L, int& tm, int& tn) {
+    const int xcd = L & 7, loc = L >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    tile_n = swz % p.tiles_n;
-    tile_m = swz / p.tiles_n;
-  }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+    tn = swz % p.tiles_n;
+    tm = swz / p.tiles_n;
+  };
+  int tile_m, tile_n;
+  tile_of(blockIdx.x, tile_m, tile_n);
+  int m0 = tile_m * BM, n0 = tile_n * BN;   // the tile being computed / written (PERSIST: advanced per tile)
 
   // ---- batch offsets ----
   const int z = blockIdx.y;
@@ -163,19 +170,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const int ld_ch = tid % C;
   const int ld_row0 = tid / C;
   long long a_off[CA], w_off[CW];
+  long long a_src[CA], w_src[CW];   // GLDS: the same with the XOR swizzle folded into the source address (see below)
+  auto setup_loads = [&](int m0_, int n0_) {
 #pragma unroll
-  for (int i = 0; i < CA; ++i) {
-    int m = m0 + ld_row0 + i * ROWS_PER_IT;
-    m = m < p.M ? m : p.M - 1;
-    a_off[i] = (p.a_rpb > 0) ? (long long)(m / p.a_rpb) * p.a_bstride + (long long)(m % p.a_rpb) * p.lda
-                             : (long long)m * p.lda;
-  }
+    for (int i = 0; i < CA; ++i) {
+      int m = m0_ + ld_row0 + i * ROWS_PER_IT;
+      m = m < p.M ? m : p.M - 1;
+      a_off[i] = (p.a_rpb > 0) ? (long long)(m / p.a_rpb) * p.a_bstride + (long long)(m % p.a_rpb) * p.lda
+                               : (long long)m * p.lda;
+      a_src[i] = a_off[i] + ((ld_ch ^ swz_of<C>(ld_row0 + i * ROWS_PER_IT)) << 3);
+    }
 #pragma unroll
-  for (int i = 0; i < CW; ++i) {
-    int n = n0 + ld_row0 + i * ROWS_PER_IT;
-    n = n < p.N ? n : p.N - 1;
-    w_off[i] = (long long)n * p.ldw;
-  }
+    for (int i = 0; i < CW; ++i) {
+      int n = n0_ + ld_row0 + i * ROWS_PER_IT;
+      n = n < p.N ? n : p.N - 1;
+      w_off[i] = (long long)n * p.ldw;
+      w_src[i] = w_off[i] + ((ld_ch ^ swz_of<C>(ld_row0 + i * ROWS_PER_IT)) << 3);
+    }
+  };
+  setup_loads(m0, n0);
 
   u32x4 ra[AP][CA], rw[WP][CW];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -218,19 +231,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // One wave-instruction fills 1 KiB of LDS linearly (lane l -> base + 16*l), i.e. 64/C whole tile
   // rows; the XOR swizzle therefore moves to the SOURCE side: the lane that owns physical chunk c'
   // of row r fetches logical chunk c' ^ f(r).  The LDS image is identical to lds_store()'s.
-  long long a_src[CA], w_src[CW];
-  if (GLDS) {
-#pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const int row = ld_row0 + i * ROWS_PER_IT;
-      a_src[i] = a_off[i] + ((ld_ch ^ swz_of<C>(row)) << 3);
-    }
-#pragma unroll
-    for (int i = 0; i < CW; ++i) {
-      const int row = ld_row0 + i * ROWS_PER_IT;
-      w_src[i] = w_off[i] + ((ld_ch ^ swz_of<C>(row)) << 3);
-    }
-  }
   const int wave_row0 = (tid >> 6) * (64 / C);  // first tile row of this wave's 1 KiB piece
   // MX kernel: registers are scarce, so the DMA addresses are a uniform base (SGPRs, advanced by k) + a 32-bit per-lane
   // byte offset (the launcher checks that the planes are < 4 GB) instead of a 64-bit VGPR pair per load.
@@ -330,170 +330,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     }
   };
 
-  if (GLDS && STAGGER) {
-    // Two wave groups (waves [0, NW/2) and [NW/2, NW): one wave of each per SIMD) run the SAME loop one barrier
-    // phase apart (group 1 takes one extra barrier up front, group 0 one at the end).  Each iteration is
-    // LOAD(t) |bar| MATH(t) |bar|, so while one group issues its MFMAs the other pulls its fragments out of LDS:
-    // the matrix pipe of every SIMD is fed by one wave at a time and never waits for an LDS read burst.
-    //   phase:     2t          2t+1        2t+2
-    //   group 0:   LOAD(t)     MATH(t)     LOAD(t+1)
-    //   group 1:   MATH(t-1)   LOAD(t)     MATH(t)
-    // DMA for slab t+D goes to stage (t-1) % NS at the top of a wave's iteration t: both groups' LOAD(t-1) ended
-    // (lgkmcnt(0)) before the barrier that precedes it.  Each wave confirms its share of slab t+1 (counted
-    // vmcnt, D-1 slabs stay in flight) before its mid-iteration barrier, i.e. at least one barrier before any
-    // wave of either group reads that slab.
-    constexpr int D = NS - 1;
-    constexpr int LPS = AP * CA + WP * CW + (MX ? 1 : 0);
-    const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN / 2);
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-      if (s < nk) glds_issue(s * BK, s);
-    if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memtime();
-    if (g1) __builtin_amdgcn_s_barrier();
-    int cur = 0, nxt = D;
-    // MX: bf8 copies of this wave's A fragments of the current 128-k group
-    i64x4 aq[MX ? TM : 1];
-#pragma unroll
-    for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i64x4{0, 0, 0, 0};
-    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto iter = [&](int kt) {
-      unsigned long long t0 = 0, tL = 0, tB1 = 0, tM = 0;
-      if (STAMP) t0 = __builtin_amdgcn_s_memtime();
-      const bool more = kt + D < nk;
-      if (more) glds_issue((kt + D) * BK, nxt);
-      load_frags(smem + cur * STAGE, 0);
-      i32x4 wcur, wnx1;   // deliberately not initialised (10 v_mov per slab): only read on the slabs that load them
-      int sc0, sc1;
-      const char* mg = smem + NS * STAGE + ((kt >> 2) & 1) * MXG_BYTES;
-      const bool mx_slab = MX && (kt & 3) == 3;
-      if (mx_slab) {   // last slab of a group: the first two fp4 fragments + the scales come in with the f16 fragments
-        wcur = *reinterpret_cast<const i32x4*>(mg + (wn * TN) * 1024 + lane * 16);
-        wnx1 = *reinterpret_cast<const i32x4*>(mg + (wn * TN + 1) * 1024 + lane * 16);
-        sc0 = *reinterpret_cast<const int*>(mg + 16384 + (wn * 2) * 256 + lane * 4);
-        sc1 = *reinterpret_cast<const int*>(mg + 16384 + (wn * 2 + 1) * 256 + lane * 4);
-      }
-      if (more) wait_vmcnt<LPS*(D - 1)>();
-      else wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (STAMP) tL = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      if (STAMP) tB1 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_setprio(1);
-      math();
-      if constexpr (MX) {
-        // 8 f16 -> 8 bf8 (RNE) per 16-row tile; the group's window shifts by one slab (oldest slab in dwords 0-1) so that
-        // one loop body serves all four slab positions.  Tried and measured worse or spilling: the 4x-unrolled loop with
-        // static indices (21 spills), per-position uniform branches (the conversions get hoisted into temporaries + 16
-        // copies), in-place inline-asm conversions (16 copies), a 64-bit window (the whole window gets copied).
-        {
-#pragma unroll
-          for (int mt = 0; mt < TM; ++mt) {
-            const v8 a = af[0][mt];
-            i16x2 r0, r1;   // both halves get written below (deliberately uninitialised: no false dependency on the window)
-            asm volatile("" : "=v"(r0), "=v"(r1));
-            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[0], a[1]}, 1.0f, false);
-            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[2], a[3]}, 1.0f, true);
-            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[4], a[5]}, 1.0f, false);
-            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[6], a[7]}, 1.0f, true);
-            // 64-bit window elements: the shift is three v_mov_b64 per tile instead of six v_mov_b32
-            aq[mt] = i64x4{aq[mt][1], aq[mt][2], aq[mt][3],
-                           __builtin_bit_cast(long long, i32x2{__builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)})};
-          }
-        }
-        if (mx_slab) {   // the group's fp4 residual fragments straight from the group buffer, one column tile at a time
-          // two column tiles ahead (the LDS is busy with the other wave group's fragment reads: one tile ahead stalled),
-          // no further: the compiler would otherwise pull all 8 reads to the top (32 live registers the kernel lacks)
-#pragma unroll
-          for (int nt = 0; nt < TN; ++nt) {
-            asm volatile("" ::: "memory");
-            i32x4 wnx2 = wnx1;
-            if (nt + 2 < TN) wnx2 = *reinterpret_cast<const i32x4*>(mg + (wn * TN + nt + 2) * 1024 + lane * 16);
-            __builtin_amdgcn_sched_barrier(0);   // keep the read ahead of this tile's MFMAs (it was sunk below them)
-            const i32x8 wb = {wcur[0], wcur[1], wcur[2], wcur[3], 0, 0, 0, 0};
-            const int sc = nt < 4 ? sc0 : sc1;
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-              switch (nt & 3) {
-                case 0: acc[mt][nt] = mx_mfma<0>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
-                case 1: acc[mt][nt] = mx_mfma<1>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
-                case 2: acc[mt][nt] = mx_mfma<2>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
-                default: acc[mt][nt] = mx_mfma<3>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
-              }
-            }
-            wcur = wnx1;
-            wnx1 = wnx2;
-          }
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (STAMP) tM = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      if (STAMP) {
-        const unsigned long long tB2 = __builtin_amdgcn_s_memtime();
-        const bool mxs = MX && (kt & 3) == 3;   // (static indices only: a dynamically indexed array would live in scratch)
-        const unsigned long long d0 = tL - t0, d1 = tB1 - tL, d2 = tM - tB1, d3 = tB2 - tM;
-        acc_t[0] += mxs ? 0 : d0; acc_t[1] += mxs ? 0 : d1; acc_t[2] += mxs ? 0 : d2; acc_t[3] += mxs ? 0 : d3;
-        acc_t[4] += mxs ? d0 : 0; acc_t[5] += mxs ? d1 : 0; acc_t[6] += mxs ? d2 : 0; acc_t[7] += mxs ? d3 : 0;
-      }
-      cur = cur + 1 == NS ? 0 : cur + 1;
-      nxt = nxt + 1 == NS ? 0 : nxt + 1;
-    };
-    for (int kt = 0; kt < nk; ++kt) iter(kt);   // MX: K % 128 == 0 (checked by the launcher)
-    if (STAMP && p.dbg && lane == 0 && (wave == 0 || wave == WM * WN / 2)) {
-      unsigned long long* d = p.dbg + 4ll * gridDim.x * gridDim.y + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) d[i] = acc_t[i];
-    }
-    if (!g1) __builtin_amdgcn_s_barrier();
-    __syncthreads();
-    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
-  } else
-  if (GLDS) {
-    // NS-stage LDS ring, LDS-DMA prefetch distance D = NS-1 slabs, counted vmcnt: at the end of iteration
-    // t only slab t+1 has to have landed, the newer D-1 slabs stay in flight ACROSS the barrier (raw
-    // s_barrier: __syncthreads() would drain vmcnt(0) because an LDS-DMA is a pending LDS write).
-    // WAR: iteration t refills stage (t+D) % NS == (t-1) % NS, whose readers all passed barrier t-1.
-    constexpr int D = NS - 1;
-    constexpr int LPS = AP * CA + WP * CW;  // LDS-DMA instructions per wave per slab
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-      if (s < nk) glds_issue(s * BK, s);
-    if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    int cur = 0, nxt = D;  // stage holding slab t / stage to refill with slab t+D
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + D < nk;
-      if (more) glds_issue((kt + D) * BK, nxt);
-      compute(smem + cur * STAGE);
-      if (more) wait_vmcnt<LPS*(D - 1)>();
-      else wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur = cur + 1 == NS ? 0 : cur + 1;
-      nxt = nxt + 1 == NS ? 0 : nxt + 1;
-    }
-  } else {
-    gload(0);
-    lds_store(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) gload((kt + 1) * BK);
-      compute(smem + cur * STAGE);
-      if (kt + 1 < nk) lds_store(cur ^ 1);
-      __syncthreads();
-    }
-  }
-
+  auto run_epilogue = [&]() {
   // ---- epilogue: accumulators -> per-wave LDS staging (EROWS rows at a time) -> 8 consecutive columns per lane, so
   // that 16-bit outputs leave as one 16-byte store per lane (the store tail is issue-bound: half the instructions,
   // half the time) and fp32 outputs / residuals as two.  The stage buffers are dead here (the K loop ended on a
   // barrier); each wave owns a private EROWS x CLD slice.
-  float* ct = reinterpret_cast<float*>(smem) + wave * EROWS * CLD;
+  float* ct = reinterpret_cast<float*>(smem + CT_OFF) + wave * EROWS * CLD;
   constexpr int CPL = 8;                       // columns per lane
   constexpr int LANES_PER_ROW = SN / CPL;
   constexpr int ROWS_IT = 64 / LANES_PER_ROW;
@@ -623,12 +465,216 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     case MER_ACT_GELU_TANH: epilogue(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
     default: epilogue(std::integral_constant<int, MER_ACT_NONE>{}); break;
   }
+  };
+
+  if (GLDS && STAGGER) {
+    // Two wave groups (waves [0, NW/2) and [NW/2, NW): one wave of each per SIMD) run the SAME loop one barrier
+    // phase apart (group 1 takes one extra barrier up front, group 0 one at the end).  Each iteration is
+    // LOAD(t) |bar| MATH(t) |bar|, so while one group issues its MFMAs the other pulls its fragments out of LDS:
+    // the matrix pipe of every SIMD is fed by one wave at a time and never waits for an LDS read burst.
+    //   phase:     2t          2t+1        2t+2
+    //   group 0:   LOAD(t)     MATH(t)     LOAD(t+1)
+    //   group 1:   MATH(t-1)   LOAD(t)     MATH(t)
+    // DMA for slab t+D goes to stage (t-1) % NS at the top of a wave's iteration t: both groups' LOAD(t-1) ended
+    // (lgkmcnt(0)) before the barrier that precedes it.  Each wave confirms its share of slab t+1 (counted
+    // vmcnt, D-1 slabs stay in flight) before its mid-iteration barrier, i.e. at least one barrier before any
+    // wave of either group reads that slab.
+    constexpr int D = NS - 1;
+    constexpr int LPS = AP * CA + WP * CW + (MX ? 1 : 0);
+    const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN / 2);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nk) glds_issue(s * BK, s);
+    if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memtime();
+    if (g1) __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = D;
+    // MX: bf8 copies of this wave's A fragments of the current 128-k group
+    i64x4 aq[MX ? TM : 1];
+#pragma unroll
+    for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i64x4{0, 0, 0, 0};
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto iter = [&](int kt) {
+      unsigned long long t0 = 0, tL = 0, tB1 = 0, tM = 0;
+      if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+      const bool more = kt + D < nk;
+      if (more) glds_issue((kt + D) * BK, nxt);
+      load_frags(smem + cur * STAGE, 0);
+      i32x4 wcur, wnx1;   // deliberately not initialised (10 v_mov per slab): only read on the slabs that load them
+      int sc0, sc1;
+      const char* mg = smem + NS * STAGE + ((kt >> 2) & 1) * MXG_BYTES;
+      const bool mx_slab = MX && (kt & 3) == 3;
+      if (mx_slab) {   // last slab of a group: the first two fp4 fragments + the scales come in with the f16 fragments
+        wcur = *reinterpret_cast<const i32x4*>(mg + (wn * TN) * 1024 + lane * 16);
+        wnx1 = *reinterpret_cast<const i32x4*>(mg + (wn * TN + 1) * 1024 + lane * 16);
+        sc0 = *reinterpret_cast<const int*>(mg + 16384 + (wn * 2) * 256 + lane * 4);
+        sc1 = *reinterpret_cast<const int*>(mg + 16384 + (wn * 2 + 1) * 256 + lane * 4);
+      }
+      if (more) wait_vmcnt<LPS*(D - 1)>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (STAMP) tL = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      if (STAMP) tB1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_setprio(1);
+      math();
+      if constexpr (MX) {
+        // 8 f16 -> 8 bf8 (RNE) per 16-row tile; the group's window shifts by one slab (oldest slab in dwords 0-1) so that
+        // one loop body serves all four slab positions.  Tried and measured worse or spilling: the 4x-unrolled loop with
+        // static indices (21 spills), per-position uniform branches (the conversions get hoisted into temporaries + 16
+        // copies), in-place inline-asm conversions (16 copies), a 64-bit window (the whole window gets copied).
+        {
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) {
+            const v8 a = af[0][mt];
+            i16x2 r0, r1;   // both halves get written below (deliberately uninitialised: no false dependency on the window)
+            asm volatile("" : "=v"(r0), "=v"(r1));
+            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[0], a[1]}, 1.0f, false);
+            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[2], a[3]}, 1.0f, true);
+            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[4], a[5]}, 1.0f, false);
+            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[6], a[7]}, 1.0f, true);
+            // 64-bit window elements: the shift is three v_mov_b64 per tile instead of six v_mov_b32
+            aq[mt] = i64x4{aq[mt][1], aq[mt][2], aq[mt][3],
+                           __builtin_bit_cast(long long, i32x2{__builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)})};
+          }
+        }
+        if (mx_slab) {   // the group's fp4 residual fragments straight from the group buffer, one column tile at a time
+          // two column tiles ahead (the LDS is busy with the other wave group's fragment reads: one tile ahead stalled),
+          // no further: the compiler would otherwise pull all 8 reads to the top (32 live registers the kernel lacks)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) {
+            asm volatile("" ::: "memory");
+            i32x4 wnx2 = wnx1;
+            if (nt + 2 < TN) wnx2 = *reinterpret_cast<const i32x4*>(mg + (wn * TN + nt + 2) * 1024 + lane * 16);
+            __builtin_amdgcn_sched_barrier(0);   // keep the read ahead of this tile's MFMAs (it was sunk below them)
+            const i32x8 wb = {wcur[0], wcur[1], wcur[2], wcur[3], 0, 0, 0, 0};
+            const int sc = nt < 4 ? sc0 : sc1;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+              switch (nt & 3) {
+                case 0: acc[mt][nt] = mx_mfma<0>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+                case 1: acc[mt][nt] = mx_mfma<1>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+                case 2: acc[mt][nt] = mx_mfma<2>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+                default: acc[mt][nt] = mx_mfma<3>(__builtin_bit_cast(i32x8, aq[mt]), wb, acc[mt][nt], sc); break;
+              }
+            }
+            wcur = wnx1;
+            wnx1 = wnx2;
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (STAMP) tM = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      if (STAMP) {
+        const unsigned long long tB2 = __builtin_amdgcn_s_memtime();
+        const bool mxs = MX && (kt & 3) == 3;   // (static indices only: a dynamically indexed array would live in scratch)
+        const unsigned long long d0 = tL - t0, d1 = tB1 - tL, d2 = tM - tB1, d3 = tB2 - tM;
+        acc_t[0] += mxs ? 0 : d0; acc_t[1] += mxs ? 0 : d1; acc_t[2] += mxs ? 0 : d2; acc_t[3] += mxs ? 0 : d3;
+        acc_t[4] += mxs ? d0 : 0; acc_t[5] += mxs ? d1 : 0; acc_t[6] += mxs ? d2 : 0; acc_t[7] += mxs ? d3 : 0;
+      }
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    };
+    int L = blockIdx.x;   // PERSIST: linear index of the tile being computed
+    for (;;) {
+      for (int kt = 0; kt < nk; ++kt) iter(kt);   // MX: K % 128 == 0 (checked by the launcher)
+      if (STAMP && p.dbg && lane == 0 && (wave == 0 || wave == WM * WN / 2)) {
+        unsigned long long* d = p.dbg + 4ll * gridDim.x * gridDim.y + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = acc_t[i];
+      }
+      if (!g1) __builtin_amdgcn_s_barrier();
+      __syncthreads();
+      if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
+      if constexpr (!PERSIST) {
+        break;
+      } else {
+        // Next tile of this workgroup: its first PF slabs go to stages 0..PF-1 now (every wave is past its last LDS read of
+        // the ring), the epilogue of the current tile stages through [CT_OFF, CT_OFF + CSTAGE) behind them, and the
+        // remaining prologue slabs follow once all waves have left the staging area.  The counted vmcnt waits stay valid:
+        // the epilogue's stores / residual loads sit between the DMAs in issue order, which only makes the waits stricter.
+        const int Ln = L + (int)gridDim.x;
+        const bool has_next = Ln < nblk;
+        int tmn = 0, tnn = 0;
+        if (has_next) {
+          tile_of(Ln, tmn, tnn);
+          setup_loads(tmn * BM, tnn * BN);
+#pragma unroll
+          for (int s = 0; s < PF; ++s)
+            if (s < nk) glds_issue(s * BK, s);
+        }
+        run_epilogue();
+        if (!has_next) return;
+        m0 = tmn * BM;
+        n0 = tnn * BN;
+        L = Ln;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave has left the C staging area: stages PF.. may be refilled
+#pragma unroll
+        for (int s = PF; s < D; ++s)
+          if (s < nk) glds_issue(s * BK, s);
+        if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (g1) __builtin_amdgcn_s_barrier();
+        cur = 0;
+        nxt = D;
+      }
+    }
+  } else
+  if (GLDS) {
+    // NS-stage LDS ring, LDS-DMA prefetch distance D = NS-1 slabs, counted vmcnt: at the end of iteration
+    // t only slab t+1 has to have landed, the newer D-1 slabs stay in flight ACROSS the barrier (raw
+    // s_barrier: __syncthreads() would drain vmcnt(0) because an LDS-DMA is a pending LDS write).
+    // WAR: iteration t refills stage (t+D) % NS == (t-1) % NS, whose readers all passed barrier t-1.
+    constexpr int D = NS - 1;
+    constexpr int LPS = AP * CA + WP * CW;  // LDS-DMA instructions per wave per slab
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nk) glds_issue(s * BK, s);
+    if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = D;  // stage holding slab t / stage to refill with slab t+D
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + D < nk;
+      if (more) glds_issue((kt + D) * BK, nxt);
+      compute(smem + cur * STAGE);
+      if (more) wait_vmcnt<LPS*(D - 1)>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+  } else {
+    gload(0);
+    lds_store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) gload((kt + 1) * BK);
+      compute(smem + cur * STAGE);
+      if (kt + 1 < nk) lds_store(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  run_epilogue();
   if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 int g_gemm_skip = 0;
 int g_gemm_stamp = 0;
+int g_gemm_persist = 0;   // mer_set_option("gemm_persist", 1): persistent-tile variant of the 8-wave non-MX kernels
 int g_gemm_glds = 1;
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
@@ -650,6 +696,19 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
     else hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, true>), grid, block, 0, st, p);
     return check_launch("gemm16_mx");
   } else {
+    if constexpr (WM * WN == 8) {
+      if (g_gemm_persist && g_gemm_glds == 1 && p.K % BK == 0 && nbatch == 1 && !p.dbg) {
+        static int ncu = 0;
+        if (!ncu) {
+          int dev = 0;
+          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        }
+        const int nb = p.tiles_m * p.tiles_n;
+        dim3 pgrid(nb < ncu ? nb : ncu, 1, 1);
+        hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, false, false, true>), pgrid, block, 0, st, p);
+        return check_launch("gemm16");
+      }
+    }
     if constexpr (WM * WN == 8 && AP == 1 && std::is_same<T, f16>::value) {
       if (g_gemm_stamp && g_gemm_glds == 1 && p.K % BK == 0) {
         hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, false, true>), grid, block, 0, st, p);
@@ -701,6 +760,7 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;

@@ -53,6 +53,8 @@ for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 
     t = buf[:nblk * 4].view(nblk, 4).cpu().double()
     pro, loop, epi, tot = (t[:, 1] - t[:, 0]), (t[:, 2] - t[:, 1]), (t[:, 3] - t[:, 2]), (t[:, 3] - t[:, 0])
     span = (t[:, 3].max() - t[:, 0].min()).item()
+    if os.environ.get("WALL_ONLY"):
+        print(f"{name:13s} wall {wall_us:.1f} us/launch = {2.0 * M * N * K / wall_us / 1e6:.0f} TF"); continue
     print(f"{name:13s} blocks={nblk} median cycles/ticks: prologue {pro.median():.0f}  kloop {loop.median():.0f}  epilogue {epi.median():.0f}  total {tot.median():.0f}"
           f" | wall {wall_us:.1f} us/launch -> eff. clock {tot.sum().item() / 256 / wall_us / 1e3:.2f} GHz (sum of tile cycles / 256 CUs / wall)"
           f" | per-slab {loop.median() / (K / 32):.0f} | kernel span {span:.0f} ticks; sum(total)/256/span = {tot.sum().item() / 256 / span:.2f}")

@@ -421,3 +421,29 @@ def test_image_normalize_u8_matches_clip_preprocess(dev):
     out = ops.image_normalize_u8(torch.from_numpy(frames).to(dev), CLIP_MEAN, CLIP_STD, bgr=True)
     torch.cuda.synchronize()
     assert_close(out.cpu(), ref, 2e-6, "image_normalize_u8")
+
+
+@pytest.mark.parametrize("passes", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(10240, 2048, 256), (70000, 768, 96), (9000, 1100, 32)])
+def test_gemm16_persistent_tiles(dev, M, N, K, passes):
+    """mer_set_option("gemm_persist", 1): more 256x256 tiles than compute units, so workgroups walk several tiles and
+    prefetch the next tile's first slabs under the epilogue; results must equal the one-tile-per-workgroup kernel bit for bit."""
+    from mertools_amd import _lib
+    ops = _ops()
+    a = _rand((M, K), 71)
+    w = _rand((N, K), 72) * 0.05
+    ah, al = ops.split16(a.to(dev), "f16")
+    wh, wl = ops.split16_host(w, "f16")
+    bias, res = _rand((N,), 73).to(dev), _rand((M, N), 74).to(dev)
+    kw = dict(a_lo=al if passes == 3 else None, w_lo=wl.to(dev) if passes >= 2 else None, bias=bias, act="gelu", residual=res, out32=True,
+              out16=True, passes=passes, tile=3)
+    ref32, ref16, _ = ops.gemm16(ah, wh.to(dev), **kw)
+    try:
+        _lib.lib().mer_set_option(b"gemm_persist", 1)
+        c32, c16, _ = ops.gemm16(ah, wh.to(dev), **kw)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().mer_set_option(b"gemm_persist", 0)
+    assert torch.equal(c32, ref32) and torch.equal(c16, ref16)
+    true = F.gelu(a.double() @ w.double().T + bias.cpu().double()) + res.cpu().double()
+    assert_close(c32.cpu(), true.float(), {1: 1e-3, 2: 5e-4, 3: 2e-5}[passes], "persistent gemm16 vs fp64")
