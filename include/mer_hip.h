@@ -256,6 +256,8 @@ typedef struct {
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
   int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split) or 4 (MX-corrected, see mer_gemm16) */
   int gated_rel_pos;  /* 1: WavLM — every layer carries gru_* and the forward call must be given the position-bias table */
+  int ffn_swiglu;     /* 1: DINOv2-giant SwiGLU feed-forward (HF:dinov2/modeling_dinov2.py Dinov2SwiGLUFFN): w1 = weights_in [2*ffn, D],
+                       * h = silu(y[:, :ffn]) * y[:, ffn:], w2 = weights_out [D, ffn]; `ffn` is the post-gate width, `act` is ignored */
   int mx_skip;        /* passes == 4 only: GEMMs that run WITHOUT the weight-residual correction (plain one-pass f16) because
                        * their rounding error does not reach the saved features (tests/studies/mx_selective.py):
                        * bit 0 = the Q and K projections (their error only perturbs softmax logits), bit 1 = FFN fc1, bit 2 = FFN fc2 */
@@ -392,6 +394,9 @@ int mer_wave_normalize(const void* x, int is_int16, long long ldx, int B, int L,
                        long long ldo, mer_stream_t stream);
 int mer_image_normalize_u8(const unsigned char* frames, int N, int H, int W, int bgr, const float* mean3,
                            const float* std3, float* out, mer_stream_t stream);
+
+/* SwiGLU gate: out[m, j] = silu(y[m, j]) * y[m, F + j] for y fp32 [M, 2F] (row stride ldy) -> 16-bit planes [M, F]. */
+int mer_swiglu(const float* y, long long ldy, int M, int F, void* out_hi, void* out_lo, int dtype, mer_stream_t stream);
 
 /* out[n, :] = scale * sum over t of x[n, t, :]   (x fp32 [N, T, D]; token sum / mean of a hidden state). */
 int mer_token_reduce(const float* x, int N, int T, int D, float scale, float* out, mer_stream_t stream);

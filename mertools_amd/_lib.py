@@ -57,7 +57,7 @@ class TfLayer(C.Structure):
 
 class TfConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("layers", c_int), ("pre_ln", c_int),
-                ("act", c_int), ("ln_eps", c_float), ("dtype", c_int), ("passes", c_int), ("gated_rel_pos", c_int), ("mx_skip", c_int)]
+                ("act", c_int), ("ln_eps", c_float), ("dtype", c_int), ("passes", c_int), ("gated_rel_pos", c_int), ("ffn_swiglu", c_int), ("mx_skip", c_int)]
 
 
 class HubertConfig(C.Structure):
@@ -179,6 +179,7 @@ _PROTOS = {
     "mer_lstm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mer_wave_normalize": (c_int, [c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_ll, c_void_p]),
     "mer_image_normalize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mer_swiglu": (c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mer_token_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mer_videomae_create": (c_int, [C.POINTER(VideoMAEConfig), C.POINTER(VideoMAEWeights), C.POINTER(c_void_p)]),
     "mer_videomae_destroy": (None, [c_void_p]),

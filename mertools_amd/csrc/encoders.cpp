@@ -69,6 +69,7 @@ struct TfBufs {
   float* t32;
   float* h1_32;
   P16 cur16, qkv16, ctx16, h1_16, f16;
+  float* ffn32;    // SwiGLU: fp32 [M, 2F] output of weights_in awaiting the gate
   float* gate;     // WavLM: [B, H, T] gate of the current layer
   float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
 };
@@ -83,6 +84,7 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
   b.ctx16 = take16(ar, M * D, lo);
   b.h1_16 = take16(ar, M * D, lo);
   b.f16 = take16(ar, M * F, lo);
+  b.ffn32 = c.ffn_swiglu ? (float*)ar.take(M * 2 * F * 4) : nullptr;
   b.gate = c.gated_rel_pos ? (float*)ar.take(M * c.heads * 4) : nullptr;
   b.gin32 = (c.gated_rel_pos && c.pre_ln) ? (float*)ar.take(M * D * 4) : nullptr;
 }
@@ -132,6 +134,10 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0));
     if (c.pre_ln) {
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.h1_16.hi, b.h1_16.lo, D, dt, st));
+      if (c.ffn_swiglu) {  // weights_in -> fp32 [M, 2F]; silu(first half) * second half -> 16-bit planes [M, F]
+        MER_TRY(gemm(st, dt, ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0));
+        MER_TRY(mer_swiglu(b.ffn32, 2 * F, M, F, b.f16.hi, b.f16.lo, dt, (mer_stream_t)st));
+      } else
       MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
       MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0));
     } else {
@@ -152,6 +158,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
   MER_REQUIRE(c.gated_rel_pos == 0 || c.gated_rel_pos == 1, MER_EINVAL, "%s: gated_rel_pos must be 0 or 1", who);
   MER_REQUIRE(c.mx_skip >= 0 && c.mx_skip <= 7, MER_EINVAL, "%s: mx_skip must be a 3-bit mask", who);
+  MER_REQUIRE(!c.ffn_swiglu || c.pre_ln, MER_EUNSUPPORTED, "%s: the SwiGLU feed-forward is only built for pre-LN blocks", who);
   MER_REQUIRE(c.dtype == MER_DT_F16 || c.dtype == MER_DT_BF16, MER_EINVAL, "%s: bad dtype", who);
   return MER_OK;
 }

@@ -450,6 +450,29 @@ __global__ void image_normalize_u8_kernel(const unsigned char* in, long long npi
   }
 }
 
+// SwiGLU gate of DINOv2-giant's feed-forward: 4 elements per thread, fp32 in, 16-bit planes out
+template <typename T>
+__global__ void swiglu_kernel(const float* y, long long ldy, int M, int F, T* ohi, T* olo) {
+  const long long total4 = (long long)M * F / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4, m = e / F;
+    const int j = (int)(e % F);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(y + m * ldy + j);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(y + m * ldy + F + j);
+    typename T16<T>::v4 h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = a[r] / (1.0f + expf(-a[r])) * b[r];
+      T hh, ll;
+      split16<T>(v, hh, ll);
+      h[r] = hh;
+      l[r] = ll;
+    }
+    *reinterpret_cast<typename T16<T>::v4*>(ohi + e) = h;
+    if (olo) *reinterpret_cast<typename T16<T>::v4*>(olo + e) = l;
+  }
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long g = cdiv(n, block);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -621,4 +644,15 @@ extern "C" int mer_image_normalize_u8(const unsigned char* frames, int N, int H,
   hipLaunchKernelGGL(image_normalize_u8_kernel, dim3(grid_for(hw, 256) > 1024 ? 1024 : grid_for(hw, 256), N), dim3(256), 0,
                      (hipStream_t)stream, frames, hw, bgr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
   return check_launch("image_normalize_u8");
+}
+
+extern "C" int mer_swiglu(const float* y, long long ldy, int M, int F, void* out_hi, void* out_lo, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(y && out_hi && M > 0 && F > 0, MER_EINVAL, "mer_swiglu: bad argument");
+  MER_REQUIRE(F % 4 == 0 && ldy % 4 == 0 && ldy >= 2ll * F, MER_ESHAPE, "mer_swiglu: F and ldy must be multiples of 4, ldy >= 2F");
+  const long long n4 = (long long)M * F / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) hipLaunchKernelGGL((swiglu_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, y, ldy, M, F, (f16*)out_hi, (f16*)out_lo);
+  else hipLaunchKernelGGL((swiglu_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, y, ldy, M, F, (bf16*)out_hi, (bf16*)out_lo);
+  return check_launch("swiglu");
 }

@@ -450,23 +450,25 @@ class HipDinov2Model(_HipModule):
     whose last entry is token-summed.  HF:dinov2/modeling_dinov2.py.  Built for ONE input resolution (`input_size`,
     224 = the processor's crop): the position table is interpolated to that grid once at load time, and the layer-scale
     vectors are folded into the attention-output / fc2 weights and biases (y = x + lambda * (h W^T + b) == x + h (lambda*W)^T
-    + lambda*b), so the blocks are the plain pre-LN blocks of the ViT engine.  SwiGLU (dinov2-giant) is not supported."""
+    + lambda*b), so the blocks are the plain pre-LN blocks of the ViT engine.  dinov2-giant's SwiGLU feed-forward is supported (`use_swiglu_ffn`)."""
 
     def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx", input_size=224):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
         self.device = torch.device(device)
-        if getattr(config, "use_swiglu_ffn", False):
-            raise _lib.MerError("HipDinov2Model: SwiGLU feed-forward (dinov2-giant) is not supported")
+        swiglu = bool(getattr(config, "use_swiglu_ffn", False))   # dinov2-giant
         _, tf_passes = _PREC[precision]
         lo, tmx = tf_passes >= 2, tf_passes == 4
         hold = self._hold = _Holder(device, dtype)
         D, Pz = config.hidden_size, config.patch_size
         ffn = int(D * config.mlp_ratio)
+        if swiglu:
+            ffn = (int(ffn * 2 / 3) + 7) // 8 * 8          # Dinov2SwiGLUFFN: width after the gate
         assert input_size % Pz == 0, "input size must be a multiple of the patch size"
         cfg = VitConfig()
         cfg.tf = _tf_config(D, config.num_attention_heads, ffn, config.num_hidden_layers, True, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+        cfg.tf.ffn_swiglu = int(swiglu)
         cfg.image_size, cfg.patch_size, cfg.channels, cfg.proj_dim, cfg.variant = input_size, Pz, config.num_channels, D, 1
         w = VitWeights()
         pw = sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
@@ -486,8 +488,10 @@ class HipDinov2Model(_HipModule):
                 hold, lo, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"],
                 sd[a + "value.weight"], sd[a + "value.bias"],
                 sd[q + "attention.output.dense.weight"] * l1[:, None], sd[q + "attention.output.dense.bias"] * l1,
-                (sd[q + "norm1.weight"], sd[q + "norm1.bias"]), sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"],
-                sd[q + "mlp.fc2.weight"] * l2[:, None], sd[q + "mlp.fc2.bias"] * l2,
+                (sd[q + "norm1.weight"], sd[q + "norm1.bias"]),
+                sd[q + ("mlp.weights_in.weight" if swiglu else "mlp.fc1.weight")], sd[q + ("mlp.weights_in.bias" if swiglu else "mlp.fc1.bias")],
+                sd[q + ("mlp.weights_out.weight" if swiglu else "mlp.fc2.weight")] * l2[:, None],
+                sd[q + ("mlp.weights_out.bias" if swiglu else "mlp.fc2.bias")] * l2,
                 (sd[q + "norm2.weight"], sd[q + "norm2.bias"]), mx=tmx)
         w.layers = C.cast(layers, C.POINTER(TfLayer))
         self._layers = layers

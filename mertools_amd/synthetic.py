@@ -171,8 +171,13 @@ def dinov2_state_dict(cfg, seed=0):
         sd[p + "norm2.weight"], sd[p + "norm2.bias"] = _ln(g, D)
         sd[p + "layer_scale1.lambda1"] = 0.5 + torch.rand(D, generator=g)
         sd[p + "layer_scale2.lambda1"] = 0.5 + torch.rand(D, generator=g)
-        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = _lin(g, ffn, D)
-        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = _lin(g, D, ffn, std=0.5 / math.sqrt(ffn))
+        if getattr(cfg, "use_swiglu_ffn", False):
+            hf = (int(ffn * 2 / 3) + 7) // 8 * 8
+            sd[p + "mlp.weights_in.weight"], sd[p + "mlp.weights_in.bias"] = _lin(g, 2 * hf, D)
+            sd[p + "mlp.weights_out.weight"], sd[p + "mlp.weights_out.bias"] = _lin(g, D, hf, std=0.5 / math.sqrt(hf))
+        else:
+            sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = _lin(g, ffn, D)
+            sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = _lin(g, D, ffn, std=0.5 / math.sqrt(ffn))
     sd["layernorm.weight"], sd["layernorm.bias"] = _ln(g, D)
     return sd
 

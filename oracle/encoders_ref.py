@@ -268,8 +268,13 @@ def dinov2_hidden_states(sd, cfg, pixel_values):
         att = _mhsa(h, sd[a + "query.weight"], sd[a + "query.bias"], sd[a + "key.weight"], sd[a + "key.bias"], sd[a + "value.weight"],
                     sd[a + "value.bias"], sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"], H)
         x = x + att * sd[p + "layer_scale1.lambda1"]
-        h = _gelu(F.linear(_ln(x, sd, p + "norm2", eps), sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
-        x = x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]) * sd[p + "layer_scale2.lambda1"]
+        if p + "mlp.weights_in.weight" in sd:   # Dinov2SwiGLUFFN (dinov2-giant)
+            y1, y2 = F.linear(_ln(x, sd, p + "norm2", eps), sd[p + "mlp.weights_in.weight"], sd[p + "mlp.weights_in.bias"]).chunk(2, dim=-1)
+            ff = F.linear(F.silu(y1) * y2, sd[p + "mlp.weights_out.weight"], sd[p + "mlp.weights_out.bias"])
+        else:
+            h = _gelu(F.linear(_ln(x, sd, p + "norm2", eps), sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+            ff = F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + ff * sd[p + "layer_scale2.lambda1"]
         hs.append(x)
     return hs
 

@@ -36,6 +36,22 @@ def test_oracle_matches_hf_dinov2():
         assert torch.allclose(R.dinov2_frame_features(sd, vars(c), px), torch.stack(hs)[-1].sum(dim=1), rtol=0, atol=1e-4)
 
 
+def test_oracle_matches_hf_dinov2_swiglu():
+    """dinov2-giant wiring (Dinov2SwiGLUFFN) against the live HF class."""
+    from transformers import Dinov2Config, Dinov2Model
+    c = W.dinov2_config("tiny", use_swiglu_ffn=True)
+    sd = W.dinov2_state_dict(c, 0)
+    m = Dinov2Model(Dinov2Config(hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                                 mlp_ratio=c.mlp_ratio, image_size=c.image_size, patch_size=c.patch_size, layer_norm_eps=c.layer_norm_eps,
+                                 use_swiglu_ffn=True, attn_implementation="eager")).eval()
+    m.load_state_dict(sd, strict=True)
+    px = torch.randn(2, 3, 42, 42, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        hs = m(px, output_hidden_states=True).hidden_states
+    for a, b in zip(R.dinov2_hidden_states(sd, vars(c), px), hs):
+        assert torch.allclose(a, b, rtol=0, atol=1e-5)
+
+
 def test_dinov2_preprocess_matches_hf_processor():
     from PIL import Image
     from mertools_amd.extract.visual import dinov2_preprocess
@@ -71,6 +87,24 @@ def test_dinov2_tiny(dev, precision, tol):
     ref = hs[-1].sum(dim=1)
     assert_close(feats.cpu(), ref, tol, f"dinov2-tiny[{precision}] token-sum features")
     assert_close(utt.cpu(), torch.stack([ref[:4].mean(0), ref[4:].mean(0)]), tol, f"dinov2-tiny[{precision}] UTT")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("accurate", 3e-4), ("mx", 1e-3)])
+def test_dinov2_swiglu_tiny(dev, precision, tol):
+    """dinov2-giant's SwiGLU feed-forward (mer_swiglu between the two FFN GEMMs)."""
+    from mertools_amd.encoders import HipDinov2Model
+    from util import assert_close
+    c = W.dinov2_config("tiny", use_swiglu_ffn=True)
+    sd = W.dinov2_state_dict(c, 0)
+    px = torch.randn(6, 3, 42, 42, generator=torch.Generator().manual_seed(6))
+    ref = R.dinov2_hidden_states(sd, vars(c), px)[-1]
+    m = HipDinov2Model(sd, c, device=dev, precision=precision, input_size=42)
+    out = m(px.to(dev), output_hidden_states=True).hidden_states[-1]
+    feats = m.extract_frames(px.to(dev))
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, tol, f"dinov2-swiglu-tiny[{precision}] last hidden state")
+    assert_close(feats.cpu(), ref.sum(dim=1), tol, f"dinov2-swiglu-tiny[{precision}] token-sum features")
 
 
 @pytest.mark.gpu
