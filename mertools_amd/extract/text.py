@@ -112,3 +112,39 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
                 n_tok = (lens[r] + (end if end is not None else 0)) - start
                 save_embeddings(os.path.join(save_dir, f'{name}.npy'), pooled[r] if n_tok > 0 else [], feature_level, feature_dim)
     print(f'Total {len(df)} files done! Time used ({model_name}): {time.time() - start_time:.1f}s.')
+
+
+def merge_subword_embeddings(tokens, output, sentence, combine_type='mean'):
+    """Sub-word -> word alignment of MER2023/feature_extraction/text/extract_text_embedding_LZ.py:254-292 (English pipeline,
+    SURVEY §8f row 4): `tokens` are the tokenizer's pieces of one sentence (special tokens already stripped), `output` their
+    embeddings [T, D], `sentence` the words that were tokenised (is_split_into_words=True).  Pieces are glued until they spell
+    the current word ('▁' of ALBERT/XLNet and 'Ġ' of RoBERTa/GPT stripped first, '##' of BERT when gluing); a piece equal
+    to the word, or '[UNK]', maps one-to-one.  combine_type: 'sum' | 'mean' | 'last'.  Returns a list of len(sentence) vectors."""
+    n_tokens, n_words = len(output), len(sentence)
+    if n_tokens == n_words:            # :252-254 every sub-word is a word
+        return list(output)
+    sentence_embedding, pointer, word, word_embedding = [], 0, '', []
+    for j, token in enumerate(tokens):
+        token_embedding = output[j]
+        current_word = sentence[pointer]
+        token = token.replace('▁', '').replace('Ġ', '')
+        if token == current_word or token == '[UNK]':
+            sentence_embedding.append(token_embedding)
+            pointer += 1
+        else:
+            word_embedding.append(token_embedding)
+            word = word + token.replace('##', '')
+            if word == current_word:
+                if combine_type == 'sum':
+                    merged = np.sum(np.vstack(word_embedding), axis=0)
+                elif combine_type == 'mean':
+                    merged = np.mean(np.vstack(word_embedding), axis=0)
+                elif combine_type == 'last':
+                    merged = word_embedding[-1]
+                else:
+                    raise Exception('Error: not supported type to combine subword embedding.')
+                sentence_embedding.append(merged)
+                word, word_embedding = '', []
+                pointer += 1
+    assert len(sentence) == len(sentence_embedding), f'{len(sentence)} words but {len(sentence_embedding)} merged embeddings: {tokens} / {sentence}'
+    return sentence_embedding
