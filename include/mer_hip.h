@@ -384,6 +384,12 @@ int mer_lstm_fwd(const float* gx, const float* w_hh_t, int B, int T, int H, floa
 int mer_lstm_bwd(const float* dh_last, const float* gates, const float* cs, const float* w_hh, int B, int T, int H,
                  float* dA, mer_stream_t stream);
 
+/* Small fp32 attention (head_dim 64, Tk <= 2048): out[b,tq,h,:] = softmax_k(q[b,tq,h,:]·k[b,k,h,:] * scale [masked k > tq if causal]) v.
+ * q [B*Tq, ldq], k / v [B*Tk, ldkv], out [B*Tq, ldo], head h at column 64h.  Decoder-side work of Whisper (two tokens per clip:
+ * causal self-attention and cross-attention to the 1500 encoder states; HF:whisper/modeling_whisper.py WhisperAttention). */
+int mer_small_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, int B, int Tq, int Tk,
+                        int H, float scale, int causal, float* out, long long ldo, mer_stream_t stream);
+
 /* ---- host pre-processing on the GPU (what the reference does on the CPU before the H2D copy) ----
  * mer_wave_normalize: Wav2Vec2FeatureExtractor's per-utterance (x - mean) / sqrt(var + 1e-7) (do_normalize != 0) or a plain
  * conversion, from device int16 PCM (x = pcm / 32768, is_int16 != 0) or device fp32; one row per utterance / chunk.

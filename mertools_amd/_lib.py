@@ -175,6 +175,8 @@ _PROTOS = {
     "mer_attention_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_ll, c_void_p, c_int, c_void_p]),
     "mer_wavlm_gate": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mer_small_attention": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_ll,
+                                    c_void_p]),
     "mer_lstm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mer_lstm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mer_wave_normalize": (c_int, [c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_ll, c_void_p]),

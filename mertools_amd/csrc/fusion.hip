@@ -309,3 +309,68 @@ extern "C" int mer_lstm_bwd(const float* dh_last, const float* gates, const floa
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(4 * H), 0, (hipStream_t)stream, dh_last, gates, cs, w_hh, T, H, dA);
   return check_launch("lstm_bwd");
 }
+
+// =============================================================================================
+// Small fp32 attention for decoder-side work (Whisper: two decoder tokens attending to themselves and to the 1500 encoder
+// states, HF:whisper/modeling_whisper.py WhisperAttention): one workgroup per (query, head, batch), head_dim 64, Tk <= 2048.
+// =============================================================================================
+namespace mer {
+__global__ __launch_bounds__(256) void small_attention_kernel(const float* __restrict__ q, long long ldq, const float* __restrict__ k,
+                                                              const float* __restrict__ v, long long ldkv, int Tq, int Tk, float scale,
+                                                              int causal, float* __restrict__ out, long long ldo) {
+  __shared__ float sc[2048];
+  __shared__ float qs[64];
+  __shared__ float red[256];
+  const int tq = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  if (tid < 64) qs[tid] = q[((long long)b * Tq + tq) * ldq + h * 64 + tid];
+  __syncthreads();
+  const float* kb = k + (long long)b * Tk * ldkv + h * 64;
+  const float* vb = v + (long long)b * Tk * ldkv + h * 64;
+  float mx = -INFINITY;
+  for (int j = tid; j < Tk; j += 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) s = fmaf(qs[d], kb[(long long)j * ldkv + d], s);
+    s = (causal && j > tq) ? -INFINITY : s * scale;
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  red[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < Tk; j += 256) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  red[tid] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float inv = 1.0f / red[0];
+  __syncthreads();
+  const int d = tid & 63, part = tid >> 6;
+  float acc = 0.f;
+  for (int j = part; j < Tk; j += 4) acc = fmaf(sc[j], vb[(long long)j * ldkv + d], acc);
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < 64) out[((long long)b * Tq + tq) * ldo + h * 64 + tid] = ((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192])) * inv;
+}
+}  // namespace mer
+
+extern "C" int mer_small_attention(const float* q, long long ldq, const float* k, const float* v, long long ldkv, int B, int Tq, int Tk,
+                                   int H, float scale, int causal, float* out, long long ldo, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(q && k && v && out && B > 0 && Tq > 0 && Tk > 0 && H > 0, MER_EINVAL, "mer_small_attention: bad argument");
+  MER_REQUIRE(Tk <= 2048, MER_EUNSUPPORTED, "mer_small_attention: Tk=%d > 2048", Tk);
+  hipLaunchKernelGGL(small_attention_kernel, dim3(Tq, H, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, v, ldkv, Tq, Tk, scale, causal, out, ldo);
+  return check_launch("small_attention");
+}

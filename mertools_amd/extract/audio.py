@@ -72,6 +72,71 @@ def load_model(model_name, gpu, precision="mx"):
     return HipHubertModel.from_hf(hf, device=f'cuda:{max(gpu, 0)}', precision=precision), fe.do_normalize
 
 
+def _slaney_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+
+def _slaney_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+
+def whisper_mel_filters(n_freq=201, n_mels=80, sr=16000):
+    """[n_freq, n_mels] Slaney-scale, Slaney-normalised triangular bank over 0 .. sr/2 (what WhisperFeatureExtractor builds
+    with mel_filter_bank(..., norm="slaney", mel_scale="slaney"); HF:whisper/feature_extraction_whisper.py:90-98)."""
+    edges = _slaney_hz(np.linspace(_slaney_mel(0.0), _slaney_mel(sr / 2.0), n_mels + 2))
+    fft_f = np.linspace(0.0, sr / 2.0, n_freq)
+    width = np.diff(edges)
+    slopes = edges[None, :] - fft_f[:, None]
+    fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / width[:-1], slopes[:, 2:] / width[1:]))
+    return fb * (2.0 / (edges[2:] - edges[:-2]))[None, :]
+
+
+def whisper_log_mel(samples, n_mels=80, n_samples=480000):
+    """WhisperFeatureExtractor.__call__ on one utterance (reference :81; HF:whisper/feature_extraction_whisper.py:100-130,
+    :260-330): zero-pad / cut to 30 s, |STFT|^2 (400-point periodic Hann, hop 160, reflect-centred), mel, log10 floored at
+    1e-10, last frame dropped, clamp to max - 8, (x + 4) / 4 -> float32 [1, n_mels, 3000]."""
+    x = np.zeros(n_samples, dtype=np.float32)
+    w = np.asarray(samples, dtype=np.float32)[:n_samples]
+    x[:len(w)] = w
+    win = torch.hann_window(400, periodic=True, dtype=torch.float64)
+    spec = torch.stft(torch.from_numpy(x).double(), 400, hop_length=160, window=win, center=True, pad_mode="reflect", return_complex=True)
+    power = spec.abs().pow(2).numpy()                                             # [201, 3001]
+    mel = whisper_mel_filters(201, n_mels).T @ power
+    log_spec = np.log10(np.maximum(mel, 1e-10))[:, :-1]
+    log_spec = np.maximum(log_spec, log_spec.max() - 8.0)
+    return torch.from_numpy(((log_spec + 4.0) / 4.0).astype(np.float32))[None]
+
+
+def load_whisper(model_name, gpu, precision="mx"):
+    from transformers import AutoModel
+    from .. import config
+    from ..whisper import HipWhisperModel
+    model_file = os.path.join(config.PATH_TO_PRETRAINED_MODELS, f'transformers/{model_name}')
+    return HipWhisperModel.from_hf(AutoModel.from_pretrained(model_file), device=f'cuda:{max(gpu, 0)}', precision=precision)
+
+
+def extract_whisper(model_name, audio_files, save_dir, feature_level, gpu, model=None, batch_clips=16, reader=read_audio):
+    """WHISPER_BASE / WHISPER_LARGE branch (reference :79-89): every clip is one fixed 30 s log-mel window, so clips batch
+    without bucketing; the two decoder states come back as (2, D) per clip (FRAME) or their mean (UTTERANCE, reference :103-108)."""
+    start_time = time.time()
+    if model is None:
+        model = load_whisper(model_name, gpu)
+    os.makedirs(save_dir, exist_ok=True)
+    for i in range(0, len(audio_files), batch_clips):
+        group = audio_files[i:i + batch_clips]
+        mels = []
+        for audio_file in group:
+            samples, sr = reader(audio_file)
+            assert sr == 16000, 'currently, we only test on 16k audio'
+            mels.append(whisper_log_mel(samples, model.config.num_mel_bins, 320 * model.config.max_source_positions))
+        feats = model.extract_utterance(torch.cat(mels, 0)).cpu().numpy()       # [B, 2, D]
+        for audio_file, feat in zip(group, feats):
+            save_feature(os.path.join(save_dir, f'{os.path.basename(audio_file)[:-4]}.npy'), feat, feature_level)
+    print(f'Total time used: {time.time() - start_time:.1f}s.')
+
+
 def device_normalize(samples, do_normalize, device):
     """wav2vec2_normalize on the GPU: the utterance goes up as 16-bit PCM when it is exactly representable (what a PCM16 file
     holds: half the H2D bytes of fp32, a quarter of the float64 the reference moves), else as fp32; mer_wave_normalize."""

@@ -148,6 +148,21 @@ def image_normalize_u8(frames, mean, std, bgr=True):
     return out
 
 
+def small_attention(q, k, v, B, Tq, Tk, H, scale, causal=False):
+    """fp32 attention for a handful of queries: q [B*Tq, H*64], k / v [B*Tk, H*64] (same row stride) -> [B*Tq, H*64]."""
+    assert q.dtype == k.dtype == v.dtype == torch.float32 and k.stride(0) == v.stride(0)
+    out = torch.empty((B * Tq, H * 64), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().mer_small_attention(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), B, Tq, Tk, H, float(scale), int(causal),
+                                              _p(out), out.stride(0), stream()), "mer_small_attention")
+    return out
+
+
+def add_pos(x, pos):
+    """x[r, :] += pos[r % P, :] in place (x fp32 [rows, D], pos fp32 [P, D])."""
+    _lib.check(_lib.lib().mer_add_pos(_p(x), _p(pos), x.shape[0], pos.shape[0], x.shape[1], stream()), "mer_add_pos")
+    return x
+
+
 def attention_bias(qkv, B, T, H, scale, bias, *, gate=None, kv_len=None):
     """attention() with scores += gate[b,h,q] * bias[h,q,k].  bias: fp32 [H, T, ldb] (ldb % 4 == 0), gate: fp32 [B,H,T] or None."""
     D = H * 64

@@ -268,6 +268,53 @@ def synth_video(B, F=16, S=224, seed=1238):
     return ((px - mean) / std).permute(0, 1, 4, 2, 3).contiguous()
 
 
+def whisper_config(size="base", **over):
+    """WhisperConfig fields the forward needs (whisper-base: 512 / 6+6 layers / 8 heads; large-v2: 1280 / 32+32 / 20 heads)."""
+    base = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8, encoder_ffn_dim=2048,
+                decoder_ffn_dim=2048, num_mel_bins=80, max_source_positions=1500, max_target_positions=448, vocab_size=51865,
+                decoder_start_token_id=50258, pad_token_id=50257, model_type="whisper")
+    if size == "large":
+        base.update(d_model=1280, encoder_layers=32, decoder_layers=32, encoder_attention_heads=20, decoder_attention_heads=20,
+                    encoder_ffn_dim=5120, decoder_ffn_dim=5120)
+    if size == "tiny":
+        base.update(d_model=128, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=256,
+                    decoder_ffn_dim=256, max_source_positions=100, max_target_positions=8, vocab_size=64, decoder_start_token_id=3, pad_token_id=2)
+    base.update(over)
+    return SimpleNamespace(**base)
+
+
+def whisper_state_dict(cfg, seed=0):
+    g = _g(seed)
+    D = cfg.d_model
+    sd = {"encoder.conv1.weight": torch.randn(D, cfg.num_mel_bins, 3, generator=g) * math.sqrt(1.0 / (3 * cfg.num_mel_bins)),
+          "encoder.conv1.bias": torch.randn(D, generator=g) * 0.05,
+          "encoder.conv2.weight": torch.randn(D, D, 3, generator=g) * math.sqrt(1.0 / (3 * D)),
+          "encoder.conv2.bias": torch.randn(D, generator=g) * 0.05,
+          "encoder.embed_positions.weight": torch.randn(cfg.max_source_positions, D, generator=g) * 0.3,
+          "decoder.embed_tokens.weight": torch.randn(cfg.vocab_size, D, generator=g) * 0.5,
+          "decoder.embed_positions.weight": torch.randn(cfg.max_target_positions, D, generator=g) * 0.3}
+    sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"] = _ln(g, D)
+    sd["decoder.layer_norm.weight"], sd["decoder.layer_norm.bias"] = _ln(g, D)
+
+    def attn(p):
+        for nme in ("q_proj", "v_proj", "out_proj"):
+            sd[p + nme + ".weight"], sd[p + nme + ".bias"] = _lin(g, D, D)
+        sd[p + "k_proj.weight"], _ = _lin(g, D, D)
+
+    for side, nl, ffn in (("encoder", cfg.encoder_layers, cfg.encoder_ffn_dim), ("decoder", cfg.decoder_layers, cfg.decoder_ffn_dim)):
+        for l in range(nl):
+            p = f"{side}.layers.{l}."
+            attn(p + "self_attn.")
+            sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"] = _ln(g, D)
+            if side == "decoder":
+                attn(p + "encoder_attn.")
+                sd[p + "encoder_attn_layer_norm.weight"], sd[p + "encoder_attn_layer_norm.bias"] = _ln(g, D)
+            sd[p + "fc1.weight"], sd[p + "fc1.bias"] = _lin(g, ffn, D)
+            sd[p + "fc2.weight"], sd[p + "fc2.bias"] = _lin(g, D, ffn, std=0.5 / math.sqrt(ffn))
+            sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = _ln(g, D)
+    return sd
+
+
 def bert_config(size="roberta-base", **over):
     base = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=50265,
                 max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5, hidden_act="gelu",

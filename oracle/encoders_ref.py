@@ -438,3 +438,52 @@ def bert_cfg_from_hf(c):
                 hidden_size=c.hidden_size, intermediate_size=c.intermediate_size, layer_norm_eps=c.layer_norm_eps,
                 vocab_size=c.vocab_size, max_position_embeddings=c.max_position_embeddings,
                 type_vocab_size=c.type_vocab_size, hidden_act=c.hidden_act)
+
+
+# ------------------------------------------------------------------------------------------------
+# Whisper  (HF:whisper/modeling_whisper.py; reference branch extract_audio_huggingface.py:82-90)
+# ------------------------------------------------------------------------------------------------
+def _whisper_attn(xq, xkv, sd, p, heads, causal=False):
+    """WhisperAttention: q/v/out with bias, k without; q scaled by head_dim**-0.5; optional causal mask (decoder self-attention)."""
+    B, Tq, D = xq.shape
+    Tk = xkv.shape[1]
+    d = D // heads
+    q = (F.linear(xq, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * d ** -0.5).view(B, Tq, heads, d).transpose(1, 2)
+    k = F.linear(xkv, sd[p + "k_proj.weight"]).view(B, Tk, heads, d).transpose(1, 2)
+    v = F.linear(xkv, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"]).view(B, Tk, heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(2, 3))
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), diagonal=1), float("-inf"))
+    o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, Tq, D)
+    return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+
+
+def whisper_encoder(sd, cfg, input_features):
+    """WhisperEncoder.forward: input_features [B, n_mels, 2*max_source_positions] -> [B, max_source_positions, D]."""
+    x = _gelu(F.conv1d(input_features, sd["encoder.conv1.weight"], sd["encoder.conv1.bias"], padding=1))
+    x = _gelu(F.conv1d(x, sd["encoder.conv2.weight"], sd["encoder.conv2.bias"], stride=2, padding=1))
+    x = x.permute(0, 2, 1) + sd["encoder.embed_positions.weight"]
+    H = cfg["encoder_attention_heads"]
+    for l in range(cfg["encoder_layers"]):
+        p = f"encoder.layers.{l}."
+        x = x + _whisper_attn(_ln(x, sd, p + "self_attn_layer_norm", 1e-5), _ln(x, sd, p + "self_attn_layer_norm", 1e-5), sd, p + "self_attn.", H)
+        h = _gelu(F.linear(_ln(x, sd, p + "final_layer_norm", 1e-5), sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+        x = x + F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return _ln(x, sd, "encoder.layer_norm", 1e-5)
+
+
+def whisper_last_hidden_state(sd, cfg, input_features, decoder_input_ids):
+    """`model(input_features, decoder_input_ids=decoder_input_ids).last_hidden_state` (extract_audio_huggingface.py:87): the
+    DECODER's final hidden states [B, T_dec, D] (the reference feeds two start tokens and saves the (2, D) result)."""
+    enc = whisper_encoder(sd, cfg, input_features)
+    Td = decoder_input_ids.shape[1]
+    x = sd["decoder.embed_tokens.weight"][decoder_input_ids] + sd["decoder.embed_positions.weight"][:Td]
+    H = cfg["decoder_attention_heads"]
+    for l in range(cfg["decoder_layers"]):
+        p = f"decoder.layers.{l}."
+        h = _ln(x, sd, p + "self_attn_layer_norm", 1e-5)
+        x = x + _whisper_attn(h, h, sd, p + "self_attn.", H, causal=True)
+        x = x + _whisper_attn(_ln(x, sd, p + "encoder_attn_layer_norm", 1e-5), enc, sd, p + "encoder_attn.", H)
+        h = _gelu(F.linear(_ln(x, sd, p + "final_layer_norm", 1e-5), sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+        x = x + F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return _ln(x, sd, "decoder.layer_norm", 1e-5)

@@ -16,7 +16,7 @@ run() { # name timeout cmd...
 if [[ $what == tests || $what == all ]]; then
   run ops 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x --no-header -p no:cacheprovider
   run enc 900 python -m pytest tests/test_encoders_gpu.py -m gpu -q --no-header -p no:cacheprovider -s
-  run fusion 900 python -m pytest tests/test_fusion_gpu.py tests/test_extract_gpu.py tests/test_dinov2.py tests/test_affectgpt.py -m gpu -q --no-header -p no:cacheprovider
+  run fusion 900 python -m pytest tests/test_fusion_gpu.py tests/test_extract_gpu.py tests/test_dinov2.py tests/test_affectgpt.py tests/test_whisper.py -m gpu -q --no-header -p no:cacheprovider
   run smoke 300 python __graft_entry__.py smoke
 fi
 if [[ $what == bench || $what == all ]]; then
