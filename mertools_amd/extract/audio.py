@@ -15,6 +15,8 @@ import numpy as np
 import torch
 
 MAXLEN = 16000 * 10
+WHISPER_BASE = 'whisper-base'        # reference :35-36
+WHISPER_LARGE = 'whisper-large-v2'
 
 
 def split_into_batch(input_values, maxlen=MAXLEN):
@@ -153,6 +155,8 @@ def device_normalize(samples, do_normalize, device):
 def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
             reader=read_audio, device_preprocess=False):
     """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy."""
+    if model_name in (WHISPER_BASE, WHISPER_LARGE) or type(model).__name__ == 'HipWhisperModel':
+        return extract_whisper(model_name, audio_files, save_dir, feature_level, gpu, model=model, reader=reader)   # reference :79-89
     start_time = time.time()
     if model is None:
         model, do_normalize = load_model(model_name, gpu)
