@@ -1,0 +1,305 @@
+// ceiling_probe.hip — standalone (no torch) measurement of the ceilings that bound gemm16's tile on gfx950:
+//   ring:   the K loop's data path in isolation — an NS-stage LDS ring of 256x256x32 f16 slabs filled by LDS-DMA
+//           (global_load_lds_dwordx4, counted vmcnt, one s_barrier per slab), optionally with the fragment reads
+//           (ds_read_b128) and the MFMAs of a register-double-buffered K loop.  NW = 8: 2x4 waves of 128x64 (gemm16's
+//           wave grid, 256 registers); NW = 4: 2x2 waves of 128x128 (one wave per SIMD, accumulators in 256 AGPRs).
+//           Answers: how many L2->LDS bytes per clock per CU the DMA path sustains with every CU streaming, and what a
+//           single-barrier, software-pipelined K loop would cost per slab next to gemm16's two-phase schedule.
+//   store:  the epilogue's store path in isolation — every wave writes 16-byte lane stores whose lanes cover row
+//           segments of SEG bytes (gemm16 today: 128 B for f16 outputs of a 64-column wave tile).
+// Output: one JSON object per line on stdout.  Numerical results are meaningless (inputs are zero-filled); only the
+// instruction streams and the memory traffic are real.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ceiling_probe.bin ceiling_probe.hip   (scripts/probes/build_probes.sh)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include <vector>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+struct RingParams {
+  const f16* a; const f16* w;
+  int M, N, K, tiles_m, tiles_n;
+  unsigned long long* stamps;   // 2 per workgroup: start, end (s_memtime)
+  float* sink;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ int swz4(int row) { return (-(row >> 2)) & 3; }   // conflict-free for 64-byte LDS rows
+
+// MODE bit 0: fragment reads, bit 1: MFMAs (implies bit 0), bit 2: no DMA at all (MFMA / ds_read ceiling on stale LDS)
+// MF: MFMA shape, 16 = v_mfma_f32_16x16x32_f16 (gemm16's), 32 = v_mfma_f32_32x32x16_f16 (half the instructions per slab)
+template <int NW, int NS, int MODE, int MF = 16>
+__global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
+  constexpr int BM = 256, BN = 256, BK = 32, RB = BK * 2;
+  constexpr int A_PLANE = BM * RB, STAGE = (BM + BN) * RB;      // 32 KB per slab
+  constexpr int WM = 2, WN = NW / 2;
+  constexpr int SM = BM / WM, SN = BN / WN, TM = SM / 16, TN = SN / 16;
+  constexpr int PA = 16 / NW * 1;          // 1-KiB DMA pieces of the A plane per wave per slab (16 pieces per plane)
+  constexpr int LPS = 2 * PA;
+  constexpr int D = NS - 1;
+  constexpr bool READS = (MODE & 3) != 0, MATH = (MODE & 2) != 0, NODMA = (MODE & 4) != 0;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, li = lane & 15, lg = lane >> 4;
+  if (tid == 0) p.stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+
+  // XCD-aware bijective tile map (same idea as gemm16: blocks b, b+8, .. share an XCD and get neighbouring tiles)
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int L = blockIdx.x, xcd = L & 7, loc = L >> 3, q = nblk >> 3, r = nblk & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+
+  // DMA piece j of a plane = tile rows 16j .. 16j+15 (lane l: row 16j + l/4, physical chunk l%4 <- logical chunk ^ swizzle)
+  unsigned a_src[PA], w_src[PA];   // element offsets (< 2^32: the probe matrices are < 4 G elements)
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int j = wave + i * NW, row = 16 * j + (lane >> 2), ch = (lane & 3) ^ swz4(row);
+    int m = tm * BM + row; m = m < p.M ? m : p.M - 1;
+    int n = tn * BN + row; n = n < p.N ? n : p.N - 1;
+    a_src[i] = (unsigned)m * (unsigned)p.K + ch * 8;
+    w_src[i] = (unsigned)n * (unsigned)p.K + ch * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+    if (NODMA) return;
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + kt * BK), (lds_void_t*)(base + (wave + i * NW) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + kt * BK), (lds_void_t*)(base + A_PLANE + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[TM][TN];
+  f32x16 acc32[TM / 2][TN / 2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TM / 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN / 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  f16x8 fa[2][TM], fw[2][TN];
+  u32x4 keep = {0u, 0u, 0u, 0u};
+  // MF == 32: entry 2*tile + h holds k-half h of a 32-row tile (lane l: row l % 32, 16-byte chunk 2h + l / 32)
+  auto load_frags = [&](const char* base, int buf) {
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+      const int row = MF == 16 ? wm * SM + mt * 16 + li : wm * SM + (mt >> 1) * 32 + (lane & 31);
+      const int ch = MF == 16 ? lg : 2 * (mt & 1) + (lane >> 5);
+      fa[buf][mt] = *reinterpret_cast<const f16x8*>(base + row * RB + ((ch ^ swz4(row)) << 4));
+    }
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int row = MF == 16 ? wn * SN + nt * 16 + li : wn * SN + (nt >> 1) * 32 + (lane & 31);
+      const int ch = MF == 16 ? lg : 2 * (nt & 1) + (lane >> 5);
+      fw[buf][nt] = *reinterpret_cast<const f16x8*>(base + A_PLANE + row * RB + ((ch ^ swz4(row)) << 4));
+    }
+  };
+  auto consume = [&](int buf) {
+    if (MATH && MF == 32) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < TM / 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN / 2; ++nt)
+            acc32[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][2 * mt + h], fw[buf][2 * nt + h], acc32[mt][nt], 0, 0, 0);
+    } else if (MATH) {
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][mt], fw[buf][nt], acc[mt][nt], 0, 0, 0);
+    } else if (READS) {
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) keep ^= __builtin_bit_cast(u32x4, fa[buf][mt]);
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) keep ^= __builtin_bit_cast(u32x4, fw[buf][nt]);
+    }
+  };
+
+  const int nk = p.K / BK;
+  // prologue: D slabs in flight, slab 0 landed, its fragments in buffer 0
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nk) issue(s, s);
+  if (nk >= D) wait_vmcnt<LPS*(D - 1)>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (READS) load_frags(smem, 0);
+  int nxt = D, rd = 1;   // stage to refill with slab kt+D / stage holding slab kt+1
+  // software-pipelined loop, two slabs per trip so that the fragment buffer index is static
+  auto body = [&](int kt, auto buf_tag) {
+    constexpr int buf = decltype(buf_tag)::value;
+    const bool more = kt + D < nk;
+    if (more) issue(kt + D, nxt);                       // refills the stage of slab kt-1 (all its reads retired before the last barrier)
+    if (more) wait_vmcnt<LPS*(D - 1)>(); else wait_vmcnt<0>();   // my share of slab kt+1 has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of slab kt (issued last trip) have retired
+    __builtin_amdgcn_s_barrier();
+    if (READS) load_frags(smem + rd * STAGE, buf ^ 1);   // slab kt+1 -> the other buffer (last trip: a stale stage, harmless; a branch here
+                                                         // would make hipcc drain lgkmcnt at the join), in the shadow of ...
+    consume(buf);                                        // ... the MFMAs of slab kt
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    rd = rd + 1 == NS ? 0 : rd + 1;
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) { body(kt, std::integral_constant<int, 0>{}); body(kt + 1, std::integral_constant<int, 1>{}); }
+  if (kt < nk) body(kt, std::integral_constant<int, 0>{});
+
+  float s = 0.f;
+  if (MATH) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+#pragma unroll
+    for (int i = 0; i < TM / 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN / 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc32[i][j][e];
+  }
+  s += (float)(keep[0] ^ keep[1] ^ keep[2] ^ keep[3]);
+  if (s == 12345.678f) p.sink[tid] = s;   // never true for zero inputs: keeps the work alive without a store
+  __syncthreads();
+  if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+}
+
+// store probe: a workgroup of NW waves writes a 256 x 256 tile of ELEM-byte outputs (ELEM = 2: 128 KB, 4: 256 KB) with
+// 16-byte lane stores; SEG = bytes of one row that consecutive lanes of a wave cover (SEG/16 lanes per row).
+struct StoreParams { char* c; long long ldc_bytes; int tiles_m, tiles_n; unsigned long long* stamps; };
+
+template <int NW, int SEG, int ELEM>
+__global__ __launch_bounds__(NW * 64) void store_kernel(const StoreParams p) {
+  constexpr int ROWB = 256 * ELEM;              // bytes of one tile row
+  constexpr int LPR = SEG / 16;                 // lanes per row segment
+  constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+  constexpr int SEGS = ROWB / SEG;              // segments per tile row
+  static_assert(SEGS <= NW && NW % SEGS == 0, "a wave owns one column segment");
+  constexpr int G = NW / SEGS;                  // waves stacked over the rows of one column segment
+  constexpr int WROWS = 256 / G;                // rows per wave (a wave tile of WROWS x SEG bytes, like gemm16's wave tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) p.stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int L = blockIdx.x, xcd = L & 7, loc = L >> 3, q = nblk >> 3, r = nblk & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+  char* base = p.c + (long long)tm * 256 * p.ldc_bytes + (long long)tn * ROWB;
+  const int seg = wave % SEGS, row0 = (wave / SEGS) * WROWS + lane / LPR;
+  const u32x4 v = {(unsigned)tid, 1u, 2u, 3u};
+#pragma unroll 8
+  for (int i = 0; i < WROWS / RPI; ++i)
+    *reinterpret_cast<u32x4*>(base + (long long)(row0 + i * RPI) * p.ldc_bytes + seg * SEG + (lane % LPR) * 16) = v;
+  __syncthreads();
+  if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+}
+
+static double avg_cycles(const std::vector<unsigned long long>& st, int n) {
+  double s = 0;
+  for (int i = 0; i < n; ++i) s += (double)(st[2 * i + 1] - st[2 * i]);
+  return s / n;
+}
+
+template <typename F>
+static float time_launches(F&& launch, int warm, int reps) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < warm; ++i) launch();
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  return ms * 1e3f / reps;   // us per launch
+}
+
+template <int NW, int NS, int MODE, int MF = 16>
+static void run_ring(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
+  RingParams p{a, w, M, N, K, (M + 255) / 256, (N + 255) / 256, d_st, sink};
+  const int nblk = p.tiles_m * p.tiles_n;
+  float us = time_launches([&] { hipLaunchKernelGGL((ring_kernel<NW, NS, MODE, MF>), dim3(nblk), dim3(NW * 64), 0, 0, p); }, warm, reps);
+  std::vector<unsigned long long> st(2 * nblk);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
+  const double bytes = (double)nblk * nk * 32768.0, flops = 2.0 * p.tiles_m * 256.0 * p.tiles_n * 256.0 * K;
+  printf("{\"probe\": \"ring\", \"name\": \"%s\", \"waves\": %d, \"stages\": %d, \"mode\": %d, \"mfma\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, "
+         "\"us\": %.1f, \"cycles_per_tile\": %.0f, \"cycles_per_slab\": %.0f, \"dma_B_per_clk_per_CU\": %.1f, \"dma_TBps_chip\": %.2f, \"mfma_TFLOPs\": %.0f}\n",
+         name, NW, NS, MODE, MF, M, N, K, nblk, us, cyc, cyc / nk, (MODE & 4) ? 0.0 : 32768.0 * nk / cyc, (MODE & 4) ? 0.0 : bytes / us * 1e-6,
+         (MODE & 2) ? flops / us * 1e-6 : 0.0);
+  fflush(stdout);
+}
+
+template <int NW, int SEG, int ELEM>
+static void run_store(char* c, int M, int N, unsigned long long* d_st, int warm, int reps) {
+  StoreParams p{c, (long long)N * ELEM, M / 256, N / 256, d_st};
+  const int nblk = p.tiles_m * p.tiles_n;
+  float us = time_launches([&] { hipLaunchKernelGGL((store_kernel<NW, SEG, ELEM>), dim3(nblk), dim3(NW * 64), 0, 0, p); }, warm, reps);
+  std::vector<unsigned long long> st(2 * nblk);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  const double cyc = avg_cycles(st, nblk), tile_bytes = 65536.0 * ELEM;
+  printf("{\"probe\": \"store\", \"waves\": %d, \"seg_bytes\": %d, \"elem_bytes\": %d, \"M\": %d, \"N\": %d, \"tiles\": %d, \"us\": %.1f, "
+         "\"cycles_per_tile\": %.0f, \"B_per_clk_per_CU\": %.1f, \"TBps_chip\": %.2f}\n",
+         NW, SEG, ELEM, M, N, nblk, us, cyc, tile_bytes / cyc, (double)nblk * tile_bytes / us * 1e-6);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const int warm = argc > 1 ? atoi(argv[1]) : 20, reps = argc > 2 ? atoi(argv[2]) : 40;
+  const int M = 100864;          // CLIP-ViT-B/16 at 64 clips x 8 frames x 197 tokens (bench.py's visual leg)
+  const int KMAX = 3072, NMAX = 3072;
+  f16 *a, *w; char* c; unsigned long long* st; float* sink;
+  CK(hipMalloc(&a, (size_t)M * KMAX * 2)); CK(hipMemset(a, 0, (size_t)M * KMAX * 2));
+  CK(hipMalloc(&w, (size_t)NMAX * KMAX * 2)); CK(hipMemset(w, 0, (size_t)NMAX * KMAX * 2));
+  CK(hipMalloc(&c, (size_t)M * NMAX * 4));
+  CK(hipMalloc(&st, 16 * 8192)); CK(hipMalloc(&sink, 4096));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_khz\": %d}\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
+
+  // --- the K loop's data path; shapes: CLIP QKV (N=2304, K=768), fc2 (N=768, K=3072)
+#define RING_SET(NW, NS, MODE, NAME) RING_SET_MF(NW, NS, MODE, 16, NAME)
+#define RING_SET_MF(NW, NS, MODE, MF, NAME) \
+  run_ring<NW, NS, MODE, MF>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
+  run_ring<NW, NS, MODE, MF>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
+  RING_SET(8, 4, 0, "dma only, 8 waves")
+  RING_SET(4, 4, 0, "dma only, 4 waves")
+  RING_SET(8, 4, 1, "dma + fragment reads, 8 waves (128x64 per wave)")
+  RING_SET(4, 4, 1, "dma + fragment reads, 4 waves (128x128 per wave)")
+  RING_SET(4, 4, 6, "mfma + fragment reads, no dma, 4 waves")
+  RING_SET(8, 4, 6, "mfma + fragment reads, no dma, 8 waves")
+  RING_SET(4, 4, 3, "pipelined K loop, 4 waves x 128x128 (1 wave/SIMD)")
+  RING_SET(4, 3, 3, "pipelined K loop, 4 waves x 128x128, 3 stages")
+  RING_SET(8, 4, 3, "pipelined K loop, 8 waves x 128x64 (single barrier)")
+  RING_SET_MF(4, 4, 6, 32, "mfma 32x32x16 + fragment reads, no dma, 4 waves")
+  RING_SET_MF(4, 4, 3, 32, "pipelined K loop, 4 waves x 128x128, 32x32x16 mfma")
+  RING_SET_MF(8, 4, 3, 32, "pipelined K loop, 8 waves x 128x64, 32x32x16 mfma")
+
+  // --- the epilogue's store path: f16 (QKV / fc1 outputs) and fp32 (residual stream) tiles
+  run_store<8, 128, 2>(c, M, 2304, st, warm, reps);
+  run_store<8, 256, 2>(c, M, 2304, st, warm, reps);
+  run_store<8, 512, 2>(c, M, 2304, st, warm, reps);
+  run_store<4, 128, 2>(c, M, 2304, st, warm, reps);
+  run_store<4, 512, 2>(c, M, 2304, st, warm, reps);
+  run_store<8, 256, 4>(c, M, 768, st, warm, reps);
+  run_store<8, 512, 4>(c, M, 768, st, warm, reps);
+  run_store<8, 1024, 4>(c, M, 768, st, warm, reps);
+  return 0;
+}
