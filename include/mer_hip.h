@@ -95,8 +95,19 @@ typedef struct {
    * needs M % T == 0, N % (64*H) == 0, c16_hi, no batching. */
   int headmajor_T, headmajor_H;
   const void* w_mx;   /* passes == 4: packed MX-fp4 residual plane of W (mer_mx_pack), 16-byte aligned */
+  /* optional pre-blocked copies of w_hi / w_lo (mer_w_block_pack): used instead of the row-major planes by the
+   * 256x256 LDS-DMA kernels (a DMA piece becomes 1 KiB contiguous); NULL = not available.  w_lo_blk is only
+   * needed for passes 2 / 3. */
+  const void* w_hi_blk; const void* w_lo_blk;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
+
+/* Pre-blocked weight plane: a DEVICE 16-bit plane w [N, K] (row stride ldw, K % 32 == 0) is re-laid as
+ * [ceil(N/256)][K/32] blocks of 16 KB, each the exact LDS image (256 rows x 64 B, 16-byte chunks XOR-swizzled) of
+ * that (column tile, k-slab) — rows beyond N repeat row N-1.  out: DEVICE buffer of mer_w_block_bytes(N, K) bytes.
+ * Row-range views stay addressable: the block of column tile t starts at byte t * 256 * K * 2. */
+long long mer_w_block_bytes(int N, int K);
+int mer_w_block_pack(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream);
 
 /* Host-side packer of the MX correction plane.  w_res: HOST fp32 [N, K] (row stride ldw) = W - f16(W);
  * out: HOST buffer of mer_mx_packed_bytes(N, K) bytes (then copied to the device once).  Per (256-column tile,
@@ -229,7 +240,8 @@ int mer_inc_i32(int* x, mer_stream_t stream);
 /* Encoder level                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-typedef struct { const void* hi; const void* lo; const void* mx; } mer_w16; /* 16-bit weight planes [N,K] (+ MX residual plane for passes == 4, may be null) */
+typedef struct { const void* hi; const void* lo; const void* mx;   /* 16-bit weight planes [N,K] (+ MX residual plane for passes == 4, may be null) */
+                 const void* hi_blk; const void* lo_blk; } mer_w16;   /* optional pre-blocked copies of hi / lo (mer_w_block_pack), may be null */
 
 /* One transformer block (HuBERT / wav2vec2 / CLIP-ViT / VideoMAE / BERT / RoBERTa).
  * wqkv = cat(q,k,v) rows [3D, D]; bqkv fp32 [3D] (zeros where the model has no bias). */

@@ -53,6 +53,7 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
   g.a_hi = a.hi; g.a_lo = a.lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.w_mx = w.mx; g.ldw = K;
+  g.w_hi_blk = w.hi_blk; g.w_lo_blk = w.lo_blk;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
@@ -110,11 +111,14 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx) {
       // Q | K columns: one f16 pass (weight rounding there only perturbs softmax logits: no measurable effect on the features);
       // V columns: MX-corrected.  The MX plane is stored per 256-column tile, so the V block starts at tile 2D/256.
-      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr};
+      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr};
       MER_TRY(gemm(st, dt, 1, M, 2 * D, D, b.cur16, D, wqk, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
       const long long woff = (long long)2 * D * D * 2;   // bytes into the 16-bit planes
       const mer_w16 wv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
-                          (const char*)w.wqkv.mx + (long long)(2 * D / 256) * (D / 32) * 5120};
+                          (const char*)w.wqkv.mx + (long long)(2 * D / 256) * (D / 32) * 5120,
+                          // the pre-blocked planes are stored per 256-row tile as well: tile 2D/256 starts woff bytes in
+                          w.wqkv.hi_blk ? (const char*)w.wqkv.hi_blk + woff : nullptr,
+                          w.wqkv.lo_blk ? (const char*)w.wqkv.lo_blk + woff : nullptr};
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
       MER_TRY(gemm(st, dt, 4, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D));
     } else
@@ -319,6 +323,7 @@ extern "C" int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, in
     g.a_hi = src.hi; g.a_lo = src.lo; g.lda = (long long)c.conv_stride[i] * C;
     g.a_rows_per_batch = p.T[i]; g.a_batch_stride = (long long)p.T[i - 1] * C;
     g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.w_mx = w.conv_w[i].mx; g.ldw = g.K;
+    g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk;
     g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
     if (c.feat_norm_group) {

@@ -34,6 +34,7 @@ struct Gemm16Params {
   const void* a_hi; const void* a_lo; long long lda; int a_rpb; long long a_bstride;
   const void* w_hi; const void* w_lo; long long ldw;
   const void* w_mx;   // MX kernel: packed fp4 + E8M0 correction plane (mer_mx_pack)
+  int w_blk;          // w_hi / w_lo are pre-blocked planes (mer_w_block_pack): [n-tile of 256][32-deep k-slab][the 16 KB LDS image]
   const float* bias; int act;
   const float* residual; long long ldr;
   float* c32; long long ldc32;
@@ -186,6 +187,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       n = n < p.N ? n : p.N - 1;
       w_off[i] = (long long)n * p.ldw;
       w_src[i] = w_off[i] + ((ld_ch ^ swz_of<C>(ld_row0 + i * ROWS_PER_IT)) << 3);
+      // pre-blocked W: the plane of (n-tile, k-slab) is the LDS image itself (swizzle applied by the packer), so a wave's
+      // DMA piece is 1 KiB contiguous in memory — whole 128-byte lines instead of sixteen 64-byte row runs, which the
+      // L2 -> LDS path moves ~1.7x faster (scripts/probes/ceiling_probe.hip); slab kt sits BN * BK elements after slab kt-1
+      if (p.w_blk) w_src[i] = ((long long)(n0_ / BN) * (p.K / BK)) * (BN * BK) + (long long)(ld_row0 + i * ROWS_PER_IT) * BK + ld_ch * 8;
     }
   };
   setup_loads(m0, n0);
@@ -242,12 +247,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     for (int i = 0; i < CW; ++i) w_o32[i] = (unsigned)(w_src[i] * 2);
     mx_o32 = (unsigned)((tid < 320 ? tid : 256 + (tid & 63)) * 16);
   }
+  const long long w_kmul = p.w_blk ? BN : 1;   // element distance of consecutive k (row-major) or of consecutive k-slabs / BK (pre-blocked)
   const char* mx_base = MX ? (const char*)p.w_mx + ((long long)tile_n * ((p.K + BK - 1) / BK)) * MX_BLOCK : nullptr;
   auto glds_issue = [&](int k0, int stage) {
     char* base = smem + stage * STAGE;
     if constexpr (MX) {
       const char* ab = (const char*)a_pl[0] + (long long)k0 * 2;
-      const char* wb = (const char*)w_pl[0] + (long long)k0 * 2;
+      const char* wb = (const char*)w_pl[0] + (long long)k0 * 2 * w_kmul;
       const unsigned lb = lds_offset_of(base) + wave_row0 * RB;
 #pragma unroll
       for (int i = 0; i < CA; ++i) dma16_sbase(ab, a_o32[i], lb + i * ROWS_PER_IT * RB);
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       for (int pl = 0; pl < WP; ++pl)
 #pragma unroll
         for (int i = 0; i < CW; ++i)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(w_pl[pl] + w_src[i] + k0),
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(w_pl[pl] + w_src[i] + k0 * w_kmul),
                                            (lds_void_t*)(base + AP * A_PLANE + pl * W_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
     }
   };
@@ -676,6 +682,7 @@ int g_gemm_skip = 0;
 int g_gemm_stamp = 0;
 int g_gemm_persist = 0;   // mer_set_option("gemm_persist", 1): persistent-tile variant of the 8-wave non-MX kernels
 int g_gemm_glds = 1;
+int g_gemm_wblk = 1;      // mer_set_option("gemm_wblk", 0): ignore pre-blocked weight planes (A/B testing)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>
@@ -761,9 +768,42 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
   if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_wblk") == 0) { mer::g_gemm_wblk = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
+}
+
+// ---- device-side packer of pre-blocked weight planes (weights are prepared once, offline) ----
+namespace mer {
+// one thread per 16-byte chunk: out[(tn, kt)][row r][physical chunk pc] = w[min(tn*256 + r, N-1)][kt*32 + 8*(pc ^ swz(r)) ..]
+__global__ void w_block_pack_kernel(const u32x4* w, long long ldw8, int N, int nk, long long total, u32x4* out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int pc = (int)(idx & 3), r = (int)((idx >> 2) & 255);
+  const long long blk = idx >> 10;
+  const int kt = (int)(blk % nk);
+  const long long tn = blk / nk;
+  long long n = tn * 256 + r;
+  n = n < N ? n : N - 1;
+  out[idx] = w[n * ldw8 + kt * 4 + (pc ^ swz_of<4>(r))];
+}
+}  // namespace mer
+
+extern "C" long long mer_w_block_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return (long long)((N + 255) / 256) * 256 * K * 2;
+}
+
+extern "C" int mer_w_block_pack(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(w && out, MER_EINVAL, "mer_w_block_pack: null pointer");
+  MER_REQUIRE(N > 0 && K > 0 && K % 32 == 0 && ldw % 8 == 0, MER_ESHAPE, "mer_w_block_pack: K must be a multiple of 32 and ldw of 8 (N=%d K=%d ldw=%lld)", N, K, ldw);
+  MER_REQUIRE((((uintptr_t)w | (uintptr_t)out) & 15) == 0, MER_EINVAL, "mer_w_block_pack: planes must be 16-byte aligned");
+  const long long total = (long long)((N + 255) / 256) * (K / 32) * 1024;
+  hipLaunchKernelGGL(w_block_pack_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)w, ldw / 8, N, K / 32, total, (u32x4*)out);
+  return check_launch("w_block_pack");
 }
 
 // ---- host-side packer of the MX correction plane (weights are prepared once, offline) ----
@@ -856,7 +896,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   Gemm16Params p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
-  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx;
+  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0;
   p.bias = a->bias; p.act = a->act;
   p.residual = a->residual; p.ldr = a->ldr;
   p.c32 = a->c32; p.ldc32 = a->ldc32;
@@ -894,6 +934,13 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
                   tile, a->K, nbatch, a->dtype);
       passes = 2;
     }
+  }
+  // pre-blocked weight planes feed the 256-wide LDS-DMA kernels only (their block is one 256 x 32 stage plane)
+  if (a->w_hi_blk && g_gemm_wblk && tile == 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && (passes == 1 || passes == 4 || a->w_lo_blk)) {
+    MER_REQUIRE((((uintptr_t)a->w_hi_blk | (uintptr_t)a->w_lo_blk) & 15) == 0, MER_EINVAL, "mer_gemm16: pre-blocked planes must be 16-byte aligned");
+    p.w_hi = a->w_hi_blk;
+    p.w_lo = a->w_lo_blk;
+    p.w_blk = 1;
   }
   if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, passes, tile, st);
   return dispatch<bf16>(p, nbatch, passes, tile, st);

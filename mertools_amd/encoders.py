@@ -54,6 +54,9 @@ def _sd_of(model_or_sd):
     return {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()}
 
 
+_WBLK = os.environ.get("MER_WBLK", "1") != "0"   # pre-blocked weight planes (tuning / A-B switch)
+
+
 class _Holder:
     """Owns the device copies of the weights and hands out raw pointers."""
 
@@ -78,10 +81,26 @@ class _Holder:
         w.hi = hi.data_ptr()
         w.lo = None
         w.mx = None
+        w.hi_blk = None
+        w.lo_blk = None
         if lo:
             lo_t = lo_t.contiguous().to(self.device)
             self.keep.append(lo_t)
             w.lo = lo_t.data_ptr()
+        if t.dim() == 2 and t.shape[0] >= 192 and t.shape[1] % 32 == 0 and self.device.type == "cuda" and _WBLK:
+            # pre-blocked copies for the 256-wide LDS-DMA kernels (1 KiB contiguous DMA pieces); the row-major planes stay
+            # for the small-batch tiles.  Costs a second copy of the weights in HBM (a few hundred MB at most).
+            from .ops import w_block_pack
+            with torch.cuda.device(self.device):
+                hb = w_block_pack(hi)
+                lb = w_block_pack(lo_t) if lo and hb is not None else None
+                torch.cuda.current_stream().synchronize()   # the forwards may run on other streams
+            if hb is not None:
+                self.keep.append(hb)
+                w.hi_blk = hb.data_ptr()
+                if lb is not None:
+                    self.keep.append(lb)
+                    w.lo_blk = lb.data_ptr()
         if mx and torch16(self.dtype) == torch.float16 and t.dim() == 2:
             # MX-fp4 plane of the rounding residual for the passes=4 GEMM (shapes without one keep using `lo`)
             from .ops import mx_pack

@@ -41,7 +41,15 @@ __device__ __forceinline__ int swz4(int row) { return (-(row >> 2)) & 3; }   // 
 
 // MODE bit 0: fragment reads, bit 1: MFMAs (implies bit 0), bit 2: no DMA at all (MFMA / ds_read ceiling on stale LDS)
 // MF: MFMA shape, 16 = v_mfma_f32_16x16x32_f16 (gemm16's), 32 = v_mfma_f32_32x32x16_f16 (half the instructions per slab)
-template <int NW, int NS, int MODE, int MF = 16>
+// LAYOUT: which bytes one 1-KiB DMA piece (one wave-instruction) covers — every layout moves the same 32 KB per slab and
+// the same bytes per tile with the same reuse across tiles, only the contiguous run per matrix row differs:
+//   0  16 rows x  64 B  (gemm16 today: BK = 32, slab s = k-range [32s, 32s+32) of all 256 rows)
+//   1  as 0, but the DMAs of slabs (2j, 2j+1) are issued together, piece by piece, so that the two 64-B halves of a
+//      128-B line are requested back to back
+//   2   8 rows x 128 B  (slab s = k-range [64 (s/2), +64) of rows 128 (s%2) ..)
+//   3   4 rows x 256 B  (slab s = k-range [128 (s/4), +128) of rows 64 (s%4) ..)
+//   4   1 KiB contiguous (operands pre-blocked [tile][slab][row][32]: what an offline-packed weight plane could look like)
+template <int NW, int NS, int MODE, int MF = 16, int LAYOUT = 0>
 __global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
   constexpr int BM = 256, BN = 256, BK = 32, RB = BK * 2;
   constexpr int A_PLANE = BM * RB, STAGE = (BM + BN) * RB;      // 32 KB per slab
@@ -64,24 +72,54 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
   const int tn = t % p.tiles_n, tm = t / p.tiles_n;
 
   // DMA piece j of a plane = tile rows 16j .. 16j+15 (lane l: row 16j + l/4, physical chunk l%4 <- logical chunk ^ swizzle)
+  const int nk = p.K / BK;
   unsigned a_src[PA], w_src[PA];   // element offsets (< 2^32: the probe matrices are < 4 G elements)
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int j = wave + i * NW, row = 16 * j + (lane >> 2), ch = (lane & 3) ^ swz4(row);
-    int m = tm * BM + row; m = m < p.M ? m : p.M - 1;
-    int n = tn * BN + row; n = n < p.N ? n : p.N - 1;
-    a_src[i] = (unsigned)m * (unsigned)p.K + ch * 8;
-    w_src[i] = (unsigned)n * (unsigned)p.K + ch * 8;
+    const int j = wave + i * NW;
+    if (LAYOUT == 4) {
+      a_src[i] = ((unsigned)(tm * nk) * 16 + j) * 512 + lane * 8;
+      w_src[i] = ((unsigned)(tn * nk) * 16 + j) * 512 + lane * 8;
+    } else {
+      constexpr int LPR = LAYOUT == 2 ? 8 : (LAYOUT == 3 ? 16 : 4);   // lanes (16-byte chunks) per row run
+      const int row = (64 / LPR) * j + lane / LPR;
+      const int ch = LAYOUT >= 2 ? lane % LPR : ((lane & 3) ^ swz4(row));
+      int m = tm * BM + row; m = m < p.M ? m : p.M - 1;
+      int n = tn * BN + row; n = n < p.N ? n : p.N - 1;
+      a_src[i] = (unsigned)m * (unsigned)p.K + ch * 8;
+      w_src[i] = (unsigned)n * (unsigned)p.K + ch * 8;
+    }
   }
+  auto slab_off = [&](int kt) -> unsigned {   // element offset of slab kt relative to a_src / w_src
+    if (LAYOUT == 2) return (unsigned)(kt & 1) * 128u * (unsigned)p.K + (unsigned)(kt >> 1) * 64u;
+    if (LAYOUT == 3) return (unsigned)(kt & 3) * 64u * (unsigned)p.K + (unsigned)(kt >> 2) * 128u;
+    if (LAYOUT == 4) return (unsigned)kt * 16u * 512u;
+    return (unsigned)kt * BK;
+  };
   auto issue = [&](int kt, int stage) {
     if (NODMA) return;
     char* base = smem + stage * STAGE;
+    const unsigned so = slab_off(kt);
 #pragma unroll
     for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + kt * BK), (lds_void_t*)(base + (wave + i * NW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + so), (lds_void_t*)(base + (wave + i * NW) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + kt * BK), (lds_void_t*)(base + A_PLANE + (wave + i * NW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + so), (lds_void_t*)(base + A_PLANE + (wave + i * NW) * 1024), 16, 0, 0);
+  };
+  auto issue_pair = [&](int kt, int stage0, int stage1) {   // LAYOUT 1: slabs kt, kt+1 piece by piece
+    char* b0 = smem + stage0 * STAGE;
+    char* b1 = smem + stage1 * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + kt * BK), (lds_void_t*)(b0 + (wave + i * NW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + (kt + 1) * BK), (lds_void_t*)(b1 + (wave + i * NW) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + kt * BK), (lds_void_t*)(b0 + A_PLANE + (wave + i * NW) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + (kt + 1) * BK), (lds_void_t*)(b1 + A_PLANE + (wave + i * NW) * 1024), 16, 0, 0);
+    }
   };
 
   f32x4 acc[TM][TN];
@@ -136,27 +174,45 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
     }
   };
 
-  const int nk = p.K / BK;
-  // prologue: D slabs in flight, slab 0 landed, its fragments in buffer 0
+  static_assert(LAYOUT != 1 || NS == 4, "pair issue: 4-stage ring");
+  // prologue: D slabs in flight, slab 0 landed, its fragments in buffer 0   (LAYOUT 1: the pair (0, 1), both landed)
+  if (LAYOUT == 1) {
+    if (!NODMA) issue_pair(0, 0, 1);
+    wait_vmcnt<0>();
+  } else {
 #pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < nk) issue(s, s);
-  if (nk >= D) wait_vmcnt<LPS*(D - 1)>(); else wait_vmcnt<0>();
+    for (int s = 0; s < D; ++s)
+      if (s < nk) issue(s, s);
+    if (nk >= D) wait_vmcnt<LPS*(D - 1)>(); else wait_vmcnt<0>();
+  }
   __builtin_amdgcn_s_barrier();
   if (READS) load_frags(smem, 0);
-  int nxt = D, rd = 1;   // stage to refill with slab kt+D / stage holding slab kt+1
+  int nxt = LAYOUT == 1 ? 2 : D, rd = 1;   // stage to refill with slab kt+D / stage holding slab kt+1
   // software-pipelined loop, two slabs per trip so that the fragment buffer index is static
   auto body = [&](int kt, auto buf_tag) {
     constexpr int buf = decltype(buf_tag)::value;
+    if (LAYOUT == 1) {
+      // even trips issue the pair (kt+2, kt+3) into the stages of slabs kt-2, kt-1 (K % 64 == 0) and wait for everything
+      // older; odd trips wait for the even slab of the pair in flight (all but the very last DMA, which is the odd slab's)
+      if (buf == 0) {
+        const bool more = kt + 2 < nk;
+        if (more && !NODMA) issue_pair(kt + 2, nxt, nxt + 1);
+        if (more) wait_vmcnt<2 * LPS>(); else wait_vmcnt<0>();
+        nxt ^= 2;
+      } else {
+        if (kt + 1 < nk) wait_vmcnt<1>(); else wait_vmcnt<0>();
+      }
+    } else {
     const bool more = kt + D < nk;
     if (more) issue(kt + D, nxt);                       // refills the stage of slab kt-1 (all its reads retired before the last barrier)
     if (more) wait_vmcnt<LPS*(D - 1)>(); else wait_vmcnt<0>();   // my share of slab kt+1 has landed
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of slab kt (issued last trip) have retired
     __builtin_amdgcn_s_barrier();
     if (READS) load_frags(smem + rd * STAGE, buf ^ 1);   // slab kt+1 -> the other buffer (last trip: a stale stage, harmless; a branch here
                                                          // would make hipcc drain lgkmcnt at the join), in the shadow of ...
     consume(buf);                                        // ... the MFMAs of slab kt
-    nxt = nxt + 1 == NS ? 0 : nxt + 1;
     rd = rd + 1 == NS ? 0 : rd + 1;
   };
   int kt = 0;
@@ -178,6 +234,121 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
   }
   s += (float)(keep[0] ^ keep[1] ^ keep[2] ^ keep[3]);
   if (s == 12345.678f) p.sink[tid] = s;   // never true for zero inputs: keeps the work alive without a store
+  __syncthreads();
+  if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+}
+
+// phase_kernel: gemm16's two-group, two-barrier K loop (8 waves = 2 x 4 of 128x64; group 1 runs one phase behind group 0;
+// an iteration is LOAD(u) |bar| MATH(u) |bar| for one 32-deep k-step u) over two LDS organisations of the same 128 KB:
+//   BK64 = false: four 32-KB stages of 64-byte rows, one slab issued per iteration, three in flight (gemm16 today)
+//   BK64 = true : two 64-KB stages of 128-byte rows (a stage = two k-steps); the next stage's DMAs (8 rows x 128 B per
+//                 piece: whole 128-B lines) are issued at the top of even k-steps and confirmed before the mid barrier
+//                 of odd ones
+// BLK: 0 = row-major operands, 1 = W pre-blocked [n-tile][stage-slab][1-KiB piece] (each DMA piece is 1 KiB contiguous; what an
+//      offline weight packer can produce), 2 = A and W pre-blocked (upper bound: needs the activation producers to write blocked planes)
+template <bool BK64, bool DO_MATH, int BLK = 0>
+__global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
+  constexpr int RB = BK64 ? 128 : 64, C = RB / 16, STAGE = 512 * RB, NS = BK64 ? 2 : 4, PLANE = 256 * RB;
+  constexpr int PA = PLANE / 1024 / 8, LPS = 2 * PA, RPP = 64 / C;   // pieces per wave per plane, DMAs per wave per stage, rows per piece
+  constexpr int TM = 8, TN = 4;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, li = lane & 15, lg = lane >> 4;
+  if (tid == 0) p.stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int L = blockIdx.x, xcd = L & 7, loc = L >> 3, q = nblk >> 3, r = nblk & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+  auto swz = [](int row) { return C == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); };
+  unsigned a_src[PA], w_src[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = RPP * (wave + i * 8) + lane / C, ch = (lane % C) ^ swz(row);
+    a_src[i] = (unsigned)(tm * 256 + row) * (unsigned)p.K + ch * 8;
+    w_src[i] = (unsigned)(tn * 256 + row) * (unsigned)p.K + ch * 8;
+    // blocked: plane image of (tile, slab) is PLANE bytes contiguous = the LDS image itself
+    if (BLK >= 2) a_src[i] = (unsigned)tm * 256u * (unsigned)p.K + (wave + i * 8) * 512 + lane * 8;
+    if (BLK >= 1) w_src[i] = (unsigned)tn * 256u * (unsigned)p.K + (wave + i * 8) * 512 + lane * 8;
+  }
+  auto issue = [&](int s, int stage) {   // stage-sized slab s (32 or 64 k)
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + s * (BLK >= 2 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + (wave + i * 8) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + s * (BLK >= 1 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + PLANE + (wave + i * 8) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 fa[TM], fw[TN];
+  u32x4 keep = {0u, 0u, 0u, 0u};
+  auto load_frags = [&](const char* base, int ks) {
+    const int chunk = ks * 4 + lg;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+      const int row = wm * 128 + mt * 16 + li;
+      fa[mt] = *reinterpret_cast<const f16x8*>(base + row * RB + ((chunk ^ swz(row)) << 4));
+    }
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int row = wn * 64 + nt * 16 + li;
+      fw[nt] = *reinterpret_cast<const f16x8*>(base + PLANE + row * RB + ((chunk ^ swz(row)) << 4));
+    }
+  };
+  const int nk = p.K / 32;
+  const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  if (BK64) {
+    issue(0, 0);
+    wait_vmcnt<0>();
+  } else {
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) issue(s2, s2);
+    wait_vmcnt<LPS * 2>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (g1) __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt = 3;
+  for (int u = 0; u < nk; ++u) {
+    if (BK64) {
+      const int pr = u >> 1, h = u & 1;
+      if (h == 0 && (pr + 1) * 2 < nk) issue(pr + 1, (pr + 1) & 1);
+      load_frags(smem + (pr & 1) * STAGE, h);
+      if (h == 1) wait_vmcnt<0>();
+    } else {
+      const bool more = u + 3 < nk;
+      if (more) issue(u + 3, nxt);
+      load_frags(smem + cur * STAGE, 0);
+      if (more) wait_vmcnt<LPS * 2>(); else wait_vmcnt<0>();
+      cur = (cur + 1) & 3; nxt = (nxt + 1) & 3;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (DO_MATH) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], fw[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) keep ^= __builtin_bit_cast(u32x4, fa[mt]);
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) keep ^= __builtin_bit_cast(u32x4, fw[nt]);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!g1) __builtin_amdgcn_s_barrier();
+  float sum = (float)(keep[0] ^ keep[1] ^ keep[2] ^ keep[3]);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (sum == 12345.678f) p.sink[tid] = sum;
   __syncthreads();
   if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
 }
@@ -232,19 +403,34 @@ static float time_launches(F&& launch, int warm, int reps) {
   return ms * 1e3f / reps;   // us per launch
 }
 
-template <int NW, int NS, int MODE, int MF = 16>
+template <int NW, int NS, int MODE, int MF = 16, int LAYOUT = 0>
 static void run_ring(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
   RingParams p{a, w, M, N, K, (M + 255) / 256, (N + 255) / 256, d_st, sink};
   const int nblk = p.tiles_m * p.tiles_n;
-  float us = time_launches([&] { hipLaunchKernelGGL((ring_kernel<NW, NS, MODE, MF>), dim3(nblk), dim3(NW * 64), 0, 0, p); }, warm, reps);
+  float us = time_launches([&] { hipLaunchKernelGGL((ring_kernel<NW, NS, MODE, MF, LAYOUT>), dim3(nblk), dim3(NW * 64), 0, 0, p); }, warm, reps);
   std::vector<unsigned long long> st(2 * nblk);
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
   const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
   const double bytes = (double)nblk * nk * 32768.0, flops = 2.0 * p.tiles_m * 256.0 * p.tiles_n * 256.0 * K;
-  printf("{\"probe\": \"ring\", \"name\": \"%s\", \"waves\": %d, \"stages\": %d, \"mode\": %d, \"mfma\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, "
+  printf("{\"probe\": \"ring\", \"name\": \"%s\", \"waves\": %d, \"stages\": %d, \"mode\": %d, \"mfma\": %d, \"layout\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, "
          "\"us\": %.1f, \"cycles_per_tile\": %.0f, \"cycles_per_slab\": %.0f, \"dma_B_per_clk_per_CU\": %.1f, \"dma_TBps_chip\": %.2f, \"mfma_TFLOPs\": %.0f}\n",
-         name, NW, NS, MODE, MF, M, N, K, nblk, us, cyc, cyc / nk, (MODE & 4) ? 0.0 : 32768.0 * nk / cyc, (MODE & 4) ? 0.0 : bytes / us * 1e-6,
+         name, NW, NS, MODE, MF, LAYOUT, M, N, K, nblk, us, cyc, cyc / nk, (MODE & 4) ? 0.0 : 32768.0 * nk / cyc, (MODE & 4) ? 0.0 : bytes / us * 1e-6,
          (MODE & 2) ? flops / us * 1e-6 : 0.0);
+  fflush(stdout);
+}
+
+template <bool BK64, bool DO_MATH, int BLK = 0>
+static void run_phase(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
+  RingParams p{a, w, M, N, K, M / 256, N / 256, d_st, sink};
+  const int nblk = p.tiles_m * p.tiles_n;
+  float us = time_launches([&] { hipLaunchKernelGGL((phase_kernel<BK64, DO_MATH, BLK>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
+  std::vector<unsigned long long> st(2 * nblk);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
+  const double bytes = (double)nblk * nk * 32768.0, flops = 2.0 * M * (double)N * K;
+  printf("{\"probe\": \"phase\", \"name\": \"%s\", \"bk64\": %d, \"math\": %d, \"blocked\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, "
+         "\"us\": %.1f, \"cycles_per_tile\": %.0f, \"cycles_per_slab\": %.0f, \"dma_B_per_clk_per_CU\": %.1f, \"dma_TBps_chip\": %.2f, \"mfma_TFLOPs\": %.0f}\n",
+         name, (int)BK64, (int)DO_MATH, BLK, M, N, K, nblk, us, cyc, cyc / nk, 32768.0 * nk / cyc, bytes / us * 1e-6, DO_MATH ? flops / us * 1e-6 : 0.0);
   fflush(stdout);
 }
 
@@ -274,11 +460,50 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("{\"device\": \"%s\", \"cus\": %d, \"clock_khz\": %d}\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
 
+  const char* set = argc > 3 ? argv[3] : "all";
+  const bool all = !strcmp(set, "all");
   // --- the K loop's data path; shapes: CLIP QKV (N=2304, K=768), fc2 (N=768, K=3072)
 #define RING_SET(NW, NS, MODE, NAME) RING_SET_MF(NW, NS, MODE, 16, NAME)
-#define RING_SET_MF(NW, NS, MODE, MF, NAME) \
-  run_ring<NW, NS, MODE, MF>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
-  run_ring<NW, NS, MODE, MF>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
+#define RING_SET_MF(NW, NS, MODE, MF, NAME) RING_SET_L(NW, NS, MODE, MF, 0, NAME)
+#define RING_SET_L(NW, NS, MODE, MF, LAYOUT, NAME) \
+  run_ring<NW, NS, MODE, MF, LAYOUT>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
+  run_ring<NW, NS, MODE, MF, LAYOUT>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
+  if (all || !strcmp(set, "phase")) {
+#define PHASE_SET(BK64, MATH, NAME) \
+  run_phase<BK64, MATH>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH>(NAME, a, w, M, 1536, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH>(NAME, a, w, M, 3072, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
+    PHASE_SET(false, false, "two-phase loop, 4 x 32 KB stages of 64-B rows, no mfma")
+    PHASE_SET(true, false, "two-phase loop, 2 x 64 KB stages of 128-B rows, no mfma")
+    PHASE_SET(false, true, "two-phase loop, 4 x 32 KB stages of 64-B rows (gemm16 today)")
+    PHASE_SET(true, true, "two-phase loop, 2 x 64 KB stages of 128-B rows")
+  }
+  if (all || !strcmp(set, "blocked")) {
+#define PHASE_SET_B(BK64, MATH, BLK, NAME) \
+  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 3072, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
+    PHASE_SET_B(false, true, 0, "two-phase loop (gemm16 today)")
+    PHASE_SET_B(false, true, 1, "two-phase loop, W pre-blocked")
+    PHASE_SET_B(false, true, 2, "two-phase loop, A and W pre-blocked")
+    PHASE_SET_B(false, false, 1, "two-phase loop, W pre-blocked, no mfma")
+    PHASE_SET_B(false, false, 2, "two-phase loop, A and W pre-blocked, no mfma")
+    PHASE_SET_B(true, true, 1, "two-phase loop 2 x 64 KB, A 128-B rows, W pre-blocked")
+  }
+  if (all || !strcmp(set, "layout")) {
+    RING_SET_L(8, 4, 0, 16, 0, "dma only, 16 rows x 64 B per piece (today)")
+    RING_SET_L(8, 4, 0, 16, 1, "dma only, 64-B runs, slab pairs issued together")
+    RING_SET_L(8, 4, 0, 16, 2, "dma only, 8 rows x 128 B per piece")
+    RING_SET_L(8, 4, 0, 16, 3, "dma only, 4 rows x 256 B per piece")
+    RING_SET_L(8, 4, 0, 16, 4, "dma only, 1 KiB contiguous per piece (pre-blocked operands)")
+    RING_SET_L(8, 4, 3, 16, 0, "pipelined K loop 8 waves, 64-B runs (today)")
+    RING_SET_L(8, 4, 3, 16, 1, "pipelined K loop 8 waves, slab pairs issued together")
+    RING_SET_L(8, 4, 3, 16, 2, "pipelined K loop 8 waves, 128-B runs")
+    RING_SET_L(8, 4, 3, 16, 3, "pipelined K loop 8 waves, 256-B runs")
+    RING_SET_L(8, 4, 3, 16, 4, "pipelined K loop 8 waves, pre-blocked operands")
+  }
+  if (all || !strcmp(set, "ring")) {
   RING_SET(8, 4, 0, "dma only, 8 waves")
   RING_SET(4, 4, 0, "dma only, 4 waves")
   RING_SET(8, 4, 1, "dma + fragment reads, 8 waves (128x64 per wave)")
@@ -292,6 +517,8 @@ int main(int argc, char** argv) {
   RING_SET_MF(4, 4, 3, 32, "pipelined K loop, 4 waves x 128x128, 32x32x16 mfma")
   RING_SET_MF(8, 4, 3, 32, "pipelined K loop, 8 waves x 128x64, 32x32x16 mfma")
 
+  }
+  if (all || !strcmp(set, "store")) {
   // --- the epilogue's store path: f16 (QKV / fc1 outputs) and fp32 (residual stream) tiles
   run_store<8, 128, 2>(c, M, 2304, st, warm, reps);
   run_store<8, 256, 2>(c, M, 2304, st, warm, reps);
@@ -301,5 +528,6 @@ int main(int argc, char** argv) {
   run_store<8, 256, 4>(c, M, 768, st, warm, reps);
   run_store<8, 512, 4>(c, M, 768, st, warm, reps);
   run_store<8, 1024, 4>(c, M, 768, st, warm, reps);
+  }
   return 0;
 }

@@ -447,3 +447,46 @@ def test_gemm16_persistent_tiles(dev, M, N, K, passes):
     assert torch.equal(c32, ref32) and torch.equal(c16, ref16)
     true = F.gelu(a.double() @ w.double().T + bias.cpu().double()) + res.cpu().double()
     assert_close(c32.cpu(), true.float(), {1: 1e-3, 2: 5e-4, 3: 2e-5}[passes], "persistent gemm16 vs fp64")
+
+
+@pytest.mark.parametrize("passes", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(10240, 2048, 256), (4100, 768, 768), (9000, 1100, 96), (2048, 200, 32), (1500, 2304, 3072)])
+def test_gemm16_preblocked_weights(dev, M, N, K, passes):
+    """mer_w_block_pack: the 256x256 kernels read the weight planes from [n-tile][k-slab][16 KB LDS image] blocks (1 KiB
+    contiguous DMA pieces) instead of the row-major planes; the LDS images are identical, so every output must equal the
+    row-major launch bit for bit — ragged N (rows beyond N repeat row N-1), ragged M, K from one slab to 96 slabs."""
+    ops = _ops()
+    if passes == 4 and K % 128 != 0:
+        pytest.skip("MX kernel needs K % 128 == 0")
+    a = _rand((M, K), 81)
+    w = _rand((N, K), 82) * 0.05
+    ah, al = ops.split16(a.to(dev), "f16")
+    wh, wl = ops.split16_host(w, "f16")
+    wh, wl = wh.to(dev), wl.to(dev)
+    mx = ops.mx_pack(w - wh.cpu().float()).to(dev) if passes == 4 else None
+    bias, res = _rand((N,), 83).to(dev), _rand((M, N), 84).to(dev)
+    kw = dict(a_lo=al if passes == 3 else None, w_lo=wl if passes in (2, 3) else None, w_mx=mx, bias=bias, act="gelu", residual=res,
+              out32=True, out16=True, passes=passes, tile=3)
+    ref32, ref16, _ = ops.gemm16(ah, wh, **kw)
+    hb = ops.w_block_pack(wh)
+    lb = ops.w_block_pack(wl) if passes in (2, 3) else None
+    assert hb is not None and hb.numel() == (N + 255) // 256 * 256 * K * 2
+    c32, c16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_lo_blk=lb, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(c32, ref32) and torch.equal(c16, ref16)
+    true = F.gelu(a.double() @ w.double().T + bias.cpu().double()) + res.cpu().double()
+    assert_close(c32.cpu(), true.float(), {1: 1e-3, 2: 5e-4, 3: 2e-5, 4: 5e-4}[passes], "pre-blocked gemm16 vs fp64")
+
+
+def test_w_block_pack_layout(dev):
+    """Block (tn, kt) of the packed plane = rows tn*256 .. +255 (clamped to N-1), k-range [32 kt, 32 kt + 32), row r at byte
+    64 r, 16-byte chunk pc holding logical chunk pc ^ ((-(r >> 2)) & 3)."""
+    ops = _ops()
+    N, K = 300, 96
+    w = torch.arange(N * K, dtype=torch.int16).view(N, K).to(dev)
+    out = ops.w_block_pack(w.view(torch.float16)).view(torch.int16).cpu().view(2, K // 32, 256, 4, 8)
+    wc = w.cpu()
+    for tn, kt, r, pc in [(0, 0, 0, 0), (0, 1, 5, 2), (0, 2, 255, 3), (1, 0, 17, 1), (1, 2, 43, 0), (1, 1, 200, 2)]:
+        n = min(tn * 256 + r, N - 1)
+        lc = pc ^ ((-(r >> 2)) & 3)
+        assert torch.equal(out[tn, kt, r, pc], wc[n, kt * 32 + lc * 8: kt * 32 + lc * 8 + 8]), (tn, kt, r, pc)
