@@ -164,11 +164,17 @@ class _HipModule:
         self._ws = None
 
     def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
-        off = (-self._ws.data_ptr()) % 256
-        return self._ws.data_ptr() + off, self._ws.numel() - off
+        # one arena per HIP stream: forwards issued on different streams (half-batches overlapping each other's kernel
+        # tails, bench.py --split) must not share scratch memory
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        return ws.data_ptr() + off, ws.numel() - off
 
     def _seg(self, seg_start, seg_len):
         if seg_start is None:

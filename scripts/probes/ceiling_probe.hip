@@ -353,6 +353,113 @@ __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
   if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
 }
 
+// phase2_kernel: the two-group schedule with TWO slabs per iteration (same four 32-KB stages): LOAD(j) reads the fragments
+// of slab 2j, MATH(j) issues the 32 MFMAs of slab 2j, re-reads each A fragment from slab 2j+1 as soon as its row of MFMAs
+// has been issued (B fragments of slab 2j+1 are read at the top of MATH into a second buffer), then the 32 MFMAs of slab
+// 2j+1 — half as many barriers per k, MATH phases of 64 MFMAs.  DMA: in phase ph every wave issues its share of slab ph+2
+// (the stage of slab ph-2, whose last readers ran in phase ph-1) and, before the barrier that ends the phase, confirms
+// slab ph+1 (first read in phase ph+1) with a counted vmcnt.  Phases: group 0 LOAD(j) = 2j, MATH(j) = 2j+1; group 1 one later.
+template <int BLK>
+__global__ __launch_bounds__(512) void phase2_kernel(const RingParams p) {
+  constexpr int RB = 64, C = 4, STAGE = 512 * RB, PLANE = 256 * RB, PA = 2, LPS = 4, TM = 8, TN = 4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, li = lane & 15, lg = lane >> 4;
+  if (tid == 0) p.stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int L = blockIdx.x, xcd = L & 7, loc = L >> 3, q = nblk >> 3, r = nblk & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+  unsigned a_src[PA], w_src[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = 16 * (wave + i * 8) + lane / C, ch = (lane % C) ^ swz4(row);
+    a_src[i] = (unsigned)(tm * 256 + row) * (unsigned)p.K + ch * 8;
+    w_src[i] = (unsigned)(tn * 256 + row) * (unsigned)p.K + ch * 8;
+    if (BLK >= 2) a_src[i] = (unsigned)tm * 256u * (unsigned)p.K + (wave + i * 8) * 512 + lane * 8;
+    if (BLK >= 1) w_src[i] = (unsigned)tn * 256u * (unsigned)p.K + (wave + i * 8) * 512 + lane * 8;
+  }
+  auto issue = [&](int s2) {
+    char* base = smem + (s2 & 3) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + s2 * (BLK >= 2 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + (wave + i * 8) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + s2 * (BLK >= 1 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + PLANE + (wave + i * 8) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 fa[TM], fw0[TN], fw1[TN];
+  int a_off[TM], w_off[TN];   // LDS byte offsets of this lane's fragments inside a stage
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) { const int row = wm * 128 + mt * 16 + li; a_off[mt] = row * RB + ((lg ^ swz4(row)) << 4); }
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) { const int row = wn * 64 + nt * 16 + li; w_off[nt] = PLANE + row * RB + ((lg ^ swz4(row)) << 4); }
+  const int nk = p.K / 32, nj = nk / 2;
+  const int g = __builtin_amdgcn_readfirstlane(wave) >= 4 ? 1 : 0;
+  auto confirm = [&](int ph) {   // before the barrier that ends phase ph: my share of slab ph+1 has landed
+    if (ph == 0) wait_vmcnt<2 * LPS>();
+    else if (ph + 2 < nk) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+  };
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) issue(s2);
+  wait_vmcnt<2 * LPS>();
+  __builtin_amdgcn_s_barrier();
+  if (g) __builtin_amdgcn_s_barrier();
+  for (int j = 0; j < nj; ++j) {
+    const int phL = 2 * j + g, phM = phL + 1;
+    // ---- LOAD(j)
+    if (phL >= 2 && phL + 2 < nk) issue(phL + 2);
+    const char* s0 = smem + ((2 * j) & 3) * STAGE;
+    const char* s1 = smem + ((2 * j + 1) & 3) * STAGE;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) fa[mt] = *reinterpret_cast<const f16x8*>(s0 + a_off[mt]);
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) fw0[nt] = *reinterpret_cast<const f16x8*>(s0 + w_off[nt]);
+    confirm(phL);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- MATH(j)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], fw0[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mt == 0) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) fw1[nt] = *reinterpret_cast<const f16x8*>(s1 + w_off[nt]);
+      }
+      fa[mt] = *reinterpret_cast<const f16x8*>(s1 + a_off[mt]);   // slab 2j+1's fragment of this row, used 28 MFMAs later
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], fw1[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mt == 1 && phM >= 2 && phM + 2 < nk) issue(phM + 2);    // this phase's DMA share, in the MFMA shadow, after the last LDS read
+    }
+    __builtin_amdgcn_s_setprio(0);
+    confirm(phM);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!g) __builtin_amdgcn_s_barrier();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (sum == 12345.678f) p.sink[tid] = sum;
+  __syncthreads();
+  if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+}
+
 // store probe: a workgroup of NW waves writes a 256 x 256 tile of ELEM-byte outputs (ELEM = 2: 128 KB, 4: 256 KB) with
 // 16-byte lane stores; SEG = bytes of one row that consecutive lanes of a wave cover (SEG/16 lanes per row).
 struct StoreParams { char* c; long long ldc_bytes; int tiles_m, tiles_n; unsigned long long* stamps; };
@@ -434,6 +541,21 @@ static void run_phase(const char* name, const f16* a, const f16* w, int M, int N
   fflush(stdout);
 }
 
+template <int BLK>
+static void run_phase2(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
+  RingParams p{a, w, M, N, K, M / 256, N / 256, d_st, sink};
+  const int nblk = p.tiles_m * p.tiles_n;
+  float us = time_launches([&] { hipLaunchKernelGGL((phase2_kernel<BLK>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
+  std::vector<unsigned long long> st(2 * nblk);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
+  const double bytes = (double)nblk * nk * 32768.0, flops = 2.0 * M * (double)N * K;
+  printf("{\"probe\": \"phase2\", \"name\": \"%s\", \"blocked\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, "
+         "\"us\": %.1f, \"cycles_per_tile\": %.0f, \"cycles_per_slab\": %.0f, \"dma_B_per_clk_per_CU\": %.1f, \"dma_TBps_chip\": %.2f, \"mfma_TFLOPs\": %.0f}\n",
+         name, BLK, M, N, K, nblk, us, cyc, cyc / nk, 32768.0 * nk / cyc, bytes / us * 1e-6, flops / us * 1e-6);
+  fflush(stdout);
+}
+
 template <int NW, int SEG, int ELEM>
 static void run_store(char* c, int M, int N, unsigned long long* d_st, int warm, int reps) {
   StoreParams p{c, (long long)N * ELEM, M / 256, N / 256, d_st};
@@ -460,6 +582,10 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("{\"device\": \"%s\", \"cus\": %d, \"clock_khz\": %d}\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
 
+#define PHASE_SET_B(BK64, MATH, BLK, NAME) \
+  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 3072, 768, st, sink, warm, reps); \
+  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
   const char* set = argc > 3 ? argv[3] : "all";
   const bool all = !strcmp(set, "all");
   // --- the K loop's data path; shapes: CLIP QKV (N=2304, K=768), fc2 (N=768, K=3072)
@@ -479,11 +605,17 @@ int main(int argc, char** argv) {
     PHASE_SET(false, true, "two-phase loop, 4 x 32 KB stages of 64-B rows (gemm16 today)")
     PHASE_SET(true, true, "two-phase loop, 2 x 64 KB stages of 128-B rows")
   }
+  if (all || !strcmp(set, "phase2")) {
+#define PHASE2_SET(BLK, NAME) \
+  run_phase2<BLK>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
+  run_phase2<BLK>(NAME, a, w, M, 3072, 768, st, sink, warm, reps); \
+  run_phase2<BLK>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
+    PHASE_SET_B(false, true, 1, "two-phase loop, W pre-blocked (gemm16 now)")
+    PHASE2_SET(0, "two slabs per iteration, row-major")
+    PHASE2_SET(1, "two slabs per iteration, W pre-blocked")
+    PHASE2_SET(2, "two slabs per iteration, A and W pre-blocked")
+  }
   if (all || !strcmp(set, "blocked")) {
-#define PHASE_SET_B(BK64, MATH, BLK, NAME) \
-  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 2304, 768, st, sink, warm, reps); \
-  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 3072, 768, st, sink, warm, reps); \
-  run_phase<BK64, MATH, BLK>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
     PHASE_SET_B(false, true, 0, "two-phase loop (gemm16 today)")
     PHASE_SET_B(false, true, 1, "two-phase loop, W pre-blocked")
     PHASE_SET_B(false, true, 2, "two-phase loop, A and W pre-blocked")
