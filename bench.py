@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--split", type=int, default=1, help="run each modality's batch as this many sub-batches on their own HIP streams "
                                                            "(kernels of one sub-batch fill the partial last wave of workgroups of the other)")
+    ap.add_argument("--split-mods", default="avt", help="modalities --split applies to (the others run their whole batch on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -126,20 +127,19 @@ def main():
     # the three encoders are independent: each runs on its own HIP stream so that the tail of one kernel (a partial
     # last wave of workgroups) and the small text GEMMs overlap with another modality's work; --split S additionally
     # runs every modality's batch as S sub-batches on S streams (same clips per step, same kernels)
-    S = max(1, args.split)
-    assert B % S == 0, "--split must divide --batch"
-    Bs = B // S
-    streams = {m: [torch.cuda.Stream(device=dev) for _ in range(S)] for m in "avt"} if (args.streams or S > 1) else None
-    parts = {"a": [inputs["a"][i * Bs:(i + 1) * Bs] for i in range(S)] if "a" in mods else None,
-             "v": [inputs["v"][i * Bs * 8:(i + 1) * Bs * 8] for i in range(S)] if "v" in mods else None,
-             "t": [inputs["t"][i * Bs:(i + 1) * Bs] for i in range(S)] if "t" in mods else None}
+    assert B % max(1, args.split) == 0, "--split must divide --batch"
+    Sm = {m: (max(1, args.split) if m in args.split_mods else 1) for m in "avt"}   # sub-batches per modality
+    S = max(Sm.values())
+    streams = {m: [torch.cuda.Stream(device=dev) for _ in range(Sm[m])] for m in "avt"} if (args.streams or S > 1) else None
+    per = {"a": 1, "v": 8, "t": 1}   # input rows per clip
+    parts = {m: [inputs[m][i * (B // Sm[m]) * per[m]:(i + 1) * (B // Sm[m]) * per[m]] for i in range(Sm[m])] for m in mods}
 
     def run(m, i=None):
         if i is None:   # whole batch (roofline leg)
             xa, xv, xt, n = inputs.get("a"), inputs.get("v"), inputs.get("t"), B
         else:
             xa = xv = xt = parts[m][i]
-            n = Bs
+            n = B // Sm[m]
         if m == "a":
             return models["a"].extract_utterance(xa)
         if m == "v":
@@ -153,7 +153,7 @@ def main():
         cur = torch.cuda.current_stream()
         for i in range(S):
             for m in "vat":   # longest first
-                if m in mods:
+                if m in mods and i < Sm[m]:
                     streams[m][i].wait_stream(cur)
                     with torch.cuda.stream(streams[m][i]):
                         out.append(run(m, i))
@@ -234,7 +234,7 @@ def main():
             "config": {"workload": "tri-modal base extract: HuBERT-base 5s@16kHz + CLIP-ViT-B/16 8x224^2 + RoBERTa-base 64 tok "
                                    "(BASELINE.json configs[3] extraction leg = configs[1]+[2]+text on each GPU)",
                        "clips_per_gpu_per_step": B, "modalities": "".join(sorted(mods)), "precision": args.precision,
-                       "weights": "random-init (seed 0), HF architectures", "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": max(1, args.split), "parallelism": f"clip-sharded x{world}, no collective",
+                       "weights": "random-init (seed 0), HF architectures", "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": {m: Sm[m] for m in sorted(mods)}, "parallelism": f"clip-sharded x{world}, no collective",
                        "gflop_per_clip": gflop_clip},
             "roofline": roofline,
         }
