@@ -39,6 +39,19 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 __device__ __forceinline__ int swz4(int row) { return (-(row >> 2)) & 3; }   // conflict-free for 64-byte LDS rows
 
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (the form gemm16's MX kernel uses):
+// no 64-bit VGPR address arithmetic per piece
+__device__ __forceinline__ void dma16_sbase(const void* sbase_any, unsigned voff, unsigned lds_off) {
+  const unsigned long long pv = (unsigned long long)sbase_any;
+  const unsigned long long sbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+
 // MODE bit 0: fragment reads, bit 1: MFMAs (implies bit 0), bit 2: no DMA at all (MFMA / ds_read ceiling on stale LDS)
 // MF: MFMA shape, 16 = v_mfma_f32_16x16x32_f16 (gemm16's), 32 = v_mfma_f32_32x32x16_f16 (half the instructions per slab)
 // LAYOUT: which bytes one 1-KiB DMA piece (one wave-instruction) covers — every layout moves the same 32 KB per slab and
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
 //                 of odd ones
 // BLK: 0 = row-major operands, 1 = W pre-blocked [n-tile][stage-slab][1-KiB piece] (each DMA piece is 1 KiB contiguous; what an
 //      offline weight packer can produce), 2 = A and W pre-blocked (upper bound: needs the activation producers to write blocked planes)
-template <bool BK64, bool DO_MATH, int BLK = 0>
+template <bool BK64, bool DO_MATH, int BLK = 0, bool SADDR = false>
 __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
   constexpr int RB = BK64 ? 128 : 64, C = RB / 16, STAGE = 512 * RB, NS = BK64 ? 2 : 4, PLANE = 256 * RB;
   constexpr int PA = PLANE / 1024 / 8, LPS = 2 * PA, RPP = 64 / C;   // pieces per wave per plane, DMAs per wave per stage, rows per piece
@@ -272,6 +285,16 @@ __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
   }
   auto issue = [&](int s, int stage) {   // stage-sized slab s (32 or 64 k)
     char* base = smem + stage * STAGE;
+    if (SADDR) {
+      const char* ab = (const char*)(p.a + (long long)s * (BLK >= 2 ? PLANE / 2 : RB / 2));
+      const char* wb = (const char*)(p.w + (long long)s * (BLK >= 1 ? PLANE / 2 : RB / 2));
+      const unsigned lb = lds_offset_of(base);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) dma16_sbase(ab, a_src[i] * 2, lb + (wave + i * 8) * 1024);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) dma16_sbase(wb, w_src[i] * 2, lb + PLANE + (wave + i * 8) * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + s * (BLK >= 2 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + (wave + i * 8) * 1024), 16, 0, 0);
@@ -526,11 +549,11 @@ static void run_ring(const char* name, const f16* a, const f16* w, int M, int N,
   fflush(stdout);
 }
 
-template <bool BK64, bool DO_MATH, int BLK = 0>
+template <bool BK64, bool DO_MATH, int BLK = 0, bool SADDR = false>
 static void run_phase(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
   RingParams p{a, w, M, N, K, M / 256, N / 256, d_st, sink};
   const int nblk = p.tiles_m * p.tiles_n;
-  float us = time_launches([&] { hipLaunchKernelGGL((phase_kernel<BK64, DO_MATH, BLK>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
+  float us = time_launches([&] { hipLaunchKernelGGL((phase_kernel<BK64, DO_MATH, BLK, SADDR>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
   std::vector<unsigned long long> st(2 * nblk);
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
   const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
@@ -604,6 +627,13 @@ int main(int argc, char** argv) {
     PHASE_SET(true, false, "two-phase loop, 2 x 64 KB stages of 128-B rows, no mfma")
     PHASE_SET(false, true, "two-phase loop, 4 x 32 KB stages of 64-B rows (gemm16 today)")
     PHASE_SET(true, true, "two-phase loop, 2 x 64 KB stages of 128-B rows")
+  }
+  if (all || !strcmp(set, "saddr")) {
+    run_phase<false, true, 1, false>("two-phase loop, W pre-blocked, flat 64-bit DMA addresses (gemm16 now)", a, w, M, 2304, 768, st, sink, warm, reps);
+    run_phase<false, true, 1, true>("two-phase loop, W pre-blocked, SGPR base + 32-bit offsets", a, w, M, 2304, 768, st, sink, warm, reps);
+    run_phase<false, true, 1, false>("two-phase loop, W pre-blocked, flat 64-bit DMA addresses (gemm16 now)", a, w, M, 768, 3072, st, sink, warm, reps);
+    run_phase<false, true, 1, true>("two-phase loop, W pre-blocked, SGPR base + 32-bit offsets", a, w, M, 768, 3072, st, sink, warm, reps);
+    run_phase<false, false, 1, true>("two-phase loop, W pre-blocked, SGPR base + 32-bit offsets, no mfma", a, w, M, 2304, 768, st, sink, warm, reps);
   }
   if (all || !strcmp(set, "phase2")) {
 #define PHASE2_SET(BLK, NAME) \
