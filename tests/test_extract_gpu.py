@@ -141,3 +141,41 @@ def test_device_preprocessing_matches_host_path(dev, tmp_path):
     for v in vids:
         a, b = np.load(tmp_path / "v_host" / f"{v}.npy"), np.load(tmp_path / "v_dev" / f"{v}.npy")
         assert a.shape == b.shape and np.abs(a - b).max() / np.abs(a).max() < 2e-4, v
+
+
+@pytest.mark.skipif(os.environ.get("MER_EXPERIMENTAL") != "1", reason="written without GPU access at the end of round 1; enable with MER_EXPERIMENTAL=1")
+def test_trimodal_pipeline_matches_direct_calls(dev):
+    """TriModalExtractor (copy stream + one stream per modality, two batch slots) returns, batch by batch, exactly what the
+    encoders return when called directly on resident inputs — fp32 inputs and the compact int16 PCM / uint8 BGR forms."""
+    from mertools_amd import ops
+    from mertools_amd.encoders import HipBertModel, HipCLIPModel, HipHubertModel
+    from mertools_amd.extract.trimodal import TriModalExtractor
+    from mertools_amd.extract.visual import CLIP_MEAN, CLIP_STD
+    hc, cc, bc = W.hubert_config("tiny"), W.clip_config("tiny"), W.bert_config("tiny")
+    ma = HipHubertModel(W.hubert_state_dict(hc, 1), hc, device=dev)
+    mv = HipCLIPModel(W.clip_state_dict(cc, 3), cc, device=dev)
+    mt = HipBertModel(W.bert_state_dict(bc, 4), bc, device=dev)
+    size = cc.vision_config.image_size
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for k, B in enumerate([3, 4, 2, 4, 1]):
+        fpc = [1 + (k + i) % 3 for i in range(B)]
+        compact = k % 2 == 1
+        batches.append({
+            "names": [f"b{k}c{i}" for i in range(B)],
+            "audio": (torch.randn(B, 8000, generator=g) * 3000).clamp(-32768, 32767).to(torch.int16) if compact else W.synth_audio(B, 8000, seed=10 + k),
+            "frames": torch.randint(0, 256, (sum(fpc), size, size, 3), dtype=torch.uint8, generator=g) if compact else W.synth_frames(sum(fpc), size, seed=20 + k),
+            "frames_per_clip": fpc,
+            "input_ids": W.synth_tokens(B, 16, vocab=300, seed=30 + k, bos=0, eos=2), "lengths": [16 - (i % 3) for i in range(B)]})
+    eng = TriModalExtractor(ma, mv, mt, device=dev)
+    got = list(eng.run(batches))
+    assert [n for n, _ in got] == [b["names"] for b in batches]
+    for (_, feats), b in zip(got, batches):
+        a, f = b["audio"].to(dev), b["frames"].to(dev)
+        if a.dtype == torch.int16:
+            a = ops.wave_normalize(a, True)
+            f = ops.image_normalize_u8(f, CLIP_MEAN, CLIP_STD, bgr=True)
+        ref_a = ma.extract_utterance(a).cpu().numpy()
+        ref_v = mv.extract_utterance(f, b["frames_per_clip"]).cpu().numpy()
+        ref_t = mt.extract_utterance(b["input_ids"].to(dev), b["lengths"], 1, -1).cpu().numpy()
+        assert np.array_equal(feats["audio"], ref_a) and np.array_equal(feats["visual"], ref_v) and np.array_equal(feats["text"], ref_t)
