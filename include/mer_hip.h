@@ -99,6 +99,11 @@ typedef struct {
    * 256x256 LDS-DMA kernels (a DMA piece becomes 1 KiB contiguous); NULL = not available.  w_lo_blk is only
    * needed for passes 2 / 3. */
   const void* w_hi_blk; const void* w_lo_blk;
+  /* blocked activation planes between two GEMMs (fc1 -> fc2): c16_blocked != 0 writes the 16-bit output as
+   * [ceil(M/256)][N/32] blocks of 16 KB (the LDS image of a 256-row x 32-k stage plane; c16_hi must hold
+   * ceil(M/256)*256 * N elements; N % 32 == 0); a_blocked != 0 reads a_hi in that form (K = the producer's N; only the
+   * 256x256 one-/two-pass kernels: M >= 1024, N >= 192, K % 32 == 0, no batching — anything else is MER_ESHAPE). */
+  int c16_blocked; int a_blocked;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 

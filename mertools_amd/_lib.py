@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("passes", c_int), ("tile", c_int), ("headmajor_T", c_int), ("headmajor_H", c_int),
         ("w_mx", c_void_p),
         ("w_hi_blk", c_void_p), ("w_lo_blk", c_void_p),
+        ("c16_blocked", c_int), ("a_blocked", c_int),
     ]
 
 

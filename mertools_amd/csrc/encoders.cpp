@@ -45,9 +45,13 @@ struct HsMap {
   float* at(int l) const { return base + (long long)(ring ? (l % ring) : l) * stride; }
 };
 
+// mer_set_option("tf_ablk", 1): the FFN's intermediate plane travels fc1 -> fc2 in blocked form (whole-line LDS-DMA pieces for
+// the K = ffn GEMM, whose A traffic dominates: ceiling probe -15 % on CLIP's fc2).  Off by default until measured end to end.
+int g_tf_ablk = 0;
+
 static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 a, long long lda, const mer_w16& w,
                 const float* bias, int act, const float* residual, long long ldr, float* c32, long long ldc32, P16 c16,
-                long long ldc16) {
+                long long ldc16, int c16_blocked = 0, int a_blocked = 0) {
   mer_gemm16_args g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
@@ -57,6 +61,7 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
+  g.c16_blocked = c16_blocked; g.a_blocked = a_blocked;
   return mer_gemm16(&g, (mer_stream_t)st);
 }
 
@@ -84,7 +89,7 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
   b.qkv16 = take16(ar, M * 3 * D, false);
   b.ctx16 = take16(ar, M * D, lo);
   b.h1_16 = take16(ar, M * D, lo);
-  b.f16 = take16(ar, M * F, lo);
+  b.f16 = take16(ar, cdiv(M, 256) * 256 * F, lo);   // rows padded to the 256-row blocks of the blocked fc1 -> fc2 plane
   b.ffn32 = c.ffn_swiglu ? (float*)ar.take(M * 2 * F * 4) : nullptr;
   b.gate = c.gated_rel_pos ? (float*)ar.take(M * c.heads * 4) : nullptr;
   b.gin32 = (c.gated_rel_pos && c.pre_ln) ? (float*)ar.take(M * D * 4) : nullptr;
@@ -100,6 +105,8 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
   const int ps2 = (ps == 4 && (c.mx_skip & 4)) ? 1 : ps;   // fc2 without the correction
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
+  // blocked fc1 -> fc2 plane: only where fc2 runs the 256x256 one-/two-pass kernel (same test as mer_gemm16's tile choice)
+  const int ablk = (g_tf_ablk && !c.ffn_swiglu && ps != 3 && (ps2 == 1 || ps2 == 2) && M >= 1024 && D >= 192 && F % 32 == 0) ? 1 : 0;
   for (int l = 0; l < c.layers; ++l) {
     const mer_tf_layer& w = L[l];
     float* x = hs.at(l);
@@ -142,12 +149,12 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
         MER_TRY(gemm(st, dt, ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0));
         MER_TRY(mer_swiglu(b.ffn32, 2 * F, M, F, b.f16.hi, b.f16.lo, dt, (mer_stream_t)st));
       } else
-      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
-      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0, 0, ablk));
     } else {
       MER_TRY(mer_layernorm(b.t32, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.h1_32, D, b.h1_16.hi, b.h1_16.lo, D, dt, st));
-      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F));
-      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0, 0, ablk));
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, y, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     }
   }

@@ -35,6 +35,8 @@ struct Gemm16Params {
   const void* w_hi; const void* w_lo; long long ldw;
   const void* w_mx;   // MX kernel: packed fp4 + E8M0 correction plane (mer_mx_pack)
   int w_blk;          // w_hi / w_lo are pre-blocked planes (mer_w_block_pack): [n-tile of 256][32-deep k-slab][the 16 KB LDS image]
+  int a_blk;          // a_hi is a blocked activation plane written by a producer GEMM with c16_blk (same block geometry, rows = M)
+  int c16_blk;        // > 0: the 16-bit output is written blocked for a consumer with K = N: value = N / 32 (k-slabs per row tile)
   const float* bias; int act;
   const float* residual; long long ldr;
   float* c32; long long ldc32;
@@ -180,6 +182,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       a_off[i] = (p.a_rpb > 0) ? (long long)(m / p.a_rpb) * p.a_bstride + (long long)(m % p.a_rpb) * p.lda
                                : (long long)m * p.lda;
       a_src[i] = a_off[i] + ((ld_ch ^ swz_of<C>(ld_row0 + i * ROWS_PER_IT)) << 3);
+      if constexpr (!MX) {   // blocked activation plane: same [tile][k-slab][LDS image] geometry as the pre-blocked weights
+        if (p.a_blk) a_src[i] = ((long long)(m0_ / BM) * (p.K / BK)) * (BM * BK) + (long long)(ld_row0 + i * ROWS_PER_IT) * BK + ld_ch * 8;
+      }
     }
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     mx_o32 = (unsigned)((tid < 320 ? tid : 256 + (tid & 63)) * 16);
   }
   const long long w_kmul = p.w_blk ? BN : 1;   // element distance of consecutive k (row-major) or of consecutive k-slabs / BK (pre-blocked)
+  const long long a_kmul = (!MX && p.a_blk) ? BM : 1;
   const char* mx_base = MX ? (const char*)p.w_mx + ((long long)tile_n * ((p.K + BK - 1) / BK)) * MX_BLOCK : nullptr;
   auto glds_issue = [&](int k0, int stage) {
     char* base = smem + stage * STAGE;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       for (int pl = 0; pl < AP; ++pl)
 #pragma unroll
         for (int i = 0; i < CA; ++i)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0),
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0 * a_kmul),
                                            (lds_void_t*)(base + pl * A_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
 #pragma unroll
       for (int pl = 0; pl < WP; ++pl)
@@ -428,6 +434,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
               const int dd = p.hm_H * 64, which = col / dd, hh2 = (col % dd) >> 6, d0 = col & 63;
               const int bb = row / p.hm_T, tt = row % p.hm_T;
               o16 = ((((long long)which * (p.M / p.hm_T) + bb) * p.hm_H + hh2) * p.hm_T + tt) * 64 + d0;
+            }
+            if (p.c16_blk > 0) {  // blocked plane for the consumer GEMM: block (row / 256, col / 32), row image of 64 B, chunks XOR-swizzled
+              const int rr = row & 255, lc = (col & 31) >> 3;
+              o16 = ((((long long)(row >> 8) * p.c16_blk + (col >> 5)) * 256 + rr) << 5) + ((lc ^ swz_of<4>(rr)) << 3);
             }
             *reinterpret_cast<v8*>(c16h + o16) = h;
             if (c16l) {  // lo plane only when a 3-pass consumer needs it (3 extra VALU per element otherwise wasted)
@@ -762,13 +772,14 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
   return MER_OK;
 }
 
-namespace mer { extern int g_attn_force_nkt; }
+namespace mer { extern int g_attn_force_nkt; extern int g_tf_ablk; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
   if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
   if (name && strcmp(name, "gemm_wblk") == 0) { mer::g_gemm_wblk = value; return MER_OK; }
+  if (name && strcmp(name, "tf_ablk") == 0) { mer::g_tf_ablk = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
@@ -896,7 +907,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   Gemm16Params p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
-  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0;
+  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0; p.a_blk = 0; p.c16_blk = 0;
   p.bias = a->bias; p.act = a->act;
   p.residual = a->residual; p.ldr = a->ldr;
   p.c32 = a->c32; p.ldc32 = a->ldc32;
@@ -941,6 +952,17 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
     p.w_hi = a->w_hi_blk;
     p.w_lo = a->w_lo_blk;
     p.w_blk = 1;
+  }
+  if (a->c16_blocked) {
+    MER_REQUIRE(a->c16_hi && !a->c16_lo && vec && a->N % 32 == 0 && a->headmajor_T == 0 && nbatch == 1, MER_ESHAPE,
+                "mer_gemm16: a blocked 16-bit output needs c16_hi only, N %% 32 == 0, aligned outputs, no batching (N=%d)", a->N);
+    p.c16_blk = a->N / 32;
+  }
+  if (a->a_blocked) {
+    // the plane has no row-major form to fall back to: the caller must only ask for what the 256x256 LDS-DMA kernels cover
+    MER_REQUIRE(tile == 3 && passes != 4 && passes != 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && a->a_rows_per_batch == 0 && !g_gemm_persist, MER_ESHAPE,
+                "mer_gemm16: a blocked A plane needs the 256x256 one-/two-pass kernel (tile %d, passes %d, K=%d)", tile, passes, a->K);
+    p.a_blk = 1;
   }
   if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, passes, tile, st);
   return dispatch<bf16>(p, nbatch, passes, tile, st);

@@ -57,7 +57,7 @@ def split16_host(x, dtype="f16", lo=True):
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
            out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
-           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None):
+           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, c16_blocked=False, a_blocked=False):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -71,11 +71,12 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.w_hi, g.w_lo, g.ldw = _p(w_hi), _p(w_lo), w_hi.stride(0)
     g.w_mx = _p(w_mx)
     g.w_hi_blk, g.w_lo_blk = _p(w_hi_blk), _p(w_lo_blk)
+    g.c16_blocked, g.a_blocked = int(c16_blocked), int(a_blocked)
     g.bias, g.act = _p(bias), ACT[act]
     g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     dev = a_hi.device
     c32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out32 else None
-    c16h = torch.empty((M, N), dtype=torch16(dtype), device=dev) if out16 else None
+    c16h = torch.empty(((M + 255) // 256 * 256 if c16_blocked else M, N), dtype=torch16(dtype), device=dev) if out16 else None
     c16l = torch.empty((M, N), dtype=torch16(dtype), device=dev) if (out16 and out16_lo) else None
     g.c32, g.ldc32 = _p(c32), N
     g.c16_hi, g.c16_lo, g.ldc16 = _p(c16h), _p(c16l), N
