@@ -202,6 +202,7 @@ def main():
         dom = max(recs.values(), key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic = None  # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh)
+        traffic_detail = None
         pmc_file, pmc_key = {"gemm16_w2": ("r01_pmc_hbm_traffic.json", "gemm16<DF16_Li256>"),
                              "gemm16_mx": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,4,2,1,1,1,3,1,0>"),
                              "gemm16": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,2,4,1,1,1,4,0,0>")}.get(dom["name"], (None, None))
@@ -209,10 +210,11 @@ def main():
         if pmc_file and os.path.exists(pmc):
             k = json.load(open(pmc)).get(pmc_key)
             if k:
-                traffic = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
-                           "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/" + pmc_file.replace(".json", ".txt")}
+                traffic_detail = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
+                                  "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/" + pmc_file.replace(".json", ".txt")}
+                traffic = round((k["fetch_mb_x2"] + k["write_mb"]) * 1e6)   # HBM-side bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE)
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                     # the default 2-pass (weights hi+lo) kernel issues 2x the algorithmic MFMA work; 3-pass 3x
                     # (gemm16_mx: one f16 pass + a bf8 x fp4 K=128 correction at the fp8 MFMA rate = 1.5 f16-pass equivalents)
                     "mfma_passes": MFMA_PASSES.get(dom["name"], 1),
