@@ -153,8 +153,10 @@ def device_normalize(samples, do_normalize, device):
 
 
 def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
-            reader=read_audio, device_preprocess=False):
-    """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy."""
+            reader=read_audio, device_preprocess=False, workers=0):
+    """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy.
+    workers: threads that read and normalise the clips ahead of the bucketing loop (extract.prefetch; 0 = in line)."""
+    from .prefetch import prefetch_map
     if model_name in (WHISPER_BASE, WHISPER_LARGE) or type(model).__name__ == 'HipWhisperModel':
         return extract_whisper(model_name, audio_files, save_dir, feature_level, gpu, model=model, reader=reader)   # reference :79-89
     start_time = time.time()
@@ -164,13 +166,17 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
     # bucket clips by the shape they have after split_into_batch: equal-length rows batch without any masking
     # (the reference never masks audio, and GroupNorm runs over the whole row, so padding would change results)
     buckets = {}
-    for audio_file in audio_files:
+
+    def host_stage(audio_file):
         samples, sr = reader(audio_file)
         assert sr == 16000, 'currently, we only test on 16k audio'
         if device_preprocess:
-            iv = split_into_batch(device_normalize(samples, do_normalize, model.device))
-        else:
-            iv = split_into_batch(wav2vec2_normalize(samples, do_normalize))
+            return audio_file, samples
+        return audio_file, split_into_batch(wav2vec2_normalize(samples, do_normalize))
+
+    for audio_file, iv in prefetch_map(host_stage, audio_files, workers):
+        if device_preprocess:   # GPU work stays on the calling thread
+            iv = split_into_batch(device_normalize(iv, do_normalize, model.device))
         buckets.setdefault(tuple(iv.shape), []).append((os.path.basename(audio_file)[:-4], iv))
 
     def flush(items):

@@ -72,14 +72,17 @@ def save_embeddings(save_file, embeddings, feature_level, embedding_dim):
 
 
 def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
-            device_preprocess=False):
+            device_preprocess=False, workers=0):
     """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video.
     device_preprocess: frames that already have the model's resolution go to the GPU as uint8 (a quarter of the fp32 bytes)
-    and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path."""
+    and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path.
+    workers: threads that read and pre-process videos ahead of the GPU loop (extract.prefetch; 0 = in line, as the reference)."""
+    from .prefetch import prefetch_map
     os.makedirs(save_dir, exist_ok=True)
     vids = vids if vids is not None else os.listdir(face_dir)
     embedding_dim = -1
     pending, nframes = [], 0
+    size = model.config.vision_config.image_size
 
     def flush():
         nonlocal pending, nframes, embedding_dim
@@ -95,18 +98,22 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             r += n
         pending, nframes = [], 0
 
-    for vid in vids:
+    def host_stage(vid):   # everything that needs no GPU: file read + (PIL) pre-processing
         frames = reader(face_dir, vid)
         if len(frames) == 0:
+            return vid, None, None
+        if device_preprocess and frames.shape[1:3] == (size, size) and frames.dtype == np.uint8:
+            return vid, 'u8', torch.from_numpy(np.ascontiguousarray(frames))
+        return vid, 'f32', clip_preprocess(frames, size)
+
+    for vid, kind, px in prefetch_map(host_stage, vids, workers):
+        if kind is None:
             flush()
             save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
             continue
-        size = model.config.vision_config.image_size
-        if device_preprocess and frames.shape[1:3] == (size, size) and frames.dtype == np.uint8:
+        if kind == 'u8':
             from .. import ops
-            px = ops.image_normalize_u8(torch.from_numpy(np.ascontiguousarray(frames)).to(model.device), CLIP_MEAN, CLIP_STD, bgr=True)
-        else:
-            px = clip_preprocess(frames, size)
+            px = ops.image_normalize_u8(px.to(model.device), CLIP_MEAN, CLIP_STD, bgr=True)
         if nframes + len(px) > frames_per_batch:
             flush()
         pending.append((vid, px))
