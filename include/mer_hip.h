@@ -418,6 +418,18 @@ int mer_wave_normalize(const void* x, int is_int16, long long ldx, int B, int L,
 int mer_image_normalize_u8(const unsigned char* frames, int N, int H, int W, int bgr, const float* mean3,
                            const float* std3, float* out, mer_stream_t stream);
 
+/* Pillow-exact bicubic resize + centre crop of 8-bit frames on the GPU (reference a6: processor(images=...) ->
+ * CLIPImageProcessor.resize -> PIL Image.resize(BICUBIC) on uint8, then center_crop;
+ * MERBench/feature_extraction/visual/extract_vision_huggingface.py:116).  frames: DEVICE u8 [N,H,W,3]; out: DEVICE u8
+ * [N,crop_h,crop_w,3] = the window (left, top, crop_w, crop_h) of the resized image.  xb / yb: DEVICE int32 [new, 2]
+ * (first input index, tap count) per output column / row; xk / yk: DEVICE int32 [new, ksize] fixed-point coefficients
+ * (22 fractional bits) — Pillow's precompute_coeffs + normalize_coeffs_8bpc, built on the host per (input, output) size
+ * (mertools_amd/extract/resize.py:pil_coeffs).  y0..y1-1: the input rows the cropped output rows touch; tmp: DEVICE u8
+ * [N, y1-y0, crop_w, 3] (the 8-bit image between the two passes, as in Pillow).  Byte-identical to Pillow. */
+int mer_image_resize_crop_u8(const unsigned char* frames, int N, int H, int W, int left, int top, int crop_w, int crop_h,
+                             const int* xb, const int* xk, int xksize, const int* yb, const int* yk, int yksize, int y0, int y1,
+                             unsigned char* tmp, unsigned char* out, mer_stream_t stream);
+
 /* SwiGLU gate: out[m, j] = silu(y[m, j]) * y[m, F + j] for y fp32 [M, 2F] (row stride ldy) -> 16-bit planes [M, F]. */
 int mer_swiglu(const float* y, long long ldy, int M, int F, void* out_hi, void* out_lo, int dtype, mer_stream_t stream);
 

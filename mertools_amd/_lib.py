@@ -185,6 +185,8 @@ _PROTOS = {
     "mer_lstm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mer_wave_normalize": (c_int, [c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_ll, c_void_p]),
     "mer_image_normalize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mer_image_resize_crop_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mer_swiglu": (c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mer_token_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mer_videomae_create": (c_int, [C.POINTER(VideoMAEConfig), C.POINTER(VideoMAEWeights), C.POINTER(c_void_p)]),

@@ -450,6 +450,61 @@ __global__ void image_normalize_u8_kernel(const unsigned char* in, long long npi
   }
 }
 
+// Pillow-exact 8-bit bicubic resampling, one axis per kernel (Resample.c: ImagingResampleHorizontal_8bpc / Vertical_8bpc):
+//   out = clip8((2^21 + sum_t in[first + t] * k[t]) >> 22), int32 accumulation, k = fixed-point coefficients (22 fractional bits).
+// The host supplies the per-output-pixel windows and coefficients (mertools_amd/extract/resize.py:pil_coeffs); only the
+// centre-crop region is computed: the horizontal pass writes rows y0..y1-1 x the cropped columns, the vertical pass the
+// cropped rows.  One thread per output pixel (3 channels).
+__device__ __forceinline__ unsigned char pil_clip8(int ss) {
+  const int v = ss >> 22;   // arithmetic shift, as Pillow's clip8 lookup index
+  return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ void pil_resize_h_kernel(const unsigned char* in, int N, int H, int W, int left, int crop_w, const int* xb, const int* xk, int ksize,
+                                    int y0, int rows, unsigned char* tmp) {
+  const long long total = (long long)N * rows * crop_w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xo = (int)(i % crop_w);
+    const int yr = (int)((i / crop_w) % rows);
+    const long long n = i / ((long long)crop_w * rows);
+    const int ox = left + xo, first = xb[2 * ox], cnt = xb[2 * ox + 1];
+    const int* k = xk + (long long)ox * ksize;
+    const unsigned char* p = in + ((n * H + (y0 + yr)) * W + first) * 3;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int t = 0; t < cnt; ++t) {
+      const int kv = k[t];
+      s0 += (int)p[3 * t] * kv;
+      s1 += (int)p[3 * t + 1] * kv;
+      s2 += (int)p[3 * t + 2] * kv;
+    }
+    unsigned char* o = tmp + i * 3;
+    o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
+  }
+}
+
+__global__ void pil_resize_v_kernel(const unsigned char* tmp, int N, int rows, int crop_w, int top, int crop_h, const int* yb, const int* yk, int ksize,
+                                    int y0, unsigned char* out) {
+  const long long total = (long long)N * crop_h * crop_w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xo = (int)(i % crop_w);
+    const int yo = (int)((i / crop_w) % crop_h);
+    const long long n = i / ((long long)crop_w * crop_h);
+    const int oy = top + yo, first = yb[2 * oy], cnt = yb[2 * oy + 1];
+    const int* k = yk + (long long)oy * ksize;
+    const unsigned char* p = tmp + ((n * rows + (first - y0)) * crop_w + xo) * 3;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int t = 0; t < cnt; ++t) {
+      const int kv = k[t];
+      const unsigned char* q = p + (long long)t * crop_w * 3;
+      s0 += (int)q[0] * kv;
+      s1 += (int)q[1] * kv;
+      s2 += (int)q[2] * kv;
+    }
+    unsigned char* o = out + i * 3;
+    o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
+  }
+}
+
 // SwiGLU gate of DINOv2-giant's feed-forward: 4 elements per thread, fp32 in, 16-bit planes out
 template <typename T>
 __global__ void swiglu_kernel(const float* y, long long ldy, int M, int F, T* ohi, T* olo) {
@@ -644,6 +699,22 @@ extern "C" int mer_image_normalize_u8(const unsigned char* frames, int N, int H,
   hipLaunchKernelGGL(image_normalize_u8_kernel, dim3(grid_for(hw, 256) > 1024 ? 1024 : grid_for(hw, 256), N), dim3(256), 0,
                      (hipStream_t)stream, frames, hw, bgr, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
   return check_launch("image_normalize_u8");
+}
+
+extern "C" int mer_image_resize_crop_u8(const unsigned char* frames, int N, int H, int W, int left, int top, int crop_w, int crop_h,
+                                        const int* xb, const int* xk, int xksize, const int* yb, const int* yk, int yksize, int y0, int y1,
+                                        unsigned char* tmp, unsigned char* out, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(frames && xb && xk && yb && yk && tmp && out, MER_EINVAL, "mer_image_resize_crop_u8: null pointer");
+  MER_REQUIRE(N > 0 && H > 0 && W > 0 && crop_w > 0 && crop_h > 0 && left >= 0 && top >= 0 && xksize > 0 && yksize > 0 && y0 >= 0 && y1 > y0 && y1 <= H,
+              MER_ESHAPE, "mer_image_resize_crop_u8: bad geometry (N=%d H=%d W=%d crop %dx%d at (%d,%d), rows %d..%d)", N, H, W, crop_w, crop_h, left, top, y0, y1);
+  const int rows = y1 - y0;
+  hipStream_t st = (hipStream_t)stream;
+  const long long nh = (long long)N * rows * crop_w, nv = (long long)N * crop_h * crop_w;
+  hipLaunchKernelGGL(pil_resize_h_kernel, dim3(grid_for(nh, 256)), dim3(256), 0, st, frames, N, H, W, left, crop_w, xb, xk, xksize, y0, rows, tmp);
+  { const int rc_ = check_launch("image_resize_h"); if (rc_ != MER_OK) return rc_; }
+  hipLaunchKernelGGL(pil_resize_v_kernel, dim3(grid_for(nv, 256)), dim3(256), 0, st, tmp, N, rows, crop_w, top, crop_h, yb, yk, yksize, y0, out);
+  return check_launch("image_resize_v");
 }
 
 extern "C" int mer_swiglu(const float* y, long long ldy, int M, int F, void* out_hi, void* out_lo, int dtype, mer_stream_t stream) {

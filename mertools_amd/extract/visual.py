@@ -75,7 +75,9 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             device_preprocess=False, workers=0):
     """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video.
     device_preprocess: frames that already have the model's resolution go to the GPU as uint8 (a quarter of the fp32 bytes)
-    and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path.
+    and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path —
+    unless device_preprocess == "resize": then every uint8 video goes up as bytes and the Pillow-exact bicubic resize +
+    centre crop runs on the GPU as well (extract.resize / mer_image_resize_crop_u8; no PIL on the host at all).
     workers: threads that read and pre-process videos ahead of the GPU loop (extract.prefetch; 0 = in line, as the reference)."""
     from .prefetch import prefetch_map
     os.makedirs(save_dir, exist_ok=True)
@@ -102,7 +104,7 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
         frames = reader(face_dir, vid)
         if len(frames) == 0:
             return vid, None, None
-        if device_preprocess and frames.shape[1:3] == (size, size) and frames.dtype == np.uint8:
+        if device_preprocess and frames.dtype == np.uint8 and (frames.shape[1:3] == (size, size) or device_preprocess == 'resize'):
             return vid, 'u8', torch.from_numpy(np.ascontiguousarray(frames))
         return vid, 'f32', clip_preprocess(frames, size)
 
@@ -113,7 +115,11 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             continue
         if kind == 'u8':
             from .. import ops
-            px = ops.image_normalize_u8(px.to(model.device), CLIP_MEAN, CLIP_STD, bgr=True)
+            px = px.to(model.device)
+            if tuple(px.shape[1:3]) != (size, size):
+                from .resize import resize_crop_u8
+                px = resize_crop_u8(px, size)
+            px = ops.image_normalize_u8(px, CLIP_MEAN, CLIP_STD, bgr=True)
         if nframes + len(px) > frames_per_batch:
             flush()
         pending.append((vid, px))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of the next round: runs what round 1 wrote after its GPU budget ran out, then A/Bs the opt-in switches.
 #   1. the gated tests (MER_EXPERIMENTAL=1): blocked fc1 -> fc2 activation plane (bit-exact vs row-major), tf_ablk option,
-#      the tri-modal pipeline against direct encoder calls
+#      the tri-modal pipeline against direct encoder calls, the Pillow-exact GPU resize (bytes vs PIL, driver vs host path)
 #   2. bench.py default vs MER_OPTIONS=tf_ablk=1 (probe estimate: -15 % on CLIP's fc2 = +1.5-2 % clips/s)
 # Everything lands in gpurun_out/ab_round2/.  Budget: ~2 GPU-minutes.
 set -u
@@ -9,7 +9,7 @@ out=gpurun_out/ab_round2
 mkdir -p $out
 export TMPDIR=/tmp
 MER_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_ops_gpu.py tests/test_extract_gpu.py -m gpu -q --no-header -p no:cacheprovider \
-  -k "blocked_activation or tf_ablk or trimodal" > $out/gated_tests.log 2>&1
+  -k "blocked_activation or tf_ablk or trimodal or resize" > $out/gated_tests.log 2>&1
 echo "gated tests rc=$?" | tee $out/summary.txt
 tail -5 $out/gated_tests.log
 for opt in "" "tf_ablk=1"; do

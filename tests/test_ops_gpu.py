@@ -551,3 +551,21 @@ def test_tf_ablk_option_is_bit_exact(dev):
     finally:
         _lib.lib().mer_set_option(b"tf_ablk", 0)
     assert torch.equal(out, ref)
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("h,w,size", [(256, 320, 224), (300, 200, 224), (100, 100, 224), (480, 640, 224), (231, 517, 224), (224, 224, 224), (40, 52, 32)])
+def test_image_resize_crop_u8_matches_pillow(dev, h, w, size):
+    """mer_image_resize_crop_u8 (two integer passes on the GPU, cropped region only) == PIL Image.resize(BICUBIC) + centre crop,
+    byte for byte — the reference's CLIPImageProcessor path on uint8 frames."""
+    import numpy as np
+    from PIL import Image
+    from mertools_amd.extract.resize import resize_crop_u8, shortest_edge_geometry
+    rng = np.random.RandomState(h * 1000 + w)
+    frames = rng.randint(0, 256, (5, h, w, 3), dtype=np.uint8)
+    frames[:, : h // 2] = np.linspace(0, 255, w)[None, None, :, None].astype(np.uint8)
+    out = resize_crop_u8(torch.from_numpy(frames).to(dev), size).cpu().numpy()
+    nw, nh, left, top, crop = shortest_edge_geometry(h, w, size)
+    for n in range(frames.shape[0]):
+        ref = np.asarray(Image.fromarray(frames[n]).resize((nw, nh), resample=Image.BICUBIC))[top:top + crop, left:left + crop]
+        assert np.array_equal(out[n], ref), n

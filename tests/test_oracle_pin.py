@@ -231,3 +231,40 @@ def test_electra_and_albert_oracle_match_hf():
     assert len(ours) == len(hs) == c.num_hidden_layers + 1
     for a, b in zip(ours, hs):
         assert torch.allclose(a, b, rtol=0, atol=1e-5)
+
+
+def test_pil_bicubic_restatement_matches_pillow():
+    """oracle.host_ref.pil_resize_bicubic_u8 (Pillow's 8-bit two-pass fixed-point resampler, restated) against the installed
+    Pillow itself: byte-identical for down- and up-scaling, one- and two-axis resizes, tiny and large inputs."""
+    from PIL import Image
+    from oracle.host_ref import pil_resize_bicubic_u8
+    rng = np.random.RandomState(0)
+    for (h, w, nh, nw) in [(256, 320, 224, 280), (320, 256, 280, 224), (112, 112, 224, 224), (500, 375, 298, 224), (224, 224, 224, 224),
+                           (97, 131, 224, 302), (480, 640, 224, 298), (224, 300, 224, 300), (30, 40, 224, 298), (64, 64, 17, 23)]:
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        img[: h // 2] = np.linspace(0, 255, w)[None, :, None].astype(np.uint8)      # a smooth half next to a noisy half
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), resample=Image.BICUBIC))
+        assert np.array_equal(pil_resize_bicubic_u8(img, nw, nh), ref), (h, w, nh, nw)
+
+
+def test_device_resize_tables_and_geometry():
+    """The product's per-axis tables (mertools_amd/extract/resize.py, what the GPU kernels consume) equal the oracle's, and its
+    shortest-edge / centre-crop geometry reproduces the host pre-processing (clip_preprocess = PIL + the processor's crop)."""
+    from oracle.host_ref import pil_resample_coeffs, pil_resize_bicubic_u8
+    from mertools_amd.extract.resize import pil_coeffs, shortest_edge_geometry
+    from mertools_amd.extract.visual import CLIP_MEAN, CLIP_STD, clip_preprocess
+    for i, o in [(320, 280), (256, 224), (112, 224), (500, 298), (224, 224), (97, 224), (640, 298), (1080, 224), (1920, 398), (225, 224), (30, 224)]:
+        b, k = pil_resample_coeffs(i, o)
+        b2, k2, ks = pil_coeffs(i, o)
+        assert np.array_equal(b, b2) and np.array_equal(k, k2) and k.shape[1] == ks, (i, o)
+    rng = np.random.RandomState(1)
+    mean = np.array(CLIP_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(CLIP_STD, dtype=np.float32)[:, None, None]
+    for h, w in [(256, 320), (300, 200), (100, 100), (224, 224), (231, 517)]:
+        f = rng.randint(0, 256, (2, h, w, 3), dtype=np.uint8)       # BGR frames as the reader returns them
+        nw, nh, left, top, crop = shortest_edge_geometry(h, w, 224)
+        ref = clip_preprocess(f, 224).numpy()
+        for n in range(2):
+            r = pil_resize_bicubic_u8(f[n], nw, nh)[top:top + crop, left:left + crop]
+            rgb = r[:, :, ::-1].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+            assert np.array_equal((rgb - mean) / std, ref[n]), (h, w)
