@@ -24,18 +24,28 @@ def _bicubic(x):
                     np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
 
 
+def _bilinear(x):
+    """Pillow's bilinear_filter (triangle, support 1)."""
+    x = np.abs(x)
+    return np.where(x < 1.0, 1.0 - x, 0.0)
+
+
+FILTERS = {"bicubic": (_bicubic, 2.0), "bilinear": (_bilinear, 1.0)}
+
+
 @functools.lru_cache(maxsize=256)
-def pil_coeffs(in_size, out_size):
+def pil_coeffs(in_size, out_size, filt="bicubic"):
     """-> (bounds int32 [out, 2] = (first input index, tap count), coeffs int32 [out, ksize], ksize) for one axis."""
+    _filter, base_support = FILTERS[filt]
     scale = float(in_size) / out_size
     filterscale = max(scale, 1.0)
-    support = 2.0 * filterscale
+    support = base_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
     xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)        # astype truncates toward zero like a C cast
     xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
     taps = np.arange(ksize, dtype=np.float64)[None, :]
-    w = _bicubic((taps + xmin[:, None] - center[:, None] + 0.5) * (1.0 / filterscale))
+    w = _filter((taps + xmin[:, None] - center[:, None] + 0.5) * (1.0 / filterscale))
     w = np.where(taps < xmax[:, None], w, 0.0)
     ww = np.zeros(out_size, dtype=np.float64)
     for t in range(ksize):                                                  # Pillow sums the taps left to right
@@ -61,28 +71,33 @@ def shortest_edge_geometry(h, w, size, crop=None):
 _DEVICE_TABLES = {}
 
 
-def device_tables(in_size, out_size, device):
-    """The axis tables as device int32 tensors, cached per (sizes, device)."""
+def device_tables(in_size, out_size, device, filt="bicubic"):
+    """The axis tables as device int32 tensors, cached per (sizes, filter, device)."""
     import torch
-    key = (in_size, out_size, str(device))
+    key = (in_size, out_size, filt, str(device))
     t = _DEVICE_TABLES.get(key)
     if t is None:
-        b, k, ks = pil_coeffs(in_size, out_size)
+        b, k, ks = pil_coeffs(in_size, out_size, filt)
         t = _DEVICE_TABLES[key] = (torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ks, b)
     return t
 
 
-def resize_crop_u8(frames, size, crop=None):
-    """Device uint8 [N, h, w, 3] -> device uint8 [N, crop, crop, 3]: Pillow-exact bicubic shortest-edge resize + centre crop."""
+def resize_crop_u8(frames, size, crop=None, filt="bicubic", exact=False):
+    """Device uint8 [N, h, w, 3] -> device uint8 [N, crop, crop, 3]: Pillow-exact resize + centre crop.
+    exact=False: the shortest edge becomes `size` (CLIP / VideoMAE / DINOv2 processors); exact=True: resize to size x size
+    without keeping the aspect ratio and without a crop (BEiT / data2vec-vision processor)."""
     import torch
     from .. import _lib
     from ..ops import stream
     assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
     N, h, w, _ = frames.shape
-    new_w, new_h, left, top, crop = shortest_edge_geometry(h, w, size, crop)
+    if exact:
+        new_w, new_h, left, top, crop = size, size, 0, 0, size
+    else:
+        new_w, new_h, left, top, crop = shortest_edge_geometry(h, w, size, crop)
     assert left >= 0 and top >= 0, "crop larger than the resized image is not supported"   # (HF pads in that case)
-    xb, xk, xks, _ = device_tables(w, new_w, frames.device)
-    yb, yk, yks, yb_host = device_tables(h, new_h, frames.device)
+    xb, xk, xks, _ = device_tables(w, new_w, frames.device, filt)
+    yb, yk, yks, yb_host = device_tables(h, new_h, frames.device, filt)
     y0 = int(yb_host[top, 0])
     y1 = int(yb_host[top + crop - 1, 0] + yb_host[top + crop - 1, 1])
     tmp = torch.empty((N, y1 - y0, crop, 3), dtype=torch.uint8, device=frames.device)
@@ -91,3 +106,43 @@ def resize_crop_u8(frames, size, crop=None):
                                                    xb.data_ptr(), xk.data_ptr(), xks, yb.data_ptr(), yk.data_ptr(), yks, y0, y1,
                                                    tmp.data_ptr(), out.data_ptr(), stream()), "mer_image_resize_crop_u8")
     return out
+
+
+# processor recipes of the reference's visual branches (extract_vision_huggingface.py:116,125,137,151): geometry, filter, mean / std
+_IMAGENET = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+RECIPES = {
+    "clip": dict(size=224, crop=None, filt="bicubic", exact=False, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)),
+    "videomae": dict(size=224, crop=None, filt="bilinear", exact=False, mean=_IMAGENET[0], std=_IMAGENET[1]),
+    "dinov2": dict(size=256, crop=224, filt="bicubic", exact=False, mean=_IMAGENET[0], std=_IMAGENET[1]),
+    "data2vec-vision": dict(size=224, crop=None, filt="bicubic", exact=True, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)),
+}
+
+
+def recipe_geometry(recipe, h, w, size=None):
+    """-> dict(new_w, new_h, left, top, crop, filt, mean, std, size, exact) for frames of h x w under a branch's processor;
+    `size` overrides the model resolution (default 224; DINOv2 keeps resizing to 256 and crops `size`, as dinov2_preprocess)."""
+    r = dict(RECIPES[recipe])
+    if size is not None:
+        if r["crop"]:
+            r["crop"] = size
+        else:
+            r["size"] = size
+    if r["exact"]:
+        new_w, new_h, left, top, crop = r["size"], r["size"], 0, 0, r["size"]
+    else:
+        new_w, new_h, left, top, crop = shortest_edge_geometry(h, w, r["size"], r["crop"])
+    r.update(new_w=new_w, new_h=new_h, left=left, top=top, crop=crop)
+    return r
+
+
+def device_preprocess_u8(frames_bgr, device, recipe, size=None):
+    """Host uint8 BGR frames [N, h, w, 3] (what the reference's readers return) -> device float32 [N, 3, S, S] exactly as the
+    branch's HF image processor would produce: bytes over PCIe, Pillow-exact resize + centre crop and the rescale / normalise
+    arithmetic on the GPU."""
+    import torch
+    from .. import ops
+    px = torch.as_tensor(np.ascontiguousarray(frames_bgr)).to(device)
+    g = recipe_geometry(recipe, px.shape[1], px.shape[2], size)
+    if (g["new_w"], g["new_h"]) != (px.shape[2], px.shape[1]) or g["crop"] != px.shape[1] or g["crop"] != px.shape[2]:
+        px = resize_crop_u8(px, g["size"], crop=g["crop"], filt=g["filt"], exact=g["exact"])
+    return ops.image_normalize_u8(px, g["mean"], g["std"], bgr=True)

@@ -127,6 +127,16 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
     flush()
 
 
+
+def _branch_preprocess(frames, recipe, host_fn, model, size, device_preprocess):
+    """Host PIL path (default, as the reference) or, with device_preprocess == "resize" on uint8 frames, bytes up + the
+    Pillow-exact resize / crop / normalise on the GPU (extract.resize recipes)."""
+    if device_preprocess == 'resize' and frames.dtype == np.uint8:
+        from .resize import device_preprocess_u8
+        return device_preprocess_u8(frames, model.device, recipe, size)
+    return host_fn(frames)
+
+
 # ---- VideoMAE branch (reference :147-159) -------------------------------------------------------------------------
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -153,7 +163,8 @@ def videomae_preprocess(frames_bgr, size=224):
     return torch.from_numpy(out)[None]
 
 
-def extract_videomae(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, videos_per_batch=8, reader=func_read_frames):
+def extract_videomae(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, videos_per_batch=8, reader=func_read_frames,
+                     device_preprocess=False):
     """VideoMAE branch of the reference loop: 16 uniformly resampled frames per video -> last_hidden_state ->
     view(8, 196, D).mean(1) -> [8, D] (FRAME) or its mean (UTTERANCE).  `model`: HipVideoMAEModel; videos are batched."""
     os.makedirs(save_dir, exist_ok=True)
@@ -171,7 +182,9 @@ def extract_videomae(model, face_dir, save_dir, feature_level='UTTERANCE', vids=
 
     for vid in vids:
         frames = resample_frames_uniform(reader(face_dir, vid), nframe=model.config.num_frames)
-        pending.append((vid, videomae_preprocess(frames, model.config.image_size)))
+        size = model.config.image_size
+        px = _branch_preprocess(frames, 'videomae', lambda f: videomae_preprocess(f, size), model, size, device_preprocess)
+        pending.append((vid, px if px.dim() == 5 else px[None]))
         if len(pending) >= videos_per_batch:
             flush()
     flush()
@@ -199,7 +212,8 @@ def dinov2_preprocess(frames_bgr, size=224, resize_to=256):
     return torch.from_numpy(out)
 
 
-def extract_dinov2(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames, nframe=64):
+def extract_dinov2(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames, nframe=64,
+                   device_preprocess=False):
     """DINOv2 branch of the reference loop: 64 uniformly resampled frames per video (:134) -> token SUM of the last hidden
     state per frame (:141-142) -> [64, D] (FRAME) or its mean (UTTERANCE).  `model`: HipDinov2Model; videos share batches."""
     os.makedirs(save_dir, exist_ok=True)
@@ -225,7 +239,8 @@ def extract_dinov2(model, face_dir, save_dir, feature_level='UTTERANCE', vids=No
             flush()
             save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
             continue
-        px = dinov2_preprocess(resample_frames_uniform(frames, nframe=nframe), model._cfg.image_size)
+        size = model._cfg.image_size
+        px = _branch_preprocess(resample_frames_uniform(frames, nframe=nframe), 'dinov2', lambda f: dinov2_preprocess(f, size), model, size, device_preprocess)
         if nframes + len(px) > frames_per_batch:
             flush()
         pending.append((vid, px))
@@ -248,7 +263,8 @@ def data2vec_vision_preprocess(frames_bgr, size=224):
     return torch.from_numpy(out)
 
 
-def extract_data2vec_vision(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames):
+def extract_data2vec_vision(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
+                            device_preprocess=False):
     """data2vec-vision branch: ALL frames of a video (no resampling) -> token sum of the last hidden state per frame (:130-131)."""
     os.makedirs(save_dir, exist_ok=True)
     vids = vids if vids is not None else os.listdir(face_dir)
@@ -273,7 +289,8 @@ def extract_data2vec_vision(model, face_dir, save_dir, feature_level='UTTERANCE'
             flush()
             save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
             continue
-        px = data2vec_vision_preprocess(frames, model._cfg.image_size)
+        size = model._cfg.image_size
+        px = _branch_preprocess(frames, 'data2vec-vision', lambda f: data2vec_vision_preprocess(f, size), model, size, device_preprocess)
         if nframes + len(px) > frames_per_batch:
             flush()
         pending.append((vid, px))

@@ -268,3 +268,40 @@ def test_device_resize_tables_and_geometry():
             r = pil_resize_bicubic_u8(f[n], nw, nh)[top:top + crop, left:left + crop]
             rgb = r[:, :, ::-1].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
             assert np.array_equal((rgb - mean) / std, ref[n]), (h, w)
+
+
+def test_pil_bilinear_restatement_matches_pillow():
+    from PIL import Image
+    from oracle.host_ref import pil_resample_coeffs, pil_resize_u8
+    from mertools_amd.extract.resize import pil_coeffs
+    rng = np.random.RandomState(2)
+    for (h, w, nh, nw) in [(256, 320, 224, 280), (112, 112, 224, 224), (500, 375, 298, 224), (97, 131, 224, 302), (480, 640, 224, 298), (64, 64, 17, 23)]:
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), resample=Image.BILINEAR))
+        assert np.array_equal(pil_resize_u8(img, nw, nh, "bilinear"), ref), (h, w, nh, nw)
+        for i, o in ((h, nh), (w, nw)):
+            b, k = pil_resample_coeffs(i, o, "bilinear")
+            b2, k2, _ = pil_coeffs(i, o, "bilinear")
+            assert np.array_equal(b, b2) and np.array_equal(k, k2)
+
+
+@pytest.mark.parametrize("recipe", ["clip", "videomae", "dinov2", "data2vec-vision"])
+def test_device_preprocess_recipes_reproduce_the_host_processors(recipe):
+    """extract.resize.recipe_geometry (what the GPU path executes: resize geometry, filter, crop window, mean / std) applied with
+    the oracle's Pillow restatement == the branch's host pre-processing (PIL + processor arithmetic, pinned against HF)."""
+    from oracle.host_ref import pil_resize_u8
+    from mertools_amd.extract import visual
+    from mertools_amd.extract.resize import recipe_geometry
+    host = {"clip": lambda f: visual.clip_preprocess(f, 224), "videomae": lambda f: visual.videomae_preprocess(f, 224)[0],
+            "dinov2": lambda f: visual.dinov2_preprocess(f, 224, 256), "data2vec-vision": lambda f: visual.data2vec_vision_preprocess(f, 224)}[recipe]
+    rng = np.random.RandomState(3)
+    for h, w in [(256, 320), (300, 200), (224, 224), (231, 517)]:
+        f = rng.randint(0, 256, (2, h, w, 3), dtype=np.uint8)
+        g = recipe_geometry(recipe, h, w)
+        mean = np.array(g["mean"], dtype=np.float32)[:, None, None]
+        std = np.array(g["std"], dtype=np.float32)[:, None, None]
+        ref = host(f).numpy()
+        for n in range(2):
+            r = pil_resize_u8(f[n], g["new_w"], g["new_h"], g["filt"])[g["top"]:g["top"] + g["crop"], g["left"]:g["left"] + g["crop"]]
+            rgb = r[:, :, ::-1].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
+            assert np.array_equal((rgb - mean) / std, ref[n]), (recipe, h, w)
