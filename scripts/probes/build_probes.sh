@@ -4,3 +4,7 @@ set -e
 cd "$(dirname "$0")"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ceiling_probe.bin ceiling_probe.hip
 ls -la ceiling_probe.bin
+# C-ABI self-test of libmer_hip.so (needs the library built: python -m mertools_amd.build); finds it next to the binary's repo copy
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -x hip abi_selftest.cpp -I../../include -L../../mertools_amd -lmer_hip \
+  -Wl,-rpath,'$ORIGIN/../../mertools_amd' -o abi_selftest.bin
+ls -la abi_selftest.bin
