@@ -12,8 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmer_hip.so")
-SOURCES = ["common.cpp", "gemm16.hip", "gemm32.hip", "norm.hip", "attention.hip", "frontend.hip",
-           "fusion.hip", "encoders.cpp"]
+# the gemm16 kernel family is instantiated in four translation units (tile class x dtype) so that it compiles in parallel;
+# the long ones go first
+SOURCES = ["gemm16_t3_f16.hip", "gemm16_t3_bf16.hip", "gemm16_small_f16.hip", "gemm16_small_bf16.hip", "attention.hip",
+           "common.cpp", "gemm16.hip", "gemm32.hip", "norm.hip", "frontend.hip", "fusion.hip", "encoders.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-x", "hip"]
 
