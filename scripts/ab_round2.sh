@@ -8,9 +8,13 @@ set -u
 out=gpurun_out/ab_round2
 mkdir -p $out
 export TMPDIR=/tmp
+# 0. no-Python checks first (seconds): C-ABI self-test, then the real GEMM kernels on the bench shapes (row-major W / pre-blocked W /
+#    blocked activation planes) — scripts/probes/build_probes.sh must have been run before gpurun ships the tree
+timeout 60 scripts/probes/abi_selftest.bin > $out/abi_selftest.jsonl 2>&1; echo "abi_selftest rc=$?" | tee $out/summary.txt
+timeout 120 scripts/probes/gemm16_bench.bin 30 30 all > $out/gemm16_bench.jsonl 2>&1; echo "gemm16_bench rc=$?" | tee -a $out/summary.txt
 MER_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_ops_gpu.py tests/test_extract_gpu.py -m gpu -q --no-header -p no:cacheprovider \
   -k "blocked_activation or tf_ablk or trimodal or resize" > $out/gated_tests.log 2>&1
-echo "gated tests rc=$?" | tee $out/summary.txt
+echo "gated tests rc=$?" | tee -a $out/summary.txt
 tail -5 $out/gated_tests.log
 for opt in "" "tf_ablk=1"; do
   tag=${opt:-default}; tag=${tag//=/_}

@@ -8,3 +8,7 @@ ls -la ceiling_probe.bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -x hip abi_selftest.cpp -I../../include -L../../mertools_amd -lmer_hip \
   -Wl,-rpath,'$ORIGIN/../../mertools_amd' -o abi_selftest.bin
 ls -la abi_selftest.bin
+# real-kernel GEMM timing over the C ABI (no Python): the cheap A/B tool
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -x hip gemm16_bench.cpp -I../../include -L../../mertools_amd -lmer_hip \
+  -Wl,-rpath,'$ORIGIN/../../mertools_amd' -o gemm16_bench.bin
+ls -la gemm16_bench.bin

@@ -1,0 +1,137 @@
+// gemm16_bench.cpp — times the REAL mer_gemm16 kernels through the C ABI of libmer_hip.so, without Python or torch, so that one
+// GPU-box call costs ~15 s instead of ~45 s (no interpreter / torch import): the tool for A/B-ing kernel changes next round.
+//
+//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | all
+//
+// For every (shape, passes, epilogue) of the bench's dominant GEMMs it runs: row-major W, pre-blocked W (mer_w_block_pack), and —
+// for the K = ffn shapes — a blocked A plane produced by a c16_blocked producer.  One JSON line per configuration:
+// microseconds per launch (hipEvents around `reps` back-to-back launches after `warm` warm-up launches: sustained clocks) and
+// algorithmic TFLOP/s.  Options can be switched for a run with MER_SET="gemm_persist=1,gemm_wblk=0" (mer_set_option).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "mer_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(100); } } while (0)
+#define MER(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s:%d rc=%d %s\n", __FILE__, __LINE__, rc_, mer_last_error()); exit(101); } } while (0)
+
+extern "C" int mer_set_option(const char* name, int value);
+
+struct Shape { const char* name; int M, N, K; int passes; int act; bool residual, out32, out16; };
+
+static void* dev_alloc(size_t bytes, int fill) {
+  void* p;
+  CK(hipMalloc(&p, bytes));
+  CK(hipMemset(p, fill, bytes));
+  return p;
+}
+
+static float time_gemm(const mer_gemm16_args& g, int warm, int reps) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < warm; ++i) MER(mer_gemm16(&g, nullptr));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) MER(mer_gemm16(&g, nullptr));
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1e3f / reps;
+}
+
+static void run_shape(const Shape& s, int warm, int reps) {
+  const int Mp = (s.M + 255) / 256 * 256;
+  // operands: 0x3c bytes = f16 1.0-ish patterns are irrelevant for timing; zero planes would let the hardware clock higher
+  // (data-dependent power), so fill with a non-trivial byte pattern
+  void* a = dev_alloc((size_t)Mp * s.K * 2, 0x2e);
+  void* w = dev_alloc((size_t)s.N * s.K * 2, 0x2b);
+  void* wlo = s.passes >= 2 && s.passes != 4 ? dev_alloc((size_t)s.N * s.K * 2, 0x11) : nullptr;
+  void* wblk = dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0);
+  void* wlo_blk = wlo ? dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0) : nullptr;
+  MER(mer_w_block_pack(w, s.K, s.N, s.K, wblk, nullptr));
+  if (wlo) MER(mer_w_block_pack(wlo, s.K, s.N, s.K, wlo_blk, nullptr));
+  void* wmx = nullptr;
+  if (s.passes == 4) {
+    const long long nb = mer_mx_packed_bytes(s.N, s.K);
+    std::vector<float> res((size_t)s.N * s.K);
+    unsigned sd = 1;
+    for (auto& v : res) { sd = sd * 1664525u + 1013904223u; v = ((int)(sd >> 9) % 2001 - 1000) * 1e-7f; }
+    std::vector<unsigned char> packed((size_t)nb);
+    MER(mer_mx_pack(res.data(), s.K, s.N, s.K, packed.data()));
+    CK(hipMalloc(&wmx, (size_t)nb));
+    CK(hipMemcpy(wmx, packed.data(), (size_t)nb, hipMemcpyHostToDevice));
+  }
+  float* bias = (float*)dev_alloc((size_t)s.N * 4, 0);
+  float* resid = s.residual ? (float*)dev_alloc((size_t)s.M * s.N * 4, 0) : nullptr;
+  float* c32 = s.out32 ? (float*)dev_alloc((size_t)s.M * s.N * 4, 0) : nullptr;
+  void* c16 = s.out16 ? dev_alloc((size_t)Mp * s.N * 2, 0) : nullptr;
+  mer_gemm16_args g;
+  memset(&g, 0, sizeof(g));
+  g.M = s.M; g.N = s.N; g.K = s.K; g.dtype = MER_DT_F16;
+  g.a_hi = a; g.lda = s.K; g.w_hi = w; g.w_lo = wlo; g.w_mx = wmx; g.ldw = s.K;
+  g.bias = bias; g.act = s.act; g.residual = resid; g.ldr = s.N;
+  g.c32 = c32; g.ldc32 = s.N; g.c16_hi = c16; g.ldc16 = s.N;
+  g.nbatch = 1; g.nb_inner = 1; g.passes = s.passes;
+  const double flops = 2.0 * s.M * (double)s.N * s.K;
+  auto report = [&](const char* variant, float us) {
+    printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"passes\": %d, \"variant\": \"%s\", \"us\": %.1f, \"TFLOPs\": %.0f}\n",
+           s.name, s.M, s.N, s.K, s.passes, variant, us, flops / us * 1e-6);
+    fflush(stdout);
+  };
+  report("row-major W", time_gemm(g, warm, reps));
+  g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk;
+  report("pre-blocked W", time_gemm(g, warm, reps));
+  if (s.out16 && s.N % 32 == 0 && !s.out32) {   // producer side of a blocked activation plane (fc1)
+    g.c16_blocked = 1;
+    report("pre-blocked W, blocked 16-bit output", time_gemm(g, warm, reps));
+    g.c16_blocked = 0;
+  }
+  if (s.K >= 2048 && (s.passes == 1 || s.passes == 2)) {   // consumer side (fc2): the A plane's content is irrelevant for timing
+    g.a_blocked = 1;
+    report("pre-blocked W, blocked A", time_gemm(g, warm, reps));
+  }
+  for (void* p : {a, w, wlo, wblk, wlo_blk, wmx, (void*)bias, (void*)resid, (void*)c32, c16})
+    if (p) CK(hipFree(p));
+}
+
+int main(int argc, char** argv) {
+  const int warm = argc > 1 ? atoi(argv[1]) : 30, reps = argc > 2 ? atoi(argv[2]) : 30;
+  const char* set = argc > 3 ? argv[3] : "clip";
+  if (const char* opts = getenv("MER_SET")) {
+    char buf[512];
+    strncpy(buf, opts, sizeof(buf) - 1); buf[sizeof(buf) - 1] = 0;
+    for (char* tok = strtok(buf, ","); tok; tok = strtok(nullptr, ",")) {
+      char* eq = strchr(tok, '=');
+      const int v = eq ? atoi(eq + 1) : 1;
+      if (eq) *eq = 0;
+      MER(mer_set_option(tok, v));
+      printf("{\"option\": \"%s\", \"value\": %d}\n", tok, v);
+    }
+  }
+  printf("{\"library\": \"%s\", \"warm\": %d, \"reps\": %d}\n", mer_version(), warm, reps);
+  // CLIP-ViT-B/16, 64 clips x 8 frames x 197 tokens (bench.py's visual leg, default mx preset with the selective correction)
+  const int Mc = 100864;
+  const Shape clip[] = {
+      {"clip Q|K (one pass)", Mc, 1536, 768, 1, MER_ACT_NONE, false, false, true},
+      {"clip V (MX)", Mc, 768, 768, 4, MER_ACT_NONE, false, false, true},
+      {"clip out-proj (MX, residual, fp32 out)", Mc, 768, 768, 4, MER_ACT_NONE, true, true, false},
+      {"clip fc1 (one pass, quick_gelu)", Mc, 3072, 768, 1, MER_ACT_QUICK_GELU, false, false, true},
+      {"clip fc2 (one pass, residual, fp32 out)", Mc, 768, 3072, 1, MER_ACT_NONE, true, true, false},
+  };
+  // HuBERT-base, 64 clips x 249 frames: post-LN blocks keep the FFN corrected; conv1 of the feature extractor (M = 64 x 7999)
+  const int Mh = 15936;
+  const Shape hubert[] = {
+      {"hubert Q|K (one pass)", Mh, 1536, 768, 1, MER_ACT_NONE, false, false, true},
+      {"hubert V (MX)", Mh, 768, 768, 4, MER_ACT_NONE, false, false, true},
+      {"hubert fc1 (MX, gelu)", Mh, 3072, 768, 4, MER_ACT_GELU, false, false, true},
+      {"hubert fc2 (MX, residual, fp32 out)", Mh, 768, 3072, 4, MER_ACT_NONE, true, true, false},
+      {"hubert conv1-like (MX, gelu, M = 511936, K = 1536, dense rows)", 511936, 512, 1536, 4, MER_ACT_GELU, false, false, true},
+  };
+  const bool all = !strcmp(set, "all");
+  if (all || !strcmp(set, "clip")) for (const Shape& s : clip) run_shape(s, warm, reps);
+  if (all || !strcmp(set, "hubert")) for (const Shape& s : hubert) run_shape(s, warm, reps);
+  return 0;
+}
