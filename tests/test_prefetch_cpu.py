@@ -115,3 +115,49 @@ def test_audio_driver_identical_with_workers(tmp_path):
         outs.append([np.load(os.path.join(d, f"a{i}.npy")) for i in range(len(files))])
     for a, b in zip(*outs):
         assert a.dtype == b.dtype == np.float32 and np.array_equal(a, b)
+
+
+def _faces(tmp_path, specs, seed=0):
+    rng = np.random.RandomState(seed)
+    face = tmp_path / "faces"
+    vids = []
+    for i, (n, h, w) in enumerate(specs):
+        vid = f"v{i}"
+        os.makedirs(face / vid)
+        np.save(face / vid / f"{vid}.npy", rng.randint(0, 256, (n, h, w, 3), dtype=np.uint8))
+        vids.append(vid)
+    return str(face), vids
+
+
+def test_other_visual_branches_run_with_stand_in_encoders(tmp_path):
+    """VideoMAE / DINOv2 / data2vec-vision drivers (host pre-processing path) end to end on CPU with stand-in encoders: batching,
+    frame resampling and the .npy layout of the reference (FRAME: [n, D]; UTTERANCE: [D])."""
+    face, vids = _faces(tmp_path, [(20, 40, 48), (5, 36, 36), (17, 50, 32)])
+
+    class _VMAE:
+        device = torch.device("cpu")
+
+        class config:
+            num_frames, tubelet_size, image_size = 16, 2, 32
+
+        def extract_segments(self, px):                      # [B, 16, 3, S, S] -> [B * 8, 4]
+            assert px.dim() == 5 and px.shape[1:] == (16, 3, 32, 32)
+            return px.view(px.shape[0] * 8, 2, -1)[:, :, :4].mean(1)
+
+    visual.extract_videomae(_VMAE(), face, str(tmp_path / "vmae"), "FRAME", vids=vids, videos_per_batch=2)
+    assert all(np.load(tmp_path / "vmae" / f"{v}.npy").shape == (8, 4) for v in vids)
+
+    class _Tok:
+        device = torch.device("cpu")
+
+        class _cfg:
+            image_size = 32
+
+        def extract_frames(self, px):                         # [N, 3, S, S] -> [N, 5]
+            assert px.shape[1:] == (3, 32, 32)
+            return px.reshape(px.shape[0], -1)[:, :5]
+
+    visual.extract_dinov2(_Tok(), face, str(tmp_path / "dino"), "FRAME", vids=vids, frames_per_batch=70, nframe=8)
+    assert all(np.load(tmp_path / "dino" / f"{v}.npy").shape == (8, 5) for v in vids)
+    visual.extract_data2vec_vision(_Tok(), face, str(tmp_path / "d2v"), "UTTERANCE", vids=vids, frames_per_batch=16)
+    assert all(np.load(tmp_path / "d2v" / f"{v}.npy").shape == (5,) for v in vids)
