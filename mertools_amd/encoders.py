@@ -176,11 +176,23 @@ class _HipModule:
         off = (-ws.data_ptr()) % 256
         return ws.data_ptr() + off, ws.numel() - off
 
+    def _ints(self, values):
+        """Device int32 copy of a small host list (segment tables, sequence lengths), cached by content: a pageable H2D copy
+        blocks the host until the current stream has drained, which would stop the host from queueing the next batch while
+        this one runs — and the drivers / bench pass the same tables batch after batch."""
+        key = tuple(int(v) for v in values)
+        cache = self.__dict__.setdefault("_int_cache", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) >= 256:
+                cache.clear()
+            t = cache[key] = torch.tensor(key, dtype=torch.int32).to(self.device)
+        return t
+
     def _seg(self, seg_start, seg_len):
         if seg_start is None:
             return None, None, 0
-        ss = torch.as_tensor(seg_start, dtype=torch.int32).to(self.device)
-        sl = torch.as_tensor(seg_len, dtype=torch.int32).to(self.device)
+        ss, sl = self._ints(seg_start), self._ints(seg_len)
         return ss, sl, ss.numel()
 
     def to(self, *a, **k):
@@ -839,7 +851,7 @@ class HipBertModel(_HipModule):
         B, T = ids.shape
         D, nl = self.config.hidden_size, self.config.num_hidden_layers
         tt = token_type_ids.to(self.device, torch.int64).contiguous() if token_type_ids is not None else None
-        ln = torch.as_tensor(lengths, dtype=torch.int32).to(self.device) if lengths is not None else None
+        ln = self._ints(lengths) if lengths is not None else None
         hs = torch.empty((nl + 1, B, T, D), dtype=torch.float32, device=self.device) if hidden_states else None
         fr = torch.empty((B * T, D), dtype=torch.float32, device=self.device) if frames else None
         ss, sl, nseg = self._seg(seg_start, seg_len)
