@@ -305,3 +305,26 @@ def test_device_preprocess_recipes_reproduce_the_host_processors(recipe):
             r = pil_resize_u8(f[n], g["new_w"], g["new_h"], g["filt"])[g["top"]:g["top"] + g["crop"], g["left"]:g["left"] + g["crop"]]
             rgb = r[:, :, ::-1].astype(np.float32).transpose(2, 0, 1) * np.float32(1 / 255.0)
             assert np.array_equal((rgb - mean) / std, ref[n]), (recipe, h, w)
+
+
+def test_pil_restatement_random_sweep():
+    """Edge cases by brute force: sizes from 1 pixel up, extreme up- and down-scaling, both filters — the oracle against Pillow and the
+    product's tables against the oracle's."""
+    from PIL import Image
+    from oracle.host_ref import pil_resample_coeffs, pil_resize_u8
+    from mertools_amd.extract.resize import pil_coeffs
+    rnd = random.Random(0)
+    rng = np.random.RandomState(0)
+    for _ in range(150):
+        i = rnd.choice([1, 2, 3, 5, 7, 16, 31, 64, 97, 224, 225, 300, 1000])
+        o = rnd.choice([1, 2, 3, 4, 9, 32, 64, 100, 224, 256, 299, 640])
+        for f in ("bicubic", "bilinear"):
+            b, k = pil_resample_coeffs(i, o, f)
+            b2, k2, _ = pil_coeffs(i, o, f)
+            assert np.array_equal(b, b2) and np.array_equal(k, k2), (i, o, f)
+    for _ in range(60):
+        h, w, nh, nw = rnd.randint(1, 70), rnd.randint(1, 70), rnd.randint(1, 90), rnd.randint(1, 90)
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        for f, res in (("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)):
+            ref = np.asarray(Image.fromarray(img).resize((nw, nh), resample=res))
+            assert np.array_equal(pil_resize_u8(img, nw, nh, f), ref), (h, w, nh, nw, f)
