@@ -14,6 +14,7 @@ run() { # name timeout cmd...
   tail -n 25 "gpurun_out/$name.log"
 }
 if [[ $what == tests || $what == all ]]; then
+  [[ -x scripts/probes/abi_selftest.bin ]] && run abi_selftest 60 scripts/probes/abi_selftest.bin   # C ABI without Python (seconds)
   run ops 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x --no-header -p no:cacheprovider
   run enc 900 python -m pytest tests/test_encoders_gpu.py -m gpu -q --no-header -p no:cacheprovider -s
   run fusion 900 python -m pytest tests/test_fusion_gpu.py tests/test_extract_gpu.py tests/test_dinov2.py tests/test_affectgpt.py tests/test_whisper.py -m gpu -q --no-header -p no:cacheprovider
