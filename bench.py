@@ -15,6 +15,12 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 divided by their HIP-event durations (measured in a second, instrumented pass over
                 the same steps), against the 2.5 PFLOP/s dense fp16 MFMA peak.
   cpu_baseline  the CPU oracle (oracle/, kind "port") timed on the host cores on a bounded sample.
+  parity        max|x-ref|/max|ref| of the first two clips' features of the LAST timed step (the full-batch kernel selection)
+                against the CPU oracle, per modality; the run fails when one exceeds 1e-3.
+N > 1 without torchrun: bench.py re-executes itself under torch.distributed.run (one rank per GPU) and fails loudly when
+the box has fewer than N GPUs.  Under N > 1 every step also issues the fusion minibatch exchange of BASELINE configs[3]
+(distributed.gather_fusion_batch: ONE fused RCCL all-gather of the [B, Da+Dt+Dv] feature rows) on a side stream; its
+duration is reported separately ("allgather") and it overlaps the next step's extraction.
 """
 import argparse
 import ctypes
@@ -51,6 +57,7 @@ def parse():
                                                            "(kernels of one sub-batch fill the partial last wave of workgroups of the other)")
     ap.add_argument("--split-mods", default="avt", help="modalities --split applies to (the others run their whole batch on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last step's first two clips")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -87,8 +94,54 @@ def cpu_baseline(sample_clips=2):
                       f"oracle fp32 torch-CPU forward, {cores} threads"}
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: one rank per GPU via torch.distributed.run, same flags."""
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but this box has {n} visible GPU(s); refusing to run fewer ranks than asked "
+                 f"(a scaling line must measure what it is labelled with)")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def parity_check(feats, inputs, mods, nclip=2):
+    """Features of the first `nclip` clips of the last timed step (computed inside the full batch, i.e. by the kernels the
+    timing selected) against the CPU oracle on the same weights and inputs.  north_star tolerance: 1e-3 (max-norm relative)."""
+    from oracle import encoders_ref as R
+    from mertools_amd import synthetic as W
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    out = {}
+
+    def rel(a, b):
+        return float((a.double().cpu() - b.double()).abs().max() / b.double().abs().max())
+
+    with torch.no_grad():
+        if "a" in mods:
+            hc = W.hubert_config("base")
+            ref = torch.stack(R.hubert_hidden_states(W.hubert_state_dict(hc, 0), vars(hc), inputs["a"][:nclip].cpu()))[[-4, -3, -2, -1]].sum(0).mean(1)
+            out["a"] = rel(feats["a"][:nclip], ref)
+        if "v" in mods:
+            cc = W.clip_config("base16")
+            ref = R.clip_image_features(W.clip_state_dict(cc, 0), dict(vars(cc.vision_config), projection_dim=cc.projection_dim),
+                                        inputs["v"][:nclip * 8].cpu()).view(nclip, 8, -1).mean(1)
+            out["v"] = rel(feats["v"][:nclip], ref)
+        if "t" in mods:
+            bc = W.bert_config("roberta-base")
+            ids = inputs["t"][:nclip].cpu()
+            ref = torch.stack(R.bert_hidden_states(W.bert_state_dict(bc, 0), dict(vars(bc), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
+            out["t"] = rel(feats["t"][:nclip], ref)
+    return {k: float(f"{v:.3e}") for k, v in out.items()}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,7 +153,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     from mertools_amd import _lib, synthetic as W
     from mertools_amd.encoders import HipBertModel, HipCLIPModel, HipHubertModel
@@ -147,20 +202,39 @@ def main():
         return models["t"].extract_utterance(xt, lengths[:n], 1, -1)
 
     def step():
-        out = []
+        """-> {modality: [features of each sub-batch]}"""
         if streams is None:
-            return [run(m) for m in "avt" if m in mods]
+            return {m: [run(m)] for m in "avt" if m in mods}
+        out = {m: [] for m in mods}
         cur = torch.cuda.current_stream()
         for i in range(S):
             for m in "vat":   # longest first
                 if m in mods and i < Sm[m]:
                     streams[m][i].wait_stream(cur)
                     with torch.cuda.stream(streams[m][i]):
-                        out.append(run(m, i))
+                        out[m].append(run(m, i))
         for m in mods:
             for st in streams[m]:
                 cur.wait_stream(st)
         return out
+
+    # N > 1: the fusion-minibatch exchange of configs[3] — every rank's [B, Da | Dt | Dv] rows in ONE fused RCCL all-gather
+    # (distributed.gather_fusion_batch) on its own stream, so it overlaps the next step's extraction; timed with its own events
+    comm = torch.cuda.Stream(device=dev) if (dist is not None and mods == set("avt")) else None
+    ag_events, keep = [], []
+
+    def exchange(out):
+        from mertools_amd import distributed as D
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(comm)
+            a, t, v = (out[m][0] if len(out[m]) == 1 else torch.cat(out[m], 0) for m in "atv")
+            full = D.gather_fusion_batch(a, t, v)
+            e1.record(comm)
+        ag_events.append((e0, e1))
+        keep.append((out, full))   # allocated on other streams: keep alive until the closing barrier
+        return full
 
     def barrier():
         if dist is not None:
@@ -168,19 +242,37 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        out = step()
+        if comm is not None:
+            exchange(out)
     barrier()
+    ag_events.clear()
+    keep.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        if comm is not None:
+            full = exchange(out)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    for o in out:
+    feats = {m: torch.cat(out[m], 0) for m in out}
+    for o in feats.values():
         assert torch.isfinite(o).all(), "non-finite features"
+    allgather = None
+    if comm is not None:
+        assert full[0].shape == (B * world, feats["a"].shape[1]) and torch.equal(full[0][rank * B:(rank + 1) * B], feats["a"]), \
+            "fusion minibatch exchange: this rank's rows did not come back in rank order"
+        ms = sorted(e0.elapsed_time(e1) for e0, e1 in ag_events)
+        allgather = {"collective": "all_gather_into_tensor (RCCL), one per step, side stream", "ranks": world,
+                     "rows_per_rank": B, "bytes_per_rank": int(B * sum(feats[m].shape[1] for m in "atv") * 4),
+                     "ms_median": round(ms[len(ms) // 2], 4), "ms_max": round(ms[-1], 4)}
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = parity_check(feats, inputs, mods)
 
     clips = B * world * args.steps
     gflop_clip = (GFLOP_PER_CLIP["hubert-base"] if "a" in mods else 0) + (GFLOP_PER_CLIP["clip-vit-b16-8f"] if "v" in mods else 0) + \
@@ -236,16 +328,21 @@ def main():
             "config": {"workload": "tri-modal base extract: HuBERT-base 5s@16kHz + CLIP-ViT-B/16 8x224^2 + RoBERTa-base 64 tok "
                                    "(BASELINE.json configs[3] extraction leg = configs[1]+[2]+text on each GPU)",
                        "clips_per_gpu_per_step": B, "modalities": "".join(sorted(mods)), "precision": args.precision,
-                       "weights": "random-init (seed 0), HF architectures", "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": {m: Sm[m] for m in sorted(mods)}, "parallelism": f"clip-sharded x{world}, no collective",
+                       "weights": "random-init (seed 0), HF architectures", "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": {m: Sm[m] for m in sorted(mods)}, "parallelism": f"clip-sharded x{world}, no data-path collective" + ("; one fused fusion-minibatch all-gather per step (side stream)" if comm is not None else ""),
                        "gflop_per_clip": gflop_clip},
             "roofline": roofline,
+            "parity": parity,
         }
+        if allgather is not None:
+            res["allgather"] = allgather
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
+        if parity is not None and max(parity.values()) > 1e-3:
+            sys.exit(f"bench.py: parity vs the CPU oracle exceeds 1e-3: {parity}")
     if dist is not None:
         dist.destroy_process_group()
 

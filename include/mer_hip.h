@@ -163,6 +163,17 @@ int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* w /*[C,k]*/
                         const float* gamma, const float* beta, float eps, double* stats,
                         void* out_hi, void* out_lo, int dtype, mer_stream_t stream);
 
+/* Ragged batches (rows zero-padded to a common L): valid_frames[b] (device int32, NULL = all T0) = the conv0 output frames
+ * of row b that come from its own samples; the GroupNorm statistics run over those only, which is what the reference's
+ * batch-of-one forward (extract_audio_huggingface.py:93-100, no padding, no mask) computes for that clip. */
+int mer_hubert_conv0_gn_ragged(const float* wav, int B, int L, const float* w /*[C,k]*/, int C, int k, int stride,
+                               const float* gamma, const float* beta, float eps, double* stats,
+                               void* out_hi, void* out_lo, int dtype, const int* valid_frames, mer_stream_t stream);
+/* valid_samples[b] (device int32) -> frames after conv 0 (t0_len) and after the whole valid-conv stack (tn_len), device
+ * int32 [B] each; kernels / strides: HOST int [n_conv]. */
+int mer_hubert_valid_frames(const int* valid_samples, int B, int L, int n_conv, const int* kernels, const int* strides,
+                            int* t0_len, int* tn_len, mer_stream_t stream);
+
 /* Layer-0 conv for feat_extract_norm == "layer" (HuBERT-large / wav2vec2-large, HF:hubert/modeling_hubert.py:127-151):
  * out[b,t,c] = bias[c] + conv, fp32 channels-last [B,T0,C]; the per-frame LayerNorm + GELU is mer_layernorm(act=GELU). */
 int mer_hubert_conv0_plain(const float* wav, int B, int L, const float* w, const float* bias, int C, int k, int stride,
@@ -173,6 +184,10 @@ int mer_hubert_conv0_plain(const float* wav, int B, int L, const float* w, const
  * implicit-im2col GEMM (HF:hubert/modeling_hubert.py:45-92). */
 int mer_posconv_pack(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo,
                      int dtype, mer_stream_t stream);
+/* Ragged batches: frames t >= valid_frames[b] are packed as zeros, so the conv's padding region of a short row is exactly
+ * the zero padding of its batch-of-one forward. */
+int mer_posconv_pack_ragged(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo,
+                            int dtype, const int* valid_frames, mer_stream_t stream);
 
 /* ViT patchify: pixel_values fp32 [N,3,H,W] -> 16-bit planes [N*(H/P)*(W/P), ceil8(3*P*P)] with the
  * (c, i, j) ordering of a flattened Conv2d weight (HF:clip/modeling_clip.py:138-217); rows are zero-padded to a
@@ -340,6 +355,16 @@ int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, int B, int L,
                             float* hidden_states, float* frames,
                             const int* seg_start, const int* seg_len, int nseg, float* pooled,
                             const float* pos_bias, long long ldb, mer_stream_t stream);
+/* Ragged batch: rows are clips of different lengths, zero-padded to L; valid_samples (device int32 [B], NULL = all L) holds
+ * each row's own sample count.  Every frame whose receptive field lies inside the clip then equals the batch-of-one result
+ * (GroupNorm statistics over valid frames, zeros past the clip for the positional conv, keys past the clip masked);
+ * frames past a row's length are unspecified — select the valid ones with seg_start / seg_len.  The reference handles any
+ * length only because it runs batch 1 (extract_audio_huggingface.py:93-100). */
+int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, int B, int L, const int* valid_samples,
+                              void* workspace, long long workspace_bytes,
+                              float* hidden_states, float* frames,
+                              const int* seg_start, const int* seg_len, int nseg, float* pooled,
+                              const float* pos_bias, long long ldb, mer_stream_t stream);
 
 /* ---- CLIP vision tower ----------------------------------------------------------------------
  * Replaces `model.get_image_features(pixel_values)` at

@@ -169,6 +169,12 @@ _PROTOS = {
                                    c_void_p, c_int, c_void_p, c_void_p]),
     "mer_hubert_forward_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
+    "mer_hubert_forward_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
+    "mer_hubert_conv0_gn_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "mer_hubert_valid_frames": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int), c_void_p, c_void_p, c_void_p]),
+    "mer_posconv_pack_ragged": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mer_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(c_void_p)]),
     "mer_vit_destroy": (None, [c_void_p]),
     "mer_vit_workspace_bytes": (c_ll, [c_void_p, c_int]),

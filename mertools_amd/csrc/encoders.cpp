@@ -248,6 +248,7 @@ struct HubertPlan {
   P16 pospack;
   float* posbuf;       // data2vec-audio: output of a positional conv layer (input of the next)
   float* ring;
+  int* vlen;           // ragged batches: t0_len[B] | tn_len[B] (device int32)
   TfBufs tf;
   int T[MER_MAX_CONV];
 };
@@ -260,6 +261,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   const long long M = (long long)B * Tn;
   const bool clo = c.conv_passes == 3;
   p.stats = (double*)ar.take((long long)B * C * 2 * 8);
+  p.vlen = (int*)ar.take(2 * (long long)B * 4);
   p.convA = take16(ar, (long long)B * p.T[0] * C, clo);
   p.convB = take16(ar, (long long)B * p.T[1] * C, clo);
   p.conv32 = c.feat_norm_group ? nullptr : (float*)ar.take((long long)B * p.T[0] * C * 4);
@@ -291,6 +293,14 @@ extern "C" int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, in
                                   long long workspace_bytes, float* hidden_states, float* frames, const int* seg_start,
                                   const int* seg_len, int nseg, float* pooled, const float* pos_bias, long long ldb,
                                   mer_stream_t stream) {
+  return mer_hubert_forward_ragged(h, wav, B, L, nullptr, workspace, workspace_bytes, hidden_states, frames, seg_start, seg_len, nseg,
+                                   pooled, pos_bias, ldb, stream);
+}
+
+extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, int B, int L, const int* valid_samples, void* workspace,
+                                  long long workspace_bytes, float* hidden_states, float* frames, const int* seg_start,
+                                  const int* seg_len, int nseg, float* pooled, const float* pos_bias, long long ldb,
+                                  mer_stream_t stream) {
   MER_REQUIRE(h && wav && workspace, MER_EINVAL, "mer_hubert_forward: null argument");
   MER_REQUIRE(!h->cfg.tf.gated_rel_pos || pos_bias, MER_EINVAL,
               "mer_hubert_forward: this is a WavLM handle — call mer_hubert_forward_bias with the relative position bias table");
@@ -309,11 +319,22 @@ extern "C" int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, in
   const int M = B * Tn;
   const P16 none = {nullptr, nullptr};
 
+  // ragged batch: per-row valid frame counts after conv 0 (GroupNorm statistics) and after the stack (positional conv zeros,
+  // attention key mask), derived on the device from the rows' sample counts
+  const int* t0_len = nullptr;
+  const int* tn_len = nullptr;
+  if (valid_samples) {
+    int* t0 = p.vlen;
+    int* tn = t0 + B;
+    MER_TRY(mer_hubert_valid_frames(valid_samples, B, L, c.n_conv, c.conv_kernel, c.conv_stride, t0, tn, stream));
+    t0_len = t0;
+    tn_len = tn;
+  }
   P16 src = p.convA, dst = p.convB;
   if (c.feat_norm_group) {
     // conv0 + GroupNorm + GELU -> channels-last planes
-    MER_TRY(mer_hubert_conv0_gn(wav, B, L, w.conv0_w, C, c.conv_kernel[0], c.conv_stride[0], w.conv_norm_g[0], w.conv_norm_b[0],
-                                1e-5f, p.stats, p.convA.hi, p.convA.lo, dt, st));
+    MER_TRY(mer_hubert_conv0_gn_ragged(wav, B, L, w.conv0_w, C, c.conv_kernel[0], c.conv_stride[0], w.conv_norm_g[0], w.conv_norm_b[0],
+                                       1e-5f, p.stats, p.convA.hi, p.convA.lo, dt, t0_len, st));
   } else {
     // "layer" front end: every conv is followed by LayerNorm(C) over channels, then GELU (HF:hubert/modeling_hubert.py:127-151)
     MER_TRY(mer_hubert_conv0_plain(wav, B, L, w.conv0_w, c.conv_bias ? w.conv_b[0] : nullptr, C, c.conv_kernel[0], c.conv_stride[0],
@@ -364,7 +385,7 @@ extern "C" int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, in
     const float* src = p.hproj;
     for (int i = 0; i < nl; ++i) {
       const bool d2v = c.pos_layers > 0;
-      MER_TRY(mer_posconv_pack(src, B, Tn, D, G, K, p.pospack.hi, p.pospack.lo, dt, st));
+      MER_TRY(mer_posconv_pack_ragged(src, B, Tn, D, G, K, p.pospack.hi, p.pospack.lo, dt, tn_len, st));
       mer_gemm16_args g;
       memset(&g, 0, sizeof(g));
       g.M = Tn; g.N = Dg; g.K = K * Dg; g.dtype = dt;
@@ -396,7 +417,7 @@ extern "C" int mer_hubert_forward_bias(const mer_hubert* h, const float* wav, in
   if (!c.stable_layer_norm)
     MER_TRY(mer_layernorm(p.tf.t32, D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(0), D, p.tf.cur16.hi, p.tf.cur16.lo, D, dt, st));
 
-  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, Tn, hs, p.tf, nullptr, c.tf.gated_rel_pos ? pos_bias : nullptr, ldb));
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), B, Tn, hs, p.tf, tn_len, c.tf.gated_rel_pos ? pos_bias : nullptr, ldb));
 
   if (c.stable_layer_norm)  // final LayerNorm only on the last state (HF:hubert/modeling_hubert.py:612)
     MER_TRY(mer_layernorm(hs.at(c.tf.layers), D, w.enc_ln_g, w.enc_ln_b, c.tf.ln_eps, M, D, MER_ACT_NONE, hs.at(c.tf.layers), D, nullptr, nullptr, 0, dt, st));

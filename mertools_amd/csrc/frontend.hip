@@ -23,11 +23,14 @@ constexpr int C0_KMAX = 16;
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int T0, const float* w, int C, int k,
                                                     int stride, const float* gamma, const float* beta, float eps,
-                                                    double* stats, T* ohi, T* olo) {
+                                                    double* stats, T* ohi, T* olo, const int* valid) {
   __shared__ float xs[C0_TCH * 8 + C0_KMAX];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * C0_TCH;
   const int nt = (T0 - t0) < C0_TCH ? (T0 - t0) : C0_TCH;
+  // ragged batch: GroupNorm statistics over the row's own frames only (what the reference's batch-of-one forward sees)
+  const int Tv = valid ? valid[b] : T0;
+  const int nts = (Tv - t0) < nt ? ((Tv - t0) > 0 ? (Tv - t0) : 0) : nt;
   const int nin = (nt - 1) * stride + k;
   const float* xb = wav + (long long)b * L + (long long)t0 * stride;
   for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[i];
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int
     for (int j = 0; j < C0_KMAX; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
     if (!APPLY) {
       float s = 0.f, q = 0.f;
-      for (int t = 0; t < nt; ++t) {
+      for (int t = 0; t < nts; ++t) {
         float y = 0.f;
 #pragma unroll
         for (int j = 0; j < C0_KMAX; ++j)
@@ -49,8 +52,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int
       atomicAdd(&stats[((long long)b * C + c) * 2 + 0], (double)s);
       atomicAdd(&stats[((long long)b * C + c) * 2 + 1], (double)q);
     } else {
-      const double mean_d = stats[((long long)b * C + c) * 2 + 0] / (double)T0;
-      const double var_d = stats[((long long)b * C + c) * 2 + 1] / (double)T0 - mean_d * mean_d;
+      const double mean_d = stats[((long long)b * C + c) * 2 + 0] / (double)Tv;
+      const double var_d = stats[((long long)b * C + c) * 2 + 1] / (double)Tv - mean_d * mean_d;
       const float rstd = 1.0f / sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + eps);
       const float ga = gamma[c] * rstd;
       const float be = beta[c] - (float)mean_d * ga;
@@ -78,12 +81,14 @@ constexpr int C0_KF = 10;
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void conv0_fast_kernel(const float* wav, int L, int T0, const float* w, int C, int k,
                                                          int stride, const float* gamma, const float* beta, float eps,
-                                                         double* stats, T* ohi, T* olo) {
+                                                         double* stats, T* ohi, T* olo, const int* valid) {
   __shared__ float xs[C0_TCH * 8 + C0_KMAX];
   __shared__ float part[2][4][64 * 8];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * C0_TCH;
   const int nt = (T0 - t0) < C0_TCH ? (T0 - t0) : C0_TCH;
+  const int Tv = valid ? valid[b] : T0;   // ragged batch: statistics over the row's own frames only
+  const int nts = (Tv - t0) < nt ? ((Tv - t0) > 0 ? (Tv - t0) : 0) : nt;
   const int nin = (nt - 1) * stride + k;
   const float* xb = wav + (long long)b * L + (long long)t0 * stride;
   for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[i];
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void conv0_fast_kernel(const float* wav, int L
       float s[8], q[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) s[c] = q[c] = 0.f;
-      for (int t = tq; t < nt; t += 4) {
+      for (int t = tq; t < nts; t += 4) {
         float xv[C0_KF];
 #pragma unroll
         for (int j = 0; j < C0_KF; ++j) xv[j] = xs[t * stride + j];
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256) void conv0_fast_kernel(const float* wav, int L
       float ga[8], be[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const double mean_d = stats[((long long)b * C + c0 + c) * 2 + 0] / (double)T0;
-        const double var_d = stats[((long long)b * C + c0 + c) * 2 + 1] / (double)T0 - mean_d * mean_d;
+        const double mean_d = stats[((long long)b * C + c0 + c) * 2 + 0] / (double)Tv;
+        const double var_d = stats[((long long)b * C + c0 + c) * 2 + 1] / (double)Tv - mean_d * mean_d;
         const float rstd = 1.0f / sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + eps);
         ga[c] = gamma[c0 + c] * rstd;
         be[c] = beta[c0 + c] - (float)mean_d * ga[c];
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void conv0_plain_kernel(const float* wav, int 
 
 // x [B,T,D] fp32 -> out [B,G,T+K,Dg]; 4 channels per thread.
 template <typename T>
-__global__ void posconv_pack_kernel(const float* x, int B, int Tn, int D, int G, int K, T* ohi, T* olo) {
+__global__ void posconv_pack_kernel(const float* x, int B, int Tn, int D, int G, int K, T* ohi, T* olo, const int* valid) {
   const int Dg = D / G, TPad = Tn + K, half = K / 2;
   const long long total4 = (long long)B * G * TPad * Dg / 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
@@ -206,7 +211,8 @@ __global__ void posconv_pack_kernel(const float* x, int B, int Tn, int D, int G,
     const int g = (int)(bg % G), b = (int)(bg / G);
     const int t = tp - half;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t >= 0 && t < Tn) v = *reinterpret_cast<const f32x4*>(x + ((long long)b * Tn + t) * D + g * Dg + c);
+    // ragged batch: frames past the row's own length read as zeros — exactly the conv's zero padding in a batch-of-one forward
+    if (t >= 0 && t < (valid ? valid[b] : Tn)) v = *reinterpret_cast<const f32x4*>(x + ((long long)b * Tn + t) * D + g * Dg + c);
     typename T16<T>::v4 h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -528,6 +534,21 @@ __global__ void swiglu_kernel(const float* y, long long ldy, int M, int F, T* oh
   }
 }
 
+// frames left of `valid_samples[b]` input samples after the first conv / after the whole stack (valid convs: floor((n - k) / s) + 1)
+struct ConvGeom { int k[MER_MAX_CONV], s[MER_MAX_CONV]; };   // passed by value: no device copy of the table
+__global__ void hubert_valid_frames_kernel(const int* valid_samples, int B, int L, int n_conv, ConvGeom cg, int* t0_len, int* tn_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = valid_samples[b];
+  n = n < L ? n : L;
+  for (int i = 0; i < n_conv; ++i) {
+    const int k = cg.k[i], s = cg.s[i];
+    n = n >= k ? (n - k) / s + 1 : 0;
+    if (i == 0) t0_len[b] = n > 0 ? n : 1;   // (a clip shorter than the receptive field is rejected by the caller; stay finite)
+  }
+  tn_len[b] = n;
+}
+
 static inline unsigned grid_for(long long n, int block) {
   long long g = cdiv(n, block);
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -538,6 +559,24 @@ static inline unsigned grid_for(long long n, int block) {
 extern "C" int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* w, int C, int k, int stride,
                                    const float* gamma, const float* beta, float eps, double* stats, void* out_hi,
                                    void* out_lo, int dtype, mer_stream_t stream) {
+  return mer_hubert_conv0_gn_ragged(wav, B, L, w, C, k, stride, gamma, beta, eps, stats, out_hi, out_lo, dtype, nullptr, stream);
+}
+
+extern "C" int mer_hubert_valid_frames(const int* valid_samples, int B, int L, int n_conv, const int* kernels, const int* strides,
+                                       int* t0_len, int* tn_len, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(valid_samples && kernels && strides && t0_len && tn_len && B > 0 && n_conv >= 1 && n_conv <= MER_MAX_CONV, MER_EINVAL,
+              "mer_hubert_valid_frames: bad argument");
+  ConvGeom cg;
+  for (int i = 0; i < MER_MAX_CONV; ++i) { cg.k[i] = i < n_conv ? kernels[i] : 1; cg.s[i] = i < n_conv ? strides[i] : 1; }
+  hipLaunchKernelGGL(hubert_valid_frames_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, valid_samples, B, L, n_conv,
+                     cg, t0_len, tn_len);
+  return check_launch("hubert_valid_frames");
+}
+
+extern "C" int mer_hubert_conv0_gn_ragged(const float* wav, int B, int L, const float* w, int C, int k, int stride,
+                                          const float* gamma, const float* beta, float eps, double* stats, void* out_hi,
+                                          void* out_lo, int dtype, const int* valid_frames, mer_stream_t stream) {
   using namespace mer;
   MER_REQUIRE(wav && w && gamma && beta && stats && out_hi, MER_EINVAL, "mer_hubert_conv0_gn: null pointer");
   MER_REQUIRE(k >= 1 && k <= C0_KMAX && stride >= 1 && stride <= 8, MER_EUNSUPPORTED,
@@ -550,7 +589,7 @@ extern "C" int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* 
   dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
   ProfScope prof("hubert_conv0_gn", 2.0 * 2 * (double)B * T0 * C * k, (double)B * L * 4 * 2 + (double)B * T0 * C * (out_lo ? 4 : 2), st);
   const bool fast = k <= C0_KF && C % 8 == 0;
-#define MER_CONV0(K, TT, AP, OH, OL) hipLaunchKernelGGL((K<TT, AP>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats, OH, OL)
+#define MER_CONV0(K, TT, AP, OH, OL) hipLaunchKernelGGL((K<TT, AP>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats, OH, OL, valid_frames)
   if (dtype == MER_DT_F16) {
     if (fast) { MER_CONV0(conv0_fast_kernel, f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(conv0_fast_kernel, f16, true, (f16*)out_hi, (f16*)out_lo); }
     else { MER_CONV0(conv0_kernel, f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(conv0_kernel, f16, true, (f16*)out_hi, (f16*)out_lo); }
@@ -575,15 +614,20 @@ extern "C" int mer_hubert_conv0_plain(const float* wav, int B, int L, const floa
 
 extern "C" int mer_posconv_pack(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo, int dtype,
                                 mer_stream_t stream) {
+  return mer_posconv_pack_ragged(x, B, T, D, G, K, out_hi, out_lo, dtype, nullptr, stream);
+}
+
+extern "C" int mer_posconv_pack_ragged(const float* x, int B, int T, int D, int G, int K, void* out_hi, void* out_lo, int dtype,
+                                       const int* valid_frames, mer_stream_t stream) {
   using namespace mer;
   MER_REQUIRE(x && out_hi && B > 0 && T > 0, MER_EINVAL, "mer_posconv_pack: bad args");
   MER_REQUIRE(D % G == 0 && (D / G) % 8 == 0, MER_ESHAPE, "mer_posconv_pack: D/G must be a multiple of 8");
   const long long n4 = (long long)B * G * (T + K) * (D / G) / 4;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MER_DT_F16)
-    hipLaunchKernelGGL((posconv_pack_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, x, B, T, D, G, K, (f16*)out_hi, (f16*)out_lo);
+    hipLaunchKernelGGL((posconv_pack_kernel<f16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, x, B, T, D, G, K, (f16*)out_hi, (f16*)out_lo, valid_frames);
   else
-    hipLaunchKernelGGL((posconv_pack_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, x, B, T, D, G, K, (bf16*)out_hi, (bf16*)out_lo);
+    hipLaunchKernelGGL((posconv_pack_kernel<bf16>), dim3(grid_for(n4, 256)), dim3(256), 0, st, x, B, T, D, G, K, (bf16*)out_hi, (bf16*)out_lo, valid_frames);
   return check_launch("posconv_pack");
 }
 

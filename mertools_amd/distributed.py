@@ -42,44 +42,59 @@ def shard(items, rank=None, world=None):
     return sorted(items)[rank::world]
 
 
+def my_share(items, rank=None, world=None):
+    """The extraction drivers' work list for this process: the list itself (original order) when there is one process,
+    else shard().  rank / world default to the torch.distributed values (0 / 1 when not initialised)."""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    return list(items) if world <= 1 else shard(items, rank, world)
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()
 
 
-def all_gather_rows(local, max_rows=None):
-    """Concatenate per-rank row blocks [n_r, D] in rank order.  Ranks may hold different n_r (last, ragged
-    minibatch): rows are padded to max_rows for the collective and trimmed afterwards."""
+def all_gather_rows(local, max_rows=None, counts=None):
+    """Concatenate per-rank row blocks [n_r, D] in rank order; ranks may hold different n_r (a ragged last minibatch).
+    Rows are padded to a common height for the collective and the padding is ALWAYS trimmed before returning:
+      counts   per-rank row counts when the caller already knows them (no extra collective);
+      max_rows common padded height when known (saves nothing on its own: without `counts` the row counts are exchanged
+               anyway, because untrimmed zero rows would reach the fusion step as fake label-0 samples)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
-    n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    if max_rows is None:
-        dist.all_gather(counts, n)
-        counts = [int(c.item()) for c in counts]
-        max_rows = max(counts)
-    else:
-        counts = None
-    buf = local.new_zeros((max_rows,) + tuple(local.shape[1:]))
-    buf[:local.shape[0]] = local
-    out = local.new_empty((world * max_rows,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, buf.contiguous())
     if counts is None:
+        n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+        got = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(got, n)
+        counts = [int(c.item()) for c in got]
+    counts = [int(c) for c in counts]
+    assert len(counts) == world and counts[dist.get_rank()] == local.shape[0], (counts, local.shape)
+    height = max(counts) if max_rows is None else int(max_rows)
+    assert height >= max(counts), f"max_rows={height} < largest rank block {max(counts)}"
+    if all(c == height for c in counts):
+        out = local.new_empty((world * height,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local.contiguous())
         return out
-    return torch.cat([out[r * max_rows: r * max_rows + c] for r, c in enumerate(counts)], 0)
+    buf = local.new_zeros((height,) + tuple(local.shape[1:]))
+    buf[:local.shape[0]] = local
+    out = local.new_empty((world * height,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, buf)
+    return torch.cat([out[r * height: r * height + c] for r, c in enumerate(counts)], 0)
 
 
-def gather_fusion_batch(audios, texts, videos, emos=None, vals=None):
+def gather_fusion_batch(audios, texts, videos, emos=None, vals=None, counts=None):
     """One fused all-gather of the minibatch every rank needs for the identical fusion step.
-    Inputs are this rank's rows; returns the full-batch (audios, texts, videos[, emos, vals]) in rank order."""
+    Inputs are this rank's rows; returns the full-batch (audios, texts, videos[, emos, vals]) in rank order.
+    counts: per-rank row counts when known (equal shards: [B/W] * W) — skips the count exchange."""
     da, dt, dv = audios.shape[1], texts.shape[1], videos.shape[1]
     cols = [audios.float(), texts.float(), videos.float()]
     if emos is not None:
         cols.append(emos.float()[:, None])  # class ids < 2^24 are exact in fp32
     if vals is not None:
         cols.append(vals.float()[:, None])
-    full = all_gather_rows(torch.cat(cols, 1).contiguous())
+    full = all_gather_rows(torch.cat(cols, 1).contiguous(), counts=counts)
     out = [full[:, :da], full[:, da:da + dt], full[:, da + dt:da + dt + dv]]
     c = da + dt + dv
     if emos is not None:

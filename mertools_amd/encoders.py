@@ -26,6 +26,7 @@ precision (see DESIGN.md §numerics for the measured parity of each):
     "mixed" / "balanced3"  HuBERT only: conv stack 3-pass with 1- / 2-pass transformer blocks
 """
 import ctypes as C
+import functools
 import os
 
 import torch
@@ -163,6 +164,21 @@ class _HipModule:
         self._handle = C.c_void_p()
         self._ws = None
 
+    def __init_subclass__(cls, **kw):
+        """Every forward runs with the model's own GPU current: the C ABI launches on the current HIP device and ops.stream()
+        returns the current device's stream, while weights / workspaces / outputs live on self.device — a model built on
+        cuda:1 and called while cuda:0 is current would otherwise launch on GPU 0 with GPU 1 pointers."""
+        super().__init_subclass__(**kw)
+        fr = cls.__dict__.get("forward_raw")
+        if fr is not None:
+            @functools.wraps(fr)
+            def guarded(self, *a, **k):
+                if self.device.type != "cuda":
+                    raise _lib.MerError("mertools_amd encoders run on a GPU (there is no CPU path)")
+                with torch.cuda.device(self.device):
+                    return fr(self, *a, **k)
+            cls.forward_raw = guarded
+
     def _workspace(self, nbytes):
         # one arena per HIP stream: forwards issued on different streams (half-batches overlapping each other's kernel
         # tails, bench.py --split) must not share scratch memory
@@ -186,7 +202,18 @@ class _HipModule:
         if t is None:
             if len(cache) >= 256:
                 cache.clear()
-            t = cache[key] = torch.tensor(key, dtype=torch.int32).to(self.device)
+            host = torch.tensor(key, dtype=torch.int32)
+            if self.device.type == "cuda":   # pinned staging + async copy: a table that changes every batch (ragged audio) must not stall the host either
+                host = host.pin_memory()
+                t = host.to(self.device, non_blocking=True)
+                self.__dict__.setdefault("_int_pins", {})[key] = host   # alive as long as the cached device copy
+                if len(self._int_pins) > 256:
+                    for k in list(self._int_pins):
+                        if k not in cache and k != key:
+                            del self._int_pins[k]
+            else:
+                t = host
+            cache[key] = t
         return t
 
     def _seg(self, seg_start, seg_len):
@@ -347,7 +374,10 @@ class HipHubertModel(_HipModule):
             self._pos_bias[T] = padded.contiguous().to(self.device)
         return self._pos_bias[T]
 
-    def forward_raw(self, input_values, *, hidden_states=False, frames=False, seg_start=None, seg_len=None):
+    def forward_raw(self, input_values, *, hidden_states=False, frames=False, seg_start=None, seg_len=None, valid_samples=None):
+        """valid_samples: per-row sample counts of a RAGGED batch (rows = clips of different lengths, zero-padded to the
+        common L).  Each row's valid frames then equal its batch-of-one forward — the reference never pads or masks audio
+        (extract_audio_huggingface.py:93-100) — and the frames past a row's length are unspecified."""
         x = input_values
         if not x.is_cuda:
             x = x.to(self.device)
@@ -361,8 +391,18 @@ class HipHubertModel(_HipModule):
         nbytes = _lib.lib().mer_hubert_workspace_bytes(self._handle, B, L, int(hidden_states))
         wp, wn = self._workspace(nbytes)
         pb = self.position_bias(T)
-        _lib.check(_lib.lib().mer_hubert_forward_bias(
-            self._handle, x.data_ptr(), B, L, wp, wn, hs.data_ptr() if hs is not None else None,
+        vs = None
+        if valid_samples is not None:
+            valid_samples = [int(v) for v in valid_samples]
+            if len(valid_samples) != B or min(valid_samples) < 1 or max(valid_samples) > L:
+                raise _lib.MerError(f"valid_samples must hold one count in [1, {L}] per row (got {valid_samples})")
+            if min(self.out_frames(v) for v in set(valid_samples)) < 1:
+                raise _lib.MerError("a clip is shorter than the conv stack's receptive field")
+            if any(v != L for v in valid_samples):
+                vs = self._ints(valid_samples)
+        _lib.check(_lib.lib().mer_hubert_forward_ragged(
+            self._handle, x.data_ptr(), B, L, vs.data_ptr() if vs is not None else None, wp, wn,
+            hs.data_ptr() if hs is not None else None,
             fr.data_ptr() if fr is not None else None, ss.data_ptr() if nseg else None, sl.data_ptr() if nseg else None, nseg,
             pooled.data_ptr() if nseg else None, pb.data_ptr() if pb is not None else None, pb.shape[2] if pb is not None else 0,
             stream()), "mer_hubert_forward")
@@ -374,18 +414,24 @@ class HipHubertModel(_HipModule):
         hs, _, _ = self.forward_raw(input_values, hidden_states=True)
         return EncoderOutput(last_hidden_state=hs[-1], hidden_states=tuple(hs[i] for i in range(hs.shape[0])) if output_hidden_states else None)
 
-    def extract_utterance(self, input_values, clip_chunks=None):
-        """Fused path: last-4 sum + mean over all frames of each clip -> [nclip, D].
-        clip_chunks[i] = number of consecutive batch rows belonging to clip i (default 1 each)."""
-        B, L = input_values.shape
+    def clip_segments(self, L, clip_chunks, valid_samples=None):
+        """(seg_start, seg_len) over the flattened [B*T] frame axis: clip i = clip_chunks[i] consecutive rows.  A one-row clip
+        of a ragged batch covers the frames its own samples produce; a chunked clip (> 10 s) covers all frames of its
+        rows, zero-padded tail included, as in the reference (extract_audio_huggingface.py:46-49,99-107)."""
         T = self.out_frames(L)
-        clip_chunks = clip_chunks or [1] * B
         starts, lens, r = [], [], 0
         for n in clip_chunks:
             starts.append(r * T)
-            lens.append(n * T)
+            lens.append(n * T if (n > 1 or valid_samples is None) else self.out_frames(int(valid_samples[r])))
             r += n
-        _, _, pooled = self.forward_raw(input_values, seg_start=starts, seg_len=lens)
+        return starts, lens
+
+    def extract_utterance(self, input_values, clip_chunks=None, valid_samples=None):
+        """Fused path: last-4 sum + mean over all frames of each clip -> [nclip, D].
+        clip_chunks[i] = number of consecutive batch rows belonging to clip i (default 1 each)."""
+        B, L = input_values.shape
+        starts, lens = self.clip_segments(L, clip_chunks or [1] * B, valid_samples)
+        _, _, pooled = self.forward_raw(input_values, seg_start=starts, seg_len=lens, valid_samples=valid_samples)
         return pooled
 
 

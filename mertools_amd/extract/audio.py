@@ -71,6 +71,7 @@ def load_model(model_name, gpu, precision="mx"):
     model_file = os.path.join(config.PATH_TO_PRETRAINED_MODELS, f'transformers/{model_name}')
     hf = AutoModel.from_pretrained(model_file)
     fe = Wav2Vec2FeatureExtractor.from_pretrained(model_file)
+    torch.cuda.set_device(max(gpu, 0))
     return HipHubertModel.from_hf(hf, device=f'cuda:{max(gpu, 0)}', precision=precision), fe.do_normalize
 
 
@@ -141,31 +142,67 @@ def extract_whisper(model_name, audio_files, save_dir, feature_level, gpu, model
 
 def device_normalize(samples, do_normalize, device):
     """wav2vec2_normalize on the GPU: the utterance goes up as 16-bit PCM when it is exactly representable (what a PCM16 file
-    holds: half the H2D bytes of fp32, a quarter of the float64 the reference moves), else as fp32; mer_wave_normalize."""
+    holds: half the H2D bytes of fp32, a quarter of the float64 the reference moves), else as fp32; mer_wave_normalize.
+    The result STAYS on the device (the batch is assembled there)."""
     from .. import ops
     x = np.asarray(samples, dtype=np.float64)
     pcm = np.round(x * 32768.0)
-    if np.array_equal(pcm / 32768.0, x) and pcm.min() >= -32768 and pcm.max() <= 32767:
-        t = torch.from_numpy(pcm.astype(np.int16))[None].to(device)
-    else:
-        t = torch.from_numpy(x.astype(np.float32))[None].to(device)
-    return ops.wave_normalize(t, do_normalize).cpu()
+    with torch.cuda.device(device):
+        if np.array_equal(pcm / 32768.0, x) and pcm.min() >= -32768 and pcm.max() <= 32767:
+            t = torch.from_numpy(pcm.astype(np.int16))[None].to(device)
+        else:
+            t = torch.from_numpy(x.astype(np.float32))[None].to(device)
+        return ops.wave_normalize(t, do_normalize)
+
+
+def plan_batches(pending, batch_rows, ragged, final, max_stretch=1.5, keep_at_most=0):
+    """Cuts the pending clips (dicts with 'rows', 'len') into batches; returns (batches, still_pending).
+    ragged: clips are sorted by length and consecutive ones share a batch while the longest is at most `max_stretch` x the
+    shortest (bounds the padded work) and the rows fit `batch_rows`; otherwise only clips of identical shape batch together.
+    Unless `final`, groups that are not full stay pending so that later clips of similar length can join them — but never
+    more than `keep_at_most` clips: beyond that the fullest partial groups are emitted too (bounded host memory)."""
+    key = (lambda it: (it['len'],)) if ragged else (lambda it: (it['len'], it['rows']))
+    groups, cur, rows = [], [], 0
+    for it in sorted(pending, key=key):
+        fits = cur and rows + it['rows'] <= batch_rows and (
+            it['len'] <= max_stretch * cur[0]['len'] if ragged else key(it) == key(cur[0]))
+        if cur and not fits:
+            groups.append(cur)
+            cur, rows = [], 0
+        cur.append(it)
+        rows += it['rows']
+    if cur:
+        groups.append(cur)
+    if final:
+        return groups, []
+    nrows = lambda g: sum(it['rows'] for it in g)   # noqa: E731
+    out = [g for g in groups if nrows(g) >= batch_rows]
+    part = sorted((g for g in groups if nrows(g) < batch_rows), key=nrows)
+    while part and sum(len(g) for g in part) > keep_at_most:
+        out.append(part.pop())
+    return out, [it for g in part for it in g]
 
 
 def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
-            reader=read_audio, device_preprocess=False, workers=0):
+            reader=read_audio, device_preprocess=False, workers=0, rank=None, world=None, window=256, ragged=True):
     """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy.
-    workers: threads that read and normalise the clips ahead of the bucketing loop (extract.prefetch; 0 = in line)."""
+    workers: threads that read and normalise the clips ahead of the batching loop (extract.prefetch; 0 = in line).
+    rank / world: this process's share of `audio_files` (distributed.shard: sorted(files)[rank::world]; default = the
+    torch.distributed rank / world size, 0 / 1 when not initialised) — clips are independent, no collective.
+    window: clips held on the host at most before batches are cut (host memory is O(window), not O(corpus)).
+    ragged: batch clips of DIFFERENT lengths together (rows zero-padded to the longest, mer_hubert_forward_ragged makes each
+    clip equal to its batch-of-one forward); False = only clips of identical length share a batch."""
     from .prefetch import prefetch_map
+    from .. import distributed
+    if rank is None:
+        rank, world = distributed.rank_world()
+    audio_files = distributed.my_share(audio_files, rank, world)
     if model_name in (WHISPER_BASE, WHISPER_LARGE) or type(model).__name__ == 'HipWhisperModel':
         return extract_whisper(model_name, audio_files, save_dir, feature_level, gpu, model=model, reader=reader)   # reference :79-89
     start_time = time.time()
     if model is None:
         model, do_normalize = load_model(model_name, gpu)
     os.makedirs(save_dir, exist_ok=True)
-    # bucket clips by the shape they have after split_into_batch: equal-length rows batch without any masking
-    # (the reference never masks audio, and GroupNorm runs over the whole row, so padding would change results)
-    buckets = {}
 
     def host_stage(audio_file):
         samples, sr = reader(audio_file)
@@ -174,35 +211,54 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
             return audio_file, samples
         return audio_file, split_into_batch(wav2vec2_normalize(samples, do_normalize))
 
+    def flush(items):
+        L = max(it['len'] for it in items)
+        same = all(it['len'] == L for it in items)
+        ivs = [it['iv'] for it in items]
+        if same:
+            rows = torch.cat(ivs, 0)
+        else:   # zero-padded rows; one-row clips only differ in length (chunked clips are exactly MAXLEN wide)
+            rows = torch.zeros((sum(it['rows'] for it in items), L), dtype=torch.float32, device=ivs[0].device)
+            r = 0
+            for it in items:
+                rows[r:r + it['rows'], :it['len']] = it['iv']
+                r += it['rows']
+        chunks = [it['rows'] for it in items]
+        valid = None if same else [it['len'] for it in items for _ in range(it['rows'])]
+        T = model.out_frames(L)
+        if feature_level == 'UTTERANCE':
+            pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid).cpu().numpy()
+            for it, feat in zip(items, pooled):
+                save_feature(os.path.join(save_dir, f"{it['vid']}.npy"), feat, feature_level)
+        else:
+            starts, lens = model.clip_segments(L, chunks, valid)
+            _, frames, _ = model.forward_raw(rows, frames=True, valid_samples=valid)
+            frames = frames.cpu().numpy()
+            for it, s0, n in zip(items, starts, lens):
+                save_feature(os.path.join(save_dir, f"{it['vid']}.npy"), frames[s0:s0 + n], feature_level)
+
+    pending = []
     for audio_file, iv in prefetch_map(host_stage, audio_files, workers):
         if device_preprocess:   # GPU work stays on the calling thread
-            iv = split_into_batch(device_normalize(iv, do_normalize, model.device))
-        buckets.setdefault(tuple(iv.shape), []).append((os.path.basename(audio_file)[:-4], iv))
-
-    def flush(items):
-        rows = torch.cat([iv for _, iv in items], 0)
-        chunks = [iv.shape[0] for _, iv in items]
-        T = model.out_frames(rows.shape[1])
-        if feature_level == 'UTTERANCE':
-            pooled = model.extract_utterance(rows, clip_chunks=chunks).cpu().numpy()
-            for (vid, _), feat in zip(items, pooled):
-                save_feature(os.path.join(save_dir, f'{vid}.npy'), feat, feature_level)
-        else:
-            _, frames, _ = model.forward_raw(rows, frames=True)
-            frames = frames.cpu().numpy()
-            r = 0
-            for (vid, _), n in zip(items, chunks):
-                save_feature(os.path.join(save_dir, f'{vid}.npy'), frames[r * T:(r + n) * T], feature_level)
-                r += n
-
-    for shape, items in buckets.items():
-        cur, rows = [], 0
-        for it in items:
-            if cur and rows + it[1].shape[0] > batch_rows:
-                flush(cur)
-                cur, rows = [], 0
-            cur.append(it)
-            rows += it[1].shape[0]
-        if cur:
-            flush(cur)
+            iv = split_into_batch_any(device_normalize(iv, do_normalize, model.device))
+        pending.append(dict(vid=os.path.basename(audio_file)[:-4], iv=iv, rows=iv.shape[0], len=iv.shape[1]))
+        if len(pending) >= window:
+            batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=window // 2)
+            for b in batches:
+                flush(b)
+    batches, pending = plan_batches(pending, batch_rows, ragged, final=True)
+    for b in batches:
+        flush(b)
     print(f'Total time used: {time.time() - start_time:.1f}s.')
+
+
+def split_into_batch_any(input_values, maxlen=None):
+    """split_into_batch for a tensor on any device (the reference's version allocates on the host)."""
+    maxlen = maxlen if maxlen is not None else split_into_batch.__defaults__[0]
+    if input_values.shape[1] <= maxlen:
+        return input_values
+    wavlen = input_values.shape[1]
+    tgtlen = math.ceil(wavlen / maxlen) * maxlen
+    out = torch.zeros((1, tgtlen), dtype=input_values.dtype, device=input_values.device)
+    out[:, :wavlen] = input_values
+    return out.view(-1, maxlen)

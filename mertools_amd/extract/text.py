@@ -58,7 +58,7 @@ def save_embeddings(csv_file, embeddings, feature_level, feature_dim):
 
 
 def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, punc_case=None, language='chinese',
-                      model_dir=None, model=None, tokenizer=None, batch_size=64):
+                      model_dir=None, model=None, tokenizer=None, batch_size=64, rank=None, world=None):
     import pandas as pd
     print('=' * 30 + f' Extracting "{model_name}" ' + '=' * 30)
     start_time = time.time()
@@ -77,12 +77,19 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
         from ..encoders import HipBertModel
         if model_dir is None:
             model_dir = os.path.join(config.PATH_TO_PRETRAINED_MODELS, f'transformers/{model_name}')
+        torch.cuda.set_device(max(gpu, 0))   # reference: torch.cuda.set_device(gpu) (extract_text_huggingface.py:192-193)
         model = HipBertModel.from_hf(AutoModel.from_pretrained(model_dir), device=f'cuda:{max(gpu, 0)}')
         tokenizer = AutoTokenizer.from_pretrained(model_dir, use_fast=False)
     start, end = find_start_end_pos(tokenizer)
     batch_pos, feature_dim = find_batchpos_embdim(tokenizer, model, gpu)
     pad_id = model.config.pad_token_id if model.config.pad_token_id is not None else 0
     df = pd.read_csv(trans_dir)
+    from ..distributed import rank_world
+    if rank is None or world is None:
+        rank, world = rank_world()
+    if world > 1:   # this process's share of the sentences: sorted names [rank::world] (sentences are independent, no collective)
+        mine = set(sorted(str(n) for n in df['name'])[rank::world])
+        df = df[[str(n) in mine for n in df['name']]]
     todo = []
     for idx, row in df.iterrows():
         sentence = row['chinese'] if language == 'chinese' else row['english']

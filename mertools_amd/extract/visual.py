@@ -72,16 +72,20 @@ def save_embeddings(save_file, embeddings, feature_level, embedding_dim):
 
 
 def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
-            device_preprocess=False, workers=0):
+            device_preprocess=False, workers=0, rank=None, world=None):
     """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video.
     device_preprocess: frames that already have the model's resolution go to the GPU as uint8 (a quarter of the fp32 bytes)
     and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path —
     unless device_preprocess == "resize": then every uint8 video goes up as bytes and the Pillow-exact bicubic resize +
     centre crop runs on the GPU as well (extract.resize / mer_image_resize_crop_u8; no PIL on the host at all).
-    workers: threads that read and pre-process videos ahead of the GPU loop (extract.prefetch; 0 = in line, as the reference)."""
+    workers: threads that read and pre-process videos ahead of the GPU loop (extract.prefetch; 0 = in line, as the reference).
+    rank / world: this process's share of the videos (distributed.my_share: sorted(vids)[rank::world]; default = the
+    torch.distributed rank / world size).  Videos are independent: no collective.  (The reference's EMBEDDING_DIM fallback for
+    an empty video is the running maximum over the videos THIS process has seen before it.)"""
     from .prefetch import prefetch_map
+    from ..distributed import my_share
     os.makedirs(save_dir, exist_ok=True)
-    vids = vids if vids is not None else os.listdir(face_dir)
+    vids = my_share(vids if vids is not None else os.listdir(face_dir), rank, world)
     embedding_dim = -1
     pending, nframes = [], 0
     size = model.config.vision_config.image_size
@@ -164,11 +168,12 @@ def videomae_preprocess(frames_bgr, size=224):
 
 
 def extract_videomae(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, videos_per_batch=8, reader=func_read_frames,
-                     device_preprocess=False):
+                     device_preprocess=False, rank=None, world=None):
     """VideoMAE branch of the reference loop: 16 uniformly resampled frames per video -> last_hidden_state ->
     view(8, 196, D).mean(1) -> [8, D] (FRAME) or its mean (UTTERANCE).  `model`: HipVideoMAEModel; videos are batched."""
     os.makedirs(save_dir, exist_ok=True)
-    vids = vids if vids is not None else os.listdir(face_dir)
+    from ..distributed import my_share
+    vids = my_share(vids if vids is not None else os.listdir(face_dir), rank, world)
     nseg = model.config.num_frames // model.config.tubelet_size
     pending = []
 
@@ -213,11 +218,12 @@ def dinov2_preprocess(frames_bgr, size=224, resize_to=256):
 
 
 def extract_dinov2(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames, nframe=64,
-                   device_preprocess=False):
+                   device_preprocess=False, rank=None, world=None):
     """DINOv2 branch of the reference loop: 64 uniformly resampled frames per video (:134) -> token SUM of the last hidden
     state per frame (:141-142) -> [64, D] (FRAME) or its mean (UTTERANCE).  `model`: HipDinov2Model; videos share batches."""
     os.makedirs(save_dir, exist_ok=True)
-    vids = vids if vids is not None else os.listdir(face_dir)
+    from ..distributed import my_share
+    vids = my_share(vids if vids is not None else os.listdir(face_dir), rank, world)
     embedding_dim = -1
     pending, nframes = [], 0
 
@@ -264,10 +270,11 @@ def data2vec_vision_preprocess(frames_bgr, size=224):
 
 
 def extract_data2vec_vision(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
-                            device_preprocess=False):
+                            device_preprocess=False, rank=None, world=None):
     """data2vec-vision branch: ALL frames of a video (no resampling) -> token sum of the last hidden state per frame (:130-131)."""
     os.makedirs(save_dir, exist_ok=True)
-    vids = vids if vids is not None else os.listdir(face_dir)
+    from ..distributed import my_share
+    vids = my_share(vids if vids is not None else os.listdir(face_dir), rank, world)
     embedding_dim = -1
     pending, nframes = [], 0
 

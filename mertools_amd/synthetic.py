@@ -393,6 +393,22 @@ def bert_state_dict(cfg, seed=0):
     return sd
 
 
+def heavy_tailed(sd, sigma=0.7, seed=99):
+    """Copy of a synthetic checkpoint whose matrix weights (Linear / Conv kernels) are multiplied elementwise by a log-normal
+    factor exp(sigma * n): pretrained checkpoints carry outlier weights / channels that a Gaussian init lacks, and those are
+    what stresses 16-bit weight rounding and the MX-fp4 residual plane (one E8M0 scale per 32 k).  Embedding tables, biases
+    and LayerNorm parameters are left alone."""
+    g = _g(seed)
+    out = {}
+    for k, v in sd.items():
+        if v.dim() >= 2 and k.endswith("weight") and "embeddings." not in k and "embedding" not in k.split(".")[-2]:
+            f = torch.exp(sigma * torch.randn(v.shape, generator=g))
+            out[k] = v * f / math.sqrt(math.exp(sigma * sigma * 2))   # keep the second moment (activations stay in range)
+        else:
+            out[k] = v
+    return out
+
+
 # ---- the seeded synthetic inputs of SURVEY.md §8(d) ----
 def synth_audio(B, L=80000, seed=1234):
     wav = 0.1 * torch.randn(B, L, generator=_g(seed))

@@ -145,8 +145,9 @@ class HipWhisperModel:
         return out.view(B, Td, D)
 
     def __call__(self, input_features=None, decoder_input_ids=None, **_):
-        enc = self.encode(input_features)
-        return EncoderOutput(last_hidden_state=self.decode(enc, decoder_input_ids))
+        with torch.cuda.device(self.device):   # the op wrappers launch on the current device's current stream
+            enc = self.encode(input_features)
+            return EncoderOutput(last_hidden_state=self.decode(enc, decoder_input_ids))
 
     def extract_utterance(self, input_features):
         """The reference's per-clip output (extract_audio_huggingface.py:84-89): two decoder start tokens -> (2, D) per clip."""

@@ -231,7 +231,7 @@ def test_roberta_base_64tok(dev):
     ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids))
     feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
     res = {}
-    for prec in ("fast", "balanced", "accurate"):
+    for prec in ("fast", "balanced", "mx", "accurate"):
         m = HipBertModel(sd, cfg, device=dev, precision=prec)
         hs, fr, pooled = m.forward_raw(ids.to(dev), lengths=[64] * 4, hidden_states=True, frames=True,
                                        seg_start=[b * 64 + 1 for b in range(4)], seg_len=[62] * 4)
@@ -241,7 +241,159 @@ def test_roberta_base_64tok(dev):
         _report(f"roberta-base[{prec}]", res[prec])
         del m
     assert res["balanced"]["utt"] <= TOL, res
+    assert res["mx"]["utt"] <= TOL, res      # 256 rows: the MX preset falls back to the 2-pass 128x128 kernels here
     assert res["accurate"]["frame"] <= TOL and res["accurate"]["utt"] <= X3, res
+
+
+# ---- the kernel selection bench.py times (B = 64): M >= 1024 rows puts every block GEMM on the 256x256 tiles — one-pass
+# [Q|K], MX-corrected V / attention output / post-LN FFN, pre-blocked weight planes.  Batches just large enough to cross
+# that threshold keep the CPU oracle at seconds; a clip's features do not depend on its batch mates, so each row is
+# compared with the oracle's row.  `heavy`: log-normal outlier weights (synthetic.heavy_tailed) — what a pretrained
+# checkpoint's outlier channels do to 16-bit weight rounding and the fp4 residual plane.
+@pytest.mark.parametrize("heavy", [False, True])
+def test_hubert_base_bench_tiles(dev, heavy):
+    from mertools_amd.encoders import HipHubertModel
+    from util import rel_err
+    cfg = W.hubert_config("base")
+    sd = W.hubert_state_dict(cfg, 0)
+    if heavy:
+        sd = W.heavy_tailed(sd)
+    B = 8                                   # M = 8 * 249 = 1992 rows
+    wav = W.synth_audio(B, 80000, seed=4321)
+    hs = R.hubert_hidden_states(sd, vars(cfg), wav)
+    feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
+    utt = feat.mean(1)
+    res = {}
+    for prec in ("mx", "balanced"):
+        m = HipHubertModel(sd, cfg, device=dev, precision=prec)
+        _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
+        torch.cuda.synchronize()
+        res[prec] = dict(frame=rel_err(fr.cpu().view(B, 249, 768), feat)[0], utt=rel_err(pooled.cpu(), utt)[0],
+                         utt_worst_clip=max(rel_err(pooled[b].cpu(), utt[b])[0] for b in range(B)))
+        _report(f"hubert-base B={B} heavy={heavy} [{prec}]", res[prec])
+        del m
+    for prec in res:
+        assert res[prec]["utt"] <= TOL and res[prec]["utt_worst_clip"] <= TOL, res
+        assert res[prec]["frame"] <= 2 * TOL, res     # FRAME features: reported; the saved default (UTT) is held to 1e-3
+
+
+@pytest.mark.parametrize("heavy", [False, True])
+def test_roberta_base_bench_tiles(dev, heavy):
+    from mertools_amd.encoders import HipBertModel
+    from util import rel_err
+    cfg = W.bert_config("roberta-base")
+    sd = W.bert_state_dict(cfg, 0)
+    if heavy:
+        sd = W.heavy_tailed(sd)
+    B = 16                                  # M = 16 * 64 = 1024 rows
+    ids = W.synth_tokens(B, 64, seed=4322)
+    ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids))
+    feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
+    utt = feat[:, 1:-1].mean(1)
+    res = {}
+    for prec in ("mx", "balanced"):
+        m = HipBertModel(sd, cfg, device=dev, precision=prec)
+        _, fr, pooled = m.forward_raw(ids.to(dev), lengths=[64] * B, frames=True, seg_start=[b * 64 + 1 for b in range(B)], seg_len=[62] * B)
+        torch.cuda.synchronize()
+        res[prec] = dict(frame=rel_err(fr.cpu().view(B, 64, 768), feat)[0], utt=rel_err(pooled.cpu(), utt)[0],
+                         utt_worst_clip=max(rel_err(pooled[b].cpu(), utt[b])[0] for b in range(B)))
+        _report(f"roberta-base B={B} heavy={heavy} [{prec}]", res[prec])
+        del m
+    for prec in res:
+        assert res[prec]["utt"] <= TOL and res[prec]["utt_worst_clip"] <= TOL, res
+        assert res[prec]["frame"] <= 2 * TOL, res
+
+
+def test_clip_base16_heavy_tailed(dev):
+    """CLIP-B/16, 8 frames (1576 rows: the bench's kernels) with outlier weights."""
+    from mertools_amd.encoders import HipCLIPModel
+    from util import rel_err
+    cfg = W.clip_config("base16")
+    sd = W.heavy_tailed(W.clip_state_dict(cfg, 0))
+    px = W.synth_frames(8, seed=4323)
+    ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
+    m = HipCLIPModel(sd, cfg, device=dev, precision="mx")
+    out = m.get_image_features(px.to(dev))
+    pooled = m.extract_utterance(px.to(dev), [8])
+    torch.cuda.synchronize()
+    e, eu = rel_err(out.cpu(), ref)[0], rel_err(pooled.cpu(), ref.mean(0, keepdim=True))[0]
+    print(f"clip-B/16 heavy-tailed [mx]: frames={e:.2e} utt={eu:.2e}")
+    assert eu <= TOL and e <= 2 * TOL
+
+
+def test_clip_base32_frames(dev):
+    """CLIP-ViT-B/32 (extract_vision_huggingface.py:64-72 model list): 50 tokens per frame -> the short-T attention
+    instantiation; 32 frames = 1600 rows so the block GEMMs take the 256x256 kernels."""
+    from mertools_amd.encoders import HipCLIPModel
+    from util import rel_err
+    cfg = W.clip_config("base16", patch_size=32)
+    sd = W.clip_state_dict(cfg, 0)
+    px = W.synth_frames(32, seed=4324)
+    ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
+    for prec in ("mx", "accurate"):
+        m = HipCLIPModel(sd, cfg, device=dev, precision=prec)
+        out = m.get_image_features(px.to(dev))
+        pooled = m.extract_utterance(px.to(dev), [8] * 4)
+        torch.cuda.synchronize()
+        e, eu = rel_err(out.cpu(), ref)[0], rel_err(pooled.cpu(), ref.view(4, 8, -1).mean(1))[0]
+        print(f"clip-B/32[{prec}]: frames={e:.2e} utt={eu:.2e}")
+        assert out.shape == (32, 512)
+        assert eu <= (TOL if prec == "mx" else X3) and e <= (2 * TOL if prec == "mx" else TOL)
+        del m
+
+
+# ---- ragged audio batches: clips of different lengths in ONE batch, each equal to its batch-of-one forward (the reference
+# runs batch 1 and never pads or masks audio: extract_audio_huggingface.py:93-100) ----
+@pytest.mark.parametrize("style", ["tiny-base", "tiny-large", "tiny-wavlm", "base", "large"])
+def test_hubert_ragged_batch(dev, style):
+    from mertools_amd.encoders import HipHubertModel
+    from util import rel_err
+    if style == "tiny-base":
+        cfg, lens = W.hubert_config("tiny"), [8000, 3001, 5555, 7999, 4000, 6123, 2000, 7000]
+    elif style == "tiny-large":
+        cfg, lens = W.hubert_config("tiny", feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True), [8000, 3001, 5555, 7999, 4000, 6123, 2000, 7000]
+    elif style == "tiny-wavlm":
+        cfg, lens = W.wavlm_config("tiny"), [8000, 3001, 5555, 7999]
+    elif style == "base":   # 8 clips of 8 different lengths, 2.1 .. 5 s: 1992 rows -> the 256x256 kernels
+        cfg, lens = W.hubert_config("base"), [80000, 33791, 52345, 79999, 41000, 66123, 71717, 60000]
+    else:
+        cfg, lens = W.hubert_config("large", num_hidden_layers=6), [48000, 20011, 33333, 40960]
+    sd = W.hubert_state_dict(cfg, 7)
+    B, L = len(lens), max(lens)
+    g = torch.Generator().manual_seed(77)
+    clips = []
+    for n in lens:   # each clip normalised on its own, as the feature extractor does per utterance
+        w = 0.1 * torch.randn(1, n, generator=g)
+        clips.append((w - w.mean()) / torch.sqrt(w.var(unbiased=False) + 1e-7))
+    batch = torch.zeros(B, L)
+    for b, w in enumerate(clips):
+        batch[b, :lens[b]] = w[0]
+    m = HipHubertModel(sd, cfg, device=dev, precision="mx" if style in ("base", "large") else "accurate")
+    tol = TOL if style in ("base", "large") else X3
+    T = m.out_frames(L)
+    starts, seglens = m.clip_segments(L, [1] * B, lens)
+    _, fr, pooled = m.forward_raw(batch.to(dev), frames=True, seg_start=starts, seg_len=seglens, valid_samples=lens)
+    torch.cuda.synchronize()
+    fr = fr.cpu().view(B, T, -1)
+    worst = {"utt": 0.0, "frame": 0.0}
+    for b, w in enumerate(clips):
+        hs = R.hubert_hidden_states(sd, vars(cfg), w)          # the reference's batch-of-one forward of this clip
+        feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)[0]       # [T_b, D]
+        Tb = feat.shape[0]
+        assert Tb == seglens[b] == m.out_frames(lens[b])
+        worst["utt"] = max(worst["utt"], rel_err(pooled[b].cpu(), feat.mean(0))[0])
+        worst["frame"] = max(worst["frame"], rel_err(fr[b, :Tb], feat)[0])
+    print(f"hubert ragged [{style}]: worst clip utt={worst['utt']:.2e} frame={worst['frame']:.2e}")
+    assert worst["utt"] <= tol, worst
+    assert worst["frame"] <= (2 * TOL if style in ("base", "large") else tol), worst
+    # padding must not leak: the same clips in a batch padded 1000 samples further give the same features
+    batch2 = torch.zeros(B, L + 1000)
+    batch2[:, :L] = batch
+    starts2, seglens2 = m.clip_segments(L + 1000, [1] * B, lens)
+    _, _, pooled2 = m.forward_raw(batch2.to(dev), seg_start=starts2, seg_len=seglens2, valid_samples=lens)
+    torch.cuda.synchronize()
+    assert seglens2 == seglens
+    assert rel_err(pooled2.cpu(), pooled.cpu())[0] <= (1e-5 if style.startswith("tiny") else 2e-4)
 
 
 # ---- BASELINE.json configs[4]: the large trio (HuBERT-large, VideoMAE-L, RoBERTa-large) — full depth, batch 1 ----

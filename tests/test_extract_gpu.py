@@ -23,15 +23,16 @@ def _write_wav(path, x):
         w.writeframes((np.clip(x, -1, 1 - 1 / 32768) * 32768).astype("<i2").tobytes())
 
 
+@pytest.mark.parametrize("precision", ["accurate", "mx"])   # "mx" = the drivers' default preset
 @pytest.mark.parametrize("level", ["UTTERANCE", "FRAME"])
-def test_audio_extract_files(dev, tmp_path, level):
+def test_audio_extract_files(dev, tmp_path, level, precision):
     from mertools_amd.encoders import HipHubertModel
     from mertools_amd.extract import audio
     cfg = W.hubert_config("tiny")
     sd = W.hubert_state_dict(cfg, 1)
-    model = HipHubertModel(sd, cfg, device=dev, precision="accurate")
+    model = HipHubertModel(sd, cfg, device=dev, precision=precision)
     rng = np.random.RandomState(0)
-    lens = [6000, 9000, 6000, 25000]  # two equal-length clips batch together; 25000 > maxlen(below) is chunked
+    lens = [6000, 9000, 6000, 25000, 7321, 4800]  # different lengths share ragged batches; 25000 > maxlen(below) is chunked
     files = []
     for i, L in enumerate(lens):
         p = str(tmp_path / f"clip{i}.wav")
@@ -56,12 +57,13 @@ def test_audio_extract_files(dev, tmp_path, level):
         audio.split_into_batch.__defaults__ = old
 
 
-def test_visual_extract_files(dev, tmp_path):
+@pytest.mark.parametrize("precision", ["accurate", "mx"])
+def test_visual_extract_files(dev, tmp_path, precision):
     from mertools_amd.encoders import HipCLIPModel
     from mertools_amd.extract import visual
     cfg = W.clip_config("tiny")
     sd = W.clip_state_dict(cfg, 3)
-    model = HipCLIPModel(sd, cfg, device=dev, precision="accurate")
+    model = HipCLIPModel(sd, cfg, device=dev, precision=precision)
     rng = np.random.RandomState(1)
     face_dir = tmp_path / "openface_face"
     counts = {"v0": 5, "v1": 1, "v2": 9}
@@ -84,7 +86,8 @@ def test_visual_extract_files(dev, tmp_path):
             assert rel_err(torch.from_numpy(out), torch.from_numpy(ref).view(out.shape))[0] < TOL, (vid, level)
 
 
-def test_text_extract_files(dev, tmp_path):
+@pytest.mark.parametrize("precision", ["accurate", "mx"])
+def test_text_extract_files(dev, tmp_path, precision):
     tr = pytest.importorskip("transformers")
     import pandas as pd
     from mertools_amd.encoders import HipBertModel
@@ -95,7 +98,7 @@ def test_text_extract_files(dev, tmp_path):
     tok = tr.BertTokenizer(str(tmp_path / "vocab.txt"))
     cfg = W.bert_config("tiny", model_type="bert", pad_token_id=0, type_vocab_size=2, layer_norm_eps=1e-12, vocab_size=len(vocab))
     sd = W.bert_state_dict(cfg, 4)
-    model = HipBertModel(sd, cfg, device=dev, precision="accurate")
+    model = HipBertModel(sd, cfg, device=dev, precision=precision)
     rows = [("s0", "今天天气真好"), ("s1", "我很高兴"), ("s2", float("nan")), ("s3", "他不是很难过的你好"), ("s4", "好")]
     csv = str(tmp_path / "trans.csv")
     pd.DataFrame([dict(name=n, chinese=s, english="x") for n, s in rows]).to_csv(csv, index=False)
@@ -143,7 +146,6 @@ def test_device_preprocessing_matches_host_path(dev, tmp_path):
         assert a.shape == b.shape and np.abs(a - b).max() / np.abs(a).max() < 2e-4, v
 
 
-@pytest.mark.skipif(os.environ.get("MER_EXPERIMENTAL") != "1", reason="written without GPU access at the end of round 1; enable with MER_EXPERIMENTAL=1")
 def test_trimodal_pipeline_matches_direct_calls(dev):
     """TriModalExtractor (copy stream + one stream per modality, two batch slots) returns, batch by batch, exactly what the
     encoders return when called directly on resident inputs — fp32 inputs and the compact int16 PCM / uint8 BGR forms."""
@@ -181,7 +183,6 @@ def test_trimodal_pipeline_matches_direct_calls(dev):
         assert np.array_equal(feats["audio"], ref_a) and np.array_equal(feats["visual"], ref_v) and np.array_equal(feats["text"], ref_t)
 
 
-@pytest.mark.skipif(os.environ.get("MER_EXPERIMENTAL") != "1", reason="written without GPU access at the end of round 1; enable with MER_EXPERIMENTAL=1")
 def test_visual_extract_device_resize_equals_host_path(dev, tmp_path):
     """device_preprocess="resize": bytes up, Pillow-exact resize + crop + normalise on the GPU — the saved features must equal the
     host-PIL path's (the resized bytes are identical; the float normalisation may differ in the last bit)."""

@@ -502,11 +502,6 @@ def _unblock(plane, Mp, N):
     return logical.permute(0, 2, 1, 3, 4).reshape(Mp, N)
 
 
-_EXPERIMENTAL = pytest.mark.skipif(__import__("os").environ.get("MER_EXPERIMENTAL") != "1",
-                                   reason="written without GPU access at the end of round 1; enable with MER_EXPERIMENTAL=1")
-
-
-@_EXPERIMENTAL
 @pytest.mark.parametrize("M,N,K", [(2048, 3072, 768), (1500, 512, 256), (4100, 1024, 96)])
 def test_gemm16_blocked_activation_plane(dev, M, N, K):
     """fc1 -> fc2 in blocked form: (i) c16_blocked writes exactly the row-major 16-bit output, re-laid as [M/256][N/32] LDS images;
@@ -534,7 +529,6 @@ def test_gemm16_blocked_activation_plane(dev, M, N, K):
         assert torch.equal(c32, r32), passes
 
 
-@_EXPERIMENTAL
 def test_tf_ablk_option_is_bit_exact(dev):
     """mer_set_option("tf_ablk", 1): CLIP-B/16 frames with the FFN plane blocked == the default path, bit for bit."""
     from mertools_amd import _lib
@@ -553,7 +547,6 @@ def test_tf_ablk_option_is_bit_exact(dev):
     assert torch.equal(out, ref)
 
 
-@_EXPERIMENTAL
 @pytest.mark.parametrize("h,w,size", [(256, 320, 224), (300, 200, 224), (100, 100, 224), (480, 640, 224), (231, 517, 224), (224, 224, 224), (40, 52, 32)])
 def test_image_resize_crop_u8_matches_pillow(dev, h, w, size):
     """mer_image_resize_crop_u8 (two integer passes on the GPU, cropped region only) == PIL Image.resize(BICUBIC) + centre crop,

@@ -84,17 +84,33 @@ def test_visual_driver_identical_with_workers(tmp_path):
 
 
 class _Audio:
+    """Stand-in with the encoder's batching interface (ragged-aware: a row's feature only looks at its own samples)."""
     device = torch.device("cpu")
 
     def out_frames(self, L):
         return L // 320
 
-    def extract_utterance(self, rows, clip_chunks=None):
+    def clip_segments(self, L, clip_chunks, valid_samples=None):
+        T = self.out_frames(L)
+        starts, lens, r = [], [], 0
+        for n in clip_chunks:
+            starts.append(r * T)
+            lens.append(n * T if (n > 1 or valid_samples is None) else self.out_frames(valid_samples[r]))
+            r += n
+        return starts, lens
+
+    def extract_utterance(self, rows, clip_chunks=None, valid_samples=None):
         out, r = [], 0
         for n in clip_chunks:
-            out.append(torch.stack([rows[r:r + n].mean(), rows[r:r + n].abs().max(), rows[r, 7]]))
+            x = rows[r:r + n] if (n > 1 or valid_samples is None) else rows[r:r + 1, :valid_samples[r]]
+            out.append(torch.stack([x.double().mean().float(), x.abs().max(), x[0, 7]]))
             r += n
         return torch.stack(out)
+
+    def forward_raw(self, rows, frames=False, valid_samples=None):
+        T = self.out_frames(rows.shape[1])
+        fr = rows[:, :T * 320].reshape(rows.shape[0] * T, 320)[:, :4].contiguous()
+        return None, fr, None
 
 
 def test_audio_driver_identical_with_workers(tmp_path):
@@ -161,3 +177,75 @@ def test_other_visual_branches_run_with_stand_in_encoders(tmp_path):
     assert all(np.load(tmp_path / "dino" / f"{v}.npy").shape == (8, 5) for v in vids)
     visual.extract_data2vec_vision(_Tok(), face, str(tmp_path / "d2v"), "UTTERANCE", vids=vids, frames_per_batch=16)
     assert all(np.load(tmp_path / "d2v" / f"{v}.npy").shape == (5,) for v in vids)
+
+
+def _wavs(tmp_path, lens, seed=1):
+    rng = np.random.RandomState(seed)
+    files = []
+    for i, L in enumerate(lens):
+        p = str(tmp_path / f"a{i:03d}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes((np.clip(rng.randn(L) * 0.1, -1, 1 - 1 / 32768) * 32768).astype("<i2").tobytes())
+        files.append(p)
+    return files
+
+
+@pytest.mark.parametrize("level", ["UTTERANCE", "FRAME"])
+def test_audio_driver_ragged_streaming_and_sharded(tmp_path, level):
+    """Ragged batches (different lengths in one batch), a small streaming window and a 2-way clip shard all write the same
+    files as one exact-length-bucket pass over the whole list; the driver never holds more than `window` clips."""
+    rng = np.random.RandomState(3)
+    lens = [int(x) for x in rng.randint(3200, 20000, size=37)] + [4000, 4000, 4000] + [23000, 41000]   # the last two are chunked (> maxlen)
+    files = _wavs(tmp_path, lens)
+    old = audio.split_into_batch.__defaults__
+    audio.split_into_batch.__defaults__ = (20000,)
+    held = {"now": 0, "max": 0}
+
+    def reader(path):
+        held["now"] += 1
+        held["max"] = max(held["max"], held["now"])
+        return audio.read_audio(path)
+
+    class Counting(_Audio):
+        def extract_utterance(self, rows, clip_chunks=None, valid_samples=None):
+            held["now"] -= len(clip_chunks)
+            return super().extract_utterance(rows, clip_chunks, valid_samples)
+
+        def forward_raw(self, rows, frames=False, valid_samples=None):
+            return super().forward_raw(rows, frames, valid_samples)
+
+    try:
+        base = str(tmp_path / "base")
+        audio.extract("stub", files, base, level, 0, model=_Audio(), batch_rows=4, ragged=False)
+        rag = str(tmp_path / "ragged")
+        audio.extract("stub", files, rag, level, 0, model=Counting(), batch_rows=4, ragged=True, window=8, reader=reader)
+        if level == "UTTERANCE":
+            assert held["max"] <= 8 + 1, held          # host memory is O(window)
+        for r in range(2):
+            audio.extract("stub", files, str(tmp_path / "sharded"), level, 0, model=_Audio(), batch_rows=4, rank=r, world=2, window=8)
+        for f in files:
+            n = os.path.basename(f)[:-4] + ".npy"
+            a = np.load(os.path.join(base, n))
+            for other in (rag, str(tmp_path / "sharded")):
+                b = np.load(os.path.join(other, n))
+                assert a.shape == b.shape and np.array_equal(a, b), (n, other)
+    finally:
+        audio.split_into_batch.__defaults__ = old
+
+
+def test_plan_batches_bounds_padding_and_memory():
+    import random
+    random.seed(0)
+    pend = [dict(vid=i, rows=1, len=random.randint(16000, 160000)) for i in range(256)]
+    out, keep = audio.plan_batches(pend, 32, True, False, keep_at_most=128)
+    assert len(keep) <= 128 and sorted(it["vid"] for g in out for it in g) + sorted(it["vid"] for it in keep) is not None
+    assert sorted([it["vid"] for g in out for it in g] + [it["vid"] for it in keep]) == list(range(256))
+    for g in out:
+        assert sum(it["rows"] for it in g) <= 32 and max(it["len"] for it in g) <= 1.5 * min(it["len"] for it in g)
+    padded = sum(max(it["len"] for it in g) * len(g) for g in out)
+    assert padded <= 1.25 * sum(it["len"] for g in out for it in g)
+    out2, keep2 = audio.plan_batches(keep, 32, True, True)
+    assert not keep2 and sum(len(g) for g in out2) == len(keep)
