@@ -65,9 +65,26 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 
+// GELU(x) = x Phi(x) = max(x, 0) - |x| T(|x|) with T(a) = erfc(a / sqrt 2) / 2 = exp2(Q(a)): Q is a degree-6 polynomial fitted
+// on [0, 5.5] under the weight a T(a) (the error as it appears in the GELU value; past 5.5 |x| T(|x|) < 1.1e-7 and the clamp
+// keeps it there).  |result - exact| <= 2.6e-7 absolute in fp32 arithmetic (the erf route above: 1.5e-7 on erf) for
+// min + 6 FMA + v_exp_f32 + max + FMA, against ~15 VALU + v_rcp_f32 + v_exp_f32: the activation is the largest single VALU
+// cost of the fc1 / conv GEMM epilogues.
+__device__ __forceinline__ float gelu_exp2poly(float x) {
+  const float a = fminf(fabsf(x), 5.5f);
+  float q = 3.589585917e-05f;
+  q = fmaf(q, a, -7.945234977e-04f);
+  q = fmaf(q, a, 8.167289912e-03f);
+  q = fmaf(q, a, -5.355345435e-02f);
+  q = fmaf(q, a, -4.586574375e-01f);
+  q = fmaf(q, a, -1.151242835e+00f);
+  q = fmaf(q, a, -9.999880846e-01f);
+  return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
-    case MER_ACT_GELU: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    case MER_ACT_GELU: return gelu_exp2poly(x);
     case MER_ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     case MER_ACT_RELU: return x > 0.f ? x : 0.f;
     case MER_ACT_GELU_TANH: {   // tanh(u) = 1 - 2 / (exp(2u) + 1); exp overflow -> inf -> tanh = 1, underflow -> -1

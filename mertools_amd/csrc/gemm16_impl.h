@@ -48,6 +48,7 @@ struct Gemm16Params {
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
+  int pk_epi;     // 16-bit-only outputs: activation on the accumulators, row pairs packed before the LDS transposition (half the LDS traffic)
   int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
   int hm_T, hm_H;  // > 0: 16-bit output scattered head-major [N/(64*hm_H)][M/hm_T][hm_H][hm_T][64] (QKV for attention)
   unsigned long long* dbg;  // optional: 4 s_memtime stamps per workgroup (start, first slab ready, K loop done, end)
@@ -473,11 +474,78 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       }
     }
   };
+  // 16-bit-only outputs (QKV, fc1, conv GEMMs: the bulk of the tiles): bias + activation run on the accumulators (a lane's
+  // column of every 16-wide column tile: TN bias registers), rows (2q, 2q+1) of a column are packed into one dword BEFORE the
+  // transposition, so the staging tile holds row PAIRS: half the ds_write_b32 (the LDS pipe's slowest instruction, 64 B/clk/CU:
+  // 4096 of its cycles per 256x256 fp32 tile) and half the read-back; a lane then owns 8 columns of a row pair and un-zips
+  // them with v_perm_b32 into two 16-byte stores.
+  auto epilogue_pk = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    constexpr int CLDP = SN + 8;                 // dwords per staged row pair; 2 * CLDP % 32 == 16: the two lg halves of a ds_write_b32 group never share a bank
+    constexpr int PAIRS = EROWS / 2;
+    constexpr int PAIRS_IT = 64 / LANES_PER_ROW;
+    constexpr int NITP = PAIRS / PAIRS_IT;
+    static_assert(PAIRS * CLDP * 4 <= EROWS * CLD * 4 && NITP >= 1, "packed staging must fit the fp32 staging slice");
+    unsigned* cp = reinterpret_cast<unsigned*>(ct);
+    float bcol[TN];
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int c = n0 + wn * SN + nt * 16 + li;
+      bcol[nt] = (bias && c < p.N) ? bias[c] : 0.f;
+    }
+#pragma unroll
+    for (int ch = 0; ch < SM / EROWS; ++ch) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int mt = 0; mt < EROWS / 16; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const f32x4 a = acc[ch * (EROWS / 16) + mt][nt];
+          typename T16<T>::v4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = T16<T>::from_f32(act_apply(a[r] + bcol[nt], ACT));
+          const u32x2 pk = __builtin_bit_cast(u32x2, h);
+          cp[(mt * 8 + lg * 2 + 0) * CLDP + nt * 16 + li] = pk[0];   // rows 4 lg + {0, 1}
+          cp[(mt * 8 + lg * 2 + 1) * CLDP + nt * 16 + li] = pk[1];   // rows 4 lg + {2, 3}
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < NITP; ++it) {
+        const int pr = it * PAIRS_IT + rsub;
+        const int row = m0 + wm * SM + ch * EROWS + 2 * pr;
+        if (row >= p.M || !col_ok) continue;
+        const u32x4 d0 = *reinterpret_cast<const u32x4*>(cp + pr * CLDP + c8 * CPL);
+        const u32x4 d1 = *reinterpret_cast<const u32x4*>(cp + pr * CLDP + c8 * CPL + 4);
+        u32x4 ev, od;   // even row: low halves of the 8 dwords, odd row: high halves
+        ev[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u); od[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u);
+        ev[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u); od[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u);
+        ev[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); od[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u);
+        ev[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u); od[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
+        if (c16h) {
+          *reinterpret_cast<u32x4*>(c16h + (long long)row * p.ldc16 + col) = ev;
+          if (row + 1 < p.M) *reinterpret_cast<u32x4*>(c16h + (long long)(row + 1) * p.ldc16 + col) = od;
+        }
+      }
+    }
+  };
   if ((p.dbg_skip & 3) == 2) {
     if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
     return;
   }
   if ((p.dbg_skip & 3) == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
+  if (p.pk_epi) {   // host-checked: vector stores, 16-bit output only, row-major
+    switch (p.act) {
+      case MER_ACT_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}); break;
+      case MER_ACT_QUICK_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
+      case MER_ACT_RELU: epilogue_pk(std::integral_constant<int, MER_ACT_RELU>{}); break;
+      case MER_ACT_GELU_TANH: epilogue_pk(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
+      default: epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}); break;
+    }
+    return;
+  }
   switch (p.act) {  // one specialised copy of the epilogue per activation: no per-element switch
     case MER_ACT_GELU: epilogue(std::integral_constant<int, MER_ACT_GELU>{}); break;
     case MER_ACT_QUICK_GELU: epilogue(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
@@ -693,7 +761,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>

@@ -68,43 +68,73 @@ class FusionGraphTrainer:
         self.opt.step()
         return loss, emos_out, vals_out
 
-    def _capture(self, B, dims):
+    @torch.no_grad()
+    def _eval_body(self, batch, emos, vals):
+        features, emos_out, vals_out, interloss = self.model(batch)
+        loss = interloss + self.cls_loss(emos_out, emos) + self.reg_loss(vals_out, vals)
+        return loss, emos_out, vals_out
+
+    def _capture(self, shapes, train):
+        """shapes: {'audios': (B, ...), 'texts': ..., 'videos': ...} — utterance-level [B, D] or frame-level [B, T, D] inputs."""
         dev = self.flat.device
-        st = dict(audios=torch.zeros(B, dims[0], device=dev), texts=torch.zeros(B, dims[1], device=dev),
-                  videos=torch.zeros(B, dims[2], device=dev), emos=torch.zeros(B, dtype=torch.int64, device=dev),
-                  vals=torch.zeros(B, device=dev))
+        B = shapes["audios"][0]
+        st = {k: torch.zeros(shapes[k], device=dev) for k in ("audios", "texts", "videos")}
+        st["emos"] = torch.zeros(B, dtype=torch.int64, device=dev)
+        st["vals"] = torch.zeros(B, device=dev)
+        body = self._step_body if train else self._eval_body
+        self.model.train() if train else self.model.eval()
         # warm up on a side stream (torch's capture protocol), restoring parameters/optimiser state afterwards
         snap = (self.flat.clone(), self.opt.m.clone(), self.opt.v.clone(), self.opt.step_dev.clone())
+        rng = torch.cuda.get_rng_state(dev)
+
+        def restore():
+            self.flat.copy_(snap[0]); self.opt.m.copy_(snap[1]); self.opt.v.copy_(snap[2]); self.opt.step_dev.copy_(snap[3])
+
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self._step_body({k: st[k] for k in ("audios", "texts", "videos")}, st["emos"], st["vals"])
+                body({k: st[k] for k in ("audios", "texts", "videos")}, st["emos"], st["vals"])
         torch.cuda.current_stream().wait_stream(s)
-        self.flat.copy_(snap[0]); self.opt.m.copy_(snap[1]); self.opt.v.copy_(snap[2]); self.opt.step_dev.copy_(snap[3])
+        restore()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self._step_body({k: st[k] for k in ("audios", "texts", "videos")}, st["emos"], st["vals"])
-        self.flat.copy_(snap[0]); self.opt.m.copy_(snap[1]); self.opt.v.copy_(snap[2]); self.opt.step_dev.copy_(snap[3])
+            out = body({k: st[k] for k in ("audios", "texts", "videos")}, st["emos"], st["vals"])
+        restore()
+        torch.cuda.set_rng_state(rng, dev)   # the warm-up's dropout draws must not shift the caller's random stream
         return g, st, out
 
-    def train_step(self, batch, emos, vals):
-        self.model.train()
-        if not self.use_graph:
-            return self._step_body(batch, emos, vals)
-        B = batch["audios"].shape[0]
-        key = (B, batch["audios"].shape[1], batch["texts"].shape[1], batch["videos"].shape[1])
+    def _replay(self, batch, emos, vals, train):
+        key = (train,) + tuple(tuple(batch[k].shape) for k in ("audios", "texts", "videos"))
         if key not in self._graphs:
-            self._graphs[key] = self._capture(B, key[1:])
+            self._graphs[key] = self._capture({k: tuple(batch[k].shape) for k in ("audios", "texts", "videos")}, train)
         g, st, out = self._graphs[key]
         for k in ("audios", "texts", "videos"):
-            st[k].copy_(batch[k], non_blocking=True)
+            st[k].copy_(batch[k], non_blocking=True)     # host (pinned) or device source
         st["emos"].copy_(emos, non_blocking=True)
         st["vals"].copy_(vals, non_blocking=True)
+        self.model.train() if train else self.model.eval()
         g.replay()
         return out
 
-    @torch.no_grad()
-    def eval_step(self, batch):
+    def train_step(self, batch, emos, vals):
+        """One optimiser step.  Returns (loss, emos_out, vals_out): with use_graph these are the graph's STATIC output buffers —
+        copy what you keep before the next step."""
+        self.model.train()
+        if not self.use_graph:
+            dev = self.flat.device
+            return self._step_body({k: v.to(dev, non_blocking=True) for k, v in batch.items()}, emos.to(dev, non_blocking=True),
+                                   vals.to(dev, non_blocking=True))
+        return self._replay(batch, emos, vals, True)
+
+    def eval_step(self, batch, emos=None, vals=None):
+        """Forward (+ losses when labels are given) without touching parameters; graph-replayed like train_step."""
         self.model.eval()
-        return self.model(batch)
+        if emos is None:
+            with torch.no_grad():
+                return self.model(batch)
+        if not self.use_graph:
+            dev = self.flat.device
+            return self._eval_body({k: v.to(dev, non_blocking=True) for k, v in batch.items()}, emos.to(dev, non_blocking=True),
+                                   vals.to(dev, non_blocking=True))
+        return self._replay(batch, emos, vals, False)

@@ -58,6 +58,54 @@ m2 = get_models(args).to(dev).train()
 tr = FusionGraphTrainer(m2, lr=1e-3, weight_decay=1e-5)
 res["hip_graph_replay"] = timed(lambda: tr.train_step(batch, emos, vals), steps=2000)
 
+# (e) / (f): the same model driven through main_release's two epoch loops over a DataLoader of pinned host minibatches —
+# the reference's loop (train_or_eval_model: 3-5 host round trips per minibatch) and the graph loop (train_or_eval_graph)
+from mertools_amd import main_release as MR  # noqa: E402
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, n):
+        g = torch.Generator().manual_seed(1)
+        self.a, self.t, self.v = torch.randn(n, 768, generator=g), torch.randn(n, 768, generator=g), torch.randn(n, 512, generator=g)
+        self.e, self.val = torch.randint(0, 6, (n,), generator=g), torch.randn(n, generator=g)
+
+    def __len__(self):
+        return len(self.e)
+
+    def __getitem__(self, i):
+        return i
+
+    def collater(self, idx):
+        idx = torch.tensor(idx)
+        return dict(audios=self.a[idx], texts=self.t[idx], videos=self.v[idx]), self.e[idx], self.val[idx], [f"c{int(i)}" for i in idx]
+
+
+class _Results:
+    @staticmethod
+    def calculate_results(emo_probs=[], emo_labels=[], val_preds=[], val_labels=[]):
+        return {}, ""
+
+
+ds = _DS(32 * 200)
+loader = torch.utils.data.DataLoader(ds, batch_size=32, collate_fn=ds.collater, pin_memory=True)
+margs = argparse.Namespace(output_dim1=6, output_dim2=1, print_iters=1e8)
+m3 = get_models(args).to(dev)
+opt3 = torch.optim.Adam(m3.parameters(), lr=1e-3, weight_decay=1e-5)
+MR.train_or_eval_model(margs, m3, MSELoss(), CELoss(), loader, 0, opt3, True, dataloader_class=_Results)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+MR.train_or_eval_model(margs, m3, MSELoss(), CELoss(), loader, 0, opt3, True, dataloader_class=_Results)
+torch.cuda.synchronize()
+res["main_release_eager_epoch"] = len(loader) / (time.perf_counter() - t0)
+m4 = get_models(args).to(dev)
+tr4 = FusionGraphTrainer(m4, lr=1e-3, weight_decay=1e-5)
+MR.train_or_eval_graph(margs, tr4, loader, 0, True, dataloader_class=_Results)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+MR.train_or_eval_graph(margs, tr4, loader, 0, True, dataloader_class=_Results)
+torch.cuda.synchronize()
+res["main_release_graph_epoch"] = len(loader) / (time.perf_counter() - t0)
+
 # CPU oracle of the reference arithmetic (plain torch modules on the host cores)
 from oracle import fusion_ref as FR  # noqa: E402  (baseline leg only)
 torch.set_num_threads(min(os.cpu_count() or 1, 8))

@@ -189,7 +189,7 @@ def test_visual_extract_device_resize_equals_host_path(dev, tmp_path):
     from mertools_amd.encoders import HipCLIPModel
     from mertools_amd.extract import visual
     cfg = W.clip_config("tiny")
-    model = HipCLIPModel(W.clip_state_dict(cfg, 3), cfg, device=dev)
+    model = HipCLIPModel(W.clip_state_dict(cfg, 3), cfg, device=dev, precision="accurate")
     rng = np.random.RandomState(0)
     face = tmp_path / "faces"
     vids = []
@@ -200,6 +200,9 @@ def test_visual_extract_device_resize_equals_host_path(dev, tmp_path):
         vids.append(vid)
     visual.extract(model, str(face), str(tmp_path / "host"), "FRAME", vids=vids)
     visual.extract(model, str(face), str(tmp_path / "dev"), "FRAME", vids=vids, device_preprocess="resize", workers=2)
-    for v in vids:   # identical bytes enter the normalisation; the GPU's fused multiply-add there differs from numpy by <= 1 ulp
+    # identical bytes enter the normalisation (test_ops_gpu's resize tests compare them with Pillow byte for byte); the GPU's fused
+    # multiply-add there differs from numpy by <= 1 ulp, and such 1e-7 input differences flip 16-bit roundings inside the encoder
+    # (measured on the MI355X: 4e-4 with the 2-pass preset, hence the 3-pass model and the sibling test's 2e-4 here)
+    for v in vids:
         a, b = np.load(tmp_path / "host" / f"{v}.npy"), np.load(tmp_path / "dev" / f"{v}.npy")
-        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * np.abs(a).max(), v
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-4 * np.abs(a).max(), v

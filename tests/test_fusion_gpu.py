@@ -264,3 +264,47 @@ def test_main_release_end_to_end_on_synthetic_features(dev, tmp_path, feat_type)
                 assert np.array_equal(a[k], b[k]), f"{feat_type}: {k} differs between two seeded runs"
     saved = os.listdir(tmp_path / f"saved-{feat_type}-trimodal" / "result")
     assert sum(f.startswith("cv_") for f in saved) == 2 and sum(f.startswith("test1_") for f in saved) == 2
+
+
+def test_main_release_graph_loop_equals_eager_loop(dev, tmp_path):
+    """main_release's default loop (one captured HIP graph per minibatch, per-epoch result copies: train_or_eval_graph) against
+    --eager --hip_adam (the reference's loop, main-release.py:17-87, with its per-step host syncs): same folds, same epochs,
+    same stored probabilities / predictions (to fp32 rounding of the Adam bias correction) and the same result-file names."""
+    from mertools_amd import main_release
+    root = tmp_path / "data" / "mer2023-dataset-process"
+    rng = np.random.RandomState(1)
+    names = {"train": [f"tr_{i:03d}" for i in range(50)], "test1": [f"t1_{i:02d}" for i in range(9)],
+             "test2": [f"t2_{i:02d}" for i in range(7)], "test3": [f"t3_{i:02d}" for i in range(5)]}
+    emos = ['neutral', 'angry', 'happy', 'sad', 'worried', 'surprise']
+    corp = {}
+    for split, ns in names.items():
+        corp[f"{split}_corpus"] = {n: {"emo": emos[rng.randint(6)], "val": float(rng.uniform(-3, 3))} for n in ns}
+        if split == "test3":
+            for n in ns:
+                del corp[f"{split}_corpus"][n]["val"]
+    os.makedirs(root / "features", exist_ok=True)
+    np.savez_compressed(root / "label-6way.npz", **{k: np.array(v, dtype=object) for k, v in corp.items()})
+    for feat, d in {"audio-UTT": 24, "text-UTT": 16, "video-UTT": 20}.items():
+        os.makedirs(root / "features" / feat, exist_ok=True)
+        for ns in names.values():
+            for n in ns:
+                np.save(root / "features" / feat / f"{n}.npy", rng.randn(d).astype(np.float32))
+    hyper = tmp_path / "tune.yaml"
+    hyper.write_text("attention:\n  hidden_dim: 64\n  dropout: 0.0\n  grad_clip: 1.0\n  lr: 1.0e-3\n")   # (dropout draws come from different RNG paths in the two loops)
+    base = ["--model", "attention", "--feat_type", "utt", "--dataset", "MER2023", "--audio_feature", "audio-UTT", "--text_feature", "text-UTT",
+            "--video_feature", "video-UTT", "--epochs", "3", "--batch_size", "16", "--gpu", "0", "--seed", "3", "--data_root", str(tmp_path / "data"),
+            "--hyper_path", str(hyper)]
+    res_g = main_release.main(base + ["--save_root", str(tmp_path / "graph")])
+    res_e = main_release.main(base + ["--save_root", str(tmp_path / "eager"), "--eager", "--hip_adam"])
+    assert len(res_g) == len(res_e) == 5
+    for a, b in zip(res_g, res_e):
+        assert set(a) == set(b)
+        for k in a:
+            if isinstance(a[k], np.ndarray) and a[k].dtype.kind == "f":
+                assert a[k].shape == b[k].shape and np.allclose(a[k], b[k], rtol=2e-4, atol=2e-5), k
+            elif isinstance(a[k], list):
+                assert a[k] == b[k], k     # clip names: same order
+    strip = lambda f: f.rsplit("_", 1)[0]   # noqa: E731  (drop the time stamp)
+    fg = sorted(strip(f) for f in os.listdir(tmp_path / "graph-trimodal" / "result"))
+    fe = sorted(strip(f) for f in os.listdir(tmp_path / "eager-trimodal" / "result"))
+    assert fg == fe, (fg, fe)
