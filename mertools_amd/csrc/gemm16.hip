@@ -8,6 +8,7 @@ int g_gemm_stamp = 0;
 int g_gemm_persist = 0;   // mer_set_option("gemm_persist", 1): persistent-tile variant of the 8-wave non-MX kernels
 int g_gemm_glds = 1;
 int g_gemm_pkepi = 1;     // mer_set_option("gemm_pkepi", 0): 16-bit-only outputs take the generic fp32-staged epilogue (A/B testing)
+int g_gemm_stagger = 0;   // mer_set_option("gemm_stagger", R): phase-spread the CUs of 256x256 launches with >= R rounds of tiles (0 = off)
 int g_gemm_wblk = 1;      // mer_set_option("gemm_wblk", 0): ignore pre-blocked weight planes (A/B testing)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
@@ -32,6 +33,7 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
   if (name && strcmp(name, "gemm_wblk") == 0) { mer::g_gemm_wblk = value; return MER_OK; }
   if (name && strcmp(name, "gemm_pkepi") == 0) { mer::g_gemm_pkepi = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_stagger") == 0) { mer::g_gemm_stagger = value; return MER_OK; }
   if (name && strcmp(name, "tf_ablk") == 0) { mer::g_tf_ablk = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");

@@ -48,6 +48,7 @@ struct Gemm16Params {
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
+  int stagger_blocks; unsigned stagger_cycles;   // > 0: the first stagger_blocks workgroups (one per CU) start up to stagger_cycles late, see the kernel
   int pk_epi;     // 16-bit-only outputs: activation on the accumulators, row pairs packed before the LDS transposition (half the LDS traffic)
   int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
   int hm_T, hm_H;  // > 0: 16-bit output scattered head-major [N/(64*hm_H)][M/hm_T][hm_H][hm_T][64] (QKV for attention)
@@ -146,6 +147,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x;
+  // Phase spreading.  Every tile of a launch costs the same time, so the CUs run in lockstep: all 256 finish their K loops
+  // together, all store their C tiles together — an HBM-write-bound burst (33 MB per round at ~5.8 TB/s) during which no CU
+  // computes — and then all sit in their K loops while the memory system idles (measured: the global stores alone are 22-24 %
+  // of the K = 768 GEMMs, profiles/r02_gemm16_bench_epilogue_split.txt).  The first workgroup of every CU therefore starts a
+  // different fraction of a tile time late (CU c of its XCD: c / 32 of stagger_cycles); from then on each CU's store phase
+  // falls into other CUs' K loops for the rest of the launch (workgroups are dispatched as CUs free up, so the offsets persist).
+  if (p.stagger_cycles && blockIdx.y == 0 && (int)blockIdx.x < p.stagger_blocks) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)((blockIdx.x >> 3) & 31) * (p.stagger_cycles >> 5);
+    while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(16);
+  }
   if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memtime();
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -761,7 +772,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_stagger;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>
@@ -770,6 +781,23 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   p.tiles_m = (int)cdiv(p.M, BM);
   p.tiles_n = (int)cdiv(p.N, BN);
   dim3 grid(p.tiles_m * p.tiles_n, nbatch, 1), block(WM * WN * 64, 1, 1);
+  p.stagger_blocks = 0;
+  p.stagger_cycles = 0;
+  if constexpr (WM * WN == 8) {   // 256x256 tiles, one workgroup per CU
+    static int ncu_s = 0;
+    if (!ncu_s) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu_s, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu_s <= 0) ncu_s = 256;
+    }
+    const long long nblk = (long long)p.tiles_m * p.tiles_n;
+    // worth it from ~4 rounds of tiles on: the spread costs up to one tile time at the end of the launch
+    if (g_gemm_stagger > 0 && nbatch == 1 && nblk >= (long long)g_gemm_stagger * ncu_s) {
+      const long long nk = (p.K + BK - 1) / BK;
+      const long long per_slab = MX ? 2700 : (AP == 2 ? 3600 : (WP == 2 ? 2400 : 1500));   // measured K-loop cycles per 32-deep slab
+      p.stagger_blocks = ncu_s;
+      p.stagger_cycles = (unsigned)(nk * per_slab + 20000);                                // + prologue and epilogue
+    }
+  }
   // algorithmic work of this launch: 2*M*N*K flops (one pass, whatever AP/WP execute), A + W read once,
   // outputs (+ residual) touched once
   const double mn = (double)p.M * p.N * nbatch;

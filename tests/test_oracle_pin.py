@@ -328,3 +328,19 @@ def test_pil_restatement_random_sweep():
         for f, res in (("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)):
             ref = np.asarray(Image.fromarray(img).resize((nw, nh), resample=res))
             assert np.array_equal(pil_resize_u8(img, nw, nh, f), ref), (h, w, nh, nw, f)
+
+
+def test_oracle_matches_live_hf_at_base_size():
+    """The oracle restatement against the live HF classes at the FULL base architectures of BASELINE.json (HuBERT-base 5 s,
+    CLIP-B/16 8 frames, RoBERTa-base 64 tokens) — the same modules bench.py's cpu_baseline leg times (oracle/hf_live.py)."""
+    pytest.importorskip("transformers")
+    from oracle import hf_live as H
+    hub, clip, rob = H.build_base_trio(W)
+    wav, px, ids = W.synth_audio(1), W.synth_frames(8), W.synth_tokens(1)
+    hc, cc, bc = W.hubert_config("base"), W.clip_config("base16"), W.bert_config("roberta-base")
+    ra = torch.stack(R.hubert_hidden_states(W.hubert_state_dict(hc, 0), vars(hc), wav))[[-4, -3, -2, -1]].sum(0).mean(1)
+    rv = R.clip_image_features(W.clip_state_dict(cc, 0), dict(vars(cc.vision_config), projection_dim=cc.projection_dim), px).mean(0, keepdim=True)
+    rt = torch.stack(R.bert_hidden_states(W.bert_state_dict(bc, 0), dict(vars(bc), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
+    assert rel_err(ra, H.audio_utt(hub, wav))[0] < 2e-6
+    assert rel_err(rv, H.visual_utt(clip, px))[0] < 2e-6
+    assert rel_err(rt, H.text_utt(rob, ids))[0] < 2e-6
