@@ -11,34 +11,34 @@ PROBE = '今天天气真好'
 
 
 def find_start_end_pos(tokenizer):
-    """How many leading (0..2) / trailing (0..2) special tokens to strip (reference :90-114; integer path)."""
-    input_ids = tokenizer(PROBE, return_tensors='pt')['input_ids'][0]
-    start, end = None, None
-    for start in range(0, 3, 1):
-        outputs = tokenizer.decode(input_ids[start:]).replace(' ', '')
-        if outputs == PROBE:
-            print(f'start: {start};  end: {end}')
-            return start, None
-        if outputs.startswith(PROBE):
-            break
-    for end in range(-1, -3, -1):
-        outputs = tokenizer.decode(input_ids[start:end]).replace(' ', '')
-        if outputs == PROBE:
-            break
-    assert tokenizer.decode(input_ids[start:end]).replace(' ', '') == PROBE
+    """(start, end) slice that strips the tokenizer's leading (0..2) / trailing (0..2) special tokens, found by decoding a probe
+    sentence (behaviour of reference :90-114, bit-exact against it in tests/test_host_logic.py; integer path).  start = the
+    first offset whose decoded tail begins with the probe (2 when none does); end = None when that tail IS the probe, else
+    the first of -1, -2 that makes it so."""
+    ids = tokenizer(PROBE, return_tensors='pt')['input_ids'][0]
+
+    def text(a, b):
+        return tokenizer.decode(ids[a:b]).replace(' ', '')
+
+    start = next((s for s in range(3) if text(s, None).startswith(PROBE)), 2)
+    end = None
+    if text(start, None) != PROBE:
+        end = next((e for e in (-1, -2) if text(start, e) == PROBE), None)
+        assert end is not None, f'cannot isolate the probe sentence from {tokenizer.decode(ids)!r}'
     print(f'start: {start};  end: {end}')
     return start, end
 
 
 def find_batchpos_embdim(tokenizer, model, gpu=-1):
-    """(batch axis, feature dim) via a probe sentence (reference :118-135).  HIP encoders are batch-first."""
-    inputs = tokenizer(PROBE, return_tensors='pt')
-    outputs = model(**inputs, output_hidden_states=True).hidden_states
-    outputs = torch.stack(outputs)[[-1]].sum(dim=0).cpu().numpy()
-    batch_pos = 0 if outputs.shape[0] == 1 else (1 if outputs.shape[1] == 1 else None)
-    assert batch_pos in [0, 1]
-    print(f'batch_pos:{batch_pos}, feature_dim:{outputs.shape[2]}')
-    return batch_pos, outputs.shape[2]
+    """(batch axis, feature dim) of `model`'s hidden states, probed with one sentence (reference :118-135: some of its LLMs are
+    sequence-first).  The HIP encoders are batch-first."""
+    probe = tokenizer(PROBE, return_tensors='pt')
+    last = model(**probe, output_hidden_states=True).hidden_states[-1]
+    shape = tuple(last.shape)
+    assert 1 in shape[:2], shape
+    batch_pos = 0 if shape[0] == 1 else 1
+    print(f'batch_pos:{batch_pos}, feature_dim:{shape[2]}')
+    return batch_pos, shape[2]
 
 
 def save_embeddings(csv_file, embeddings, feature_level, feature_dim):

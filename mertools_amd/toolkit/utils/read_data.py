@@ -1,6 +1,15 @@
-""".npy feature readers and utterance/frame alignment — mirror of MERBench/toolkit/utils/read_data.py:15-125.
-This is the on-disk contract between the extractors and the trainer: shapes, dtypes,
-padding side and pooling windows are reproduced exactly; values are numpy float arithmetic on the host."""
+"""Per-clip feature files -> model-ready arrays: the on-disk contract between the extractors and the fusion trainer
+(SURVEY.md §8 a16).  Behaviour follows MERBench/toolkit/utils/read_data.py:15-125 — shapes, dtypes (float64 as soon as
+padding zeros are involved), FRONT padding, ceil-sized mean-pooling windows — and is checked bit for bit against vectors
+produced by the reference's own functions (tests/golden/index_paths.npz); the code is organised around two primitives:
+
+    load_rows(root, name)   one clip's [T, D] array from `<name>.npy` or a directory of per-face files
+    fit_length(rows, n)     [T, D] -> [n, D]: zeros in front when short, mean over ceil(T / n)-row windows when long
+
+and `regroup()`, which expresses every alignment mode of the reference (utterance pooling, feat_scale compression,
+align-to-text, pad-to-longest) as a choice of target lengths per clip and modality.  The reference's function names are kept
+as aliases at the bottom because MERBench's `feat_data.py` / user scripts import them.
+"""
 import math
 import multiprocessing
 import os
@@ -8,85 +17,107 @@ import os
 import numpy as np
 
 
-def func_read_one_feat(argv=None, feature_root=None, name=None, processor=None, model_name=None):
-    feature_root, name, processor, model_name = argv
-    feature_path = os.path.join(feature_root, name + '.npy')
-    feature_dir = os.path.join(feature_root, name)
-    feature = []
-    if os.path.exists(feature_path):
-        feature.append(np.load(feature_path).squeeze())  # [D] or [T, D]
-    elif os.path.isdir(feature_dir):
-        for facename in sorted(os.listdir(feature_dir)):
-            feature.append(np.load(os.path.join(feature_dir, facename)))
+def load_rows(root, name):
+    """[T, D] features of clip `name` under `root` (reference :15-41: `<name>.npy`, else every file of directory `<name>` in
+    sorted order; a 1-D utterance vector becomes one row)."""
+    single = os.path.join(root, name + '.npy')
+    folder = os.path.join(root, name)
+    if os.path.exists(single):
+        parts = [np.load(single).squeeze()]
+    elif os.path.isdir(folder):
+        parts = [np.load(os.path.join(folder, f)) for f in sorted(os.listdir(folder))]
     else:
         raise Exception('feature path or dir do not exist!')
-    single_feature = np.array(feature).squeeze()
-    if len(single_feature) == 0:
+    rows = np.array(parts).squeeze()
+    if len(rows) == 0:
         print('feature has errors!!')
-    elif len(single_feature.shape) == 1:
-        single_feature = single_feature[np.newaxis, :]
-    return single_feature
+        return rows
+    return rows[np.newaxis, :] if rows.ndim == 1 else rows
+
+
+def _load_rows_packed(job):
+    return load_rows(*job)
+
+
+def load_all(root, names, processes=8):
+    """([T_i, D] per clip, D).  Large corpora are read by a process pool (the reference's Pool(8), :44-68)."""
+    jobs = [(root, name) for name in names]
+    if processes and processes > 1 and len(jobs) > 64:
+        with multiprocessing.Pool(processes=processes) as pool:
+            clips = list(pool.imap(_load_rows_packed, jobs))
+    else:
+        clips = [load_rows(*j) for j in jobs]
+    assert len(clips) == len(names), 'Error: len(names) != len(features)'
+    shape = np.array(clips[0]).shape
+    print(f'Input feature {os.path.basename(root)} ===> dim is {shape}')
+    return clips, shape[-1]
+
+
+def fit_length(rows, n):
+    """[T, D] -> [n, D] (reference :72-89).  T == n: the array itself.  Otherwise zeros are put in FRONT until the length is
+    n * w with w = ceil(T / n) (w = 1 when T < n) and every w consecutive rows are averaged — float64, because the padding
+    zeros are."""
+    t, d = rows.shape
+    if t == n:
+        return rows
+    w = 1 if t < n else -(-t // n)
+    padded = np.concatenate([np.zeros((n * w - t, d)), rows])
+    return padded if w == 1 else padded.reshape(n, w, d).mean(axis=1)
+
+
+def regroup(audios, texts, videos, mode, scale=1):
+    """The reference's alignment pipeline (feat_data.py:30-44 over read_data.py:92-125) for three per-clip lists, in place:
+         'compress'     every stream to ceil(T / scale) rows                                   (feature_scale_compress)
+         'utt'          every stream to its mean row [D]                                       (align_to_utt)
+         'text'         audio and video to the clip's text length                              (align_to_text)
+         'longest'      every stream to the longest clip of its own modality                   (pad_to_maxlen_pre_modality)"""
+    streams = (audios, texts, videos)
+    if mode == 'utt':
+        for s in streams:
+            for i, rows in enumerate(s):
+                s[i] = np.mean(rows, axis=0)
+        return audios, texts, videos
+    if mode == 'compress':
+        target = lambda s, i: math.ceil(len(s[i]) / scale)           # noqa: E731
+    elif mode == 'text':
+        lens = [len(t) for t in texts]
+        target = lambda s, i: lens[i]                                # noqa: E731
+    elif mode == 'longest':
+        longest = {id(s): max(len(r) for r in s) for s in streams}
+        target = lambda s, i: longest[id(s)]                         # noqa: E731
+    else:
+        raise ValueError(mode)
+    for i in range(len(audios)):
+        for s in streams:
+            s[i] = fit_length(s[i], target(s, i))
+    return audios, texts, videos
+
+
+# ---- the reference's names (MERBench/toolkit/utils/read_data.py) --------------------------------------------------------
+func_mapping_feature = fit_length
+
+
+def func_read_one_feat(argv=None, feature_root=None, name=None, processor=None, model_name=None):
+    root, name = argv[0], argv[1]
+    return load_rows(root, name)
 
 
 def func_read_multiprocess(feature_root, names, processor=None, read_type='feat', model_name=None, processes=8):
-    params = [(feature_root, name, processor, model_name) for name in names]
-    features = []
-    if read_type == 'feat':
-        if processes and processes > 1 and len(params) > 64:
-            with multiprocessing.Pool(processes=processes) as pool:
-                features = list(pool.imap(func_read_one_feat, params))
-        else:
-            features = [func_read_one_feat(p) for p in params]
-    feature_shape = np.array(features[0]).shape
-    print(f'Input feature {os.path.basename(feature_root)} ===> dim is {feature_shape}')
-    assert len(names) == len(features), 'Error: len(names) != len(features)'
-    return features, feature_shape[-1]
-
-
-def func_mapping_feature(feature, dst_len):
-    """(seqlen, D) -> (dst_len, D): zero-pad in FRONT when short; mean-pool ceil windows (front-padded) when long."""
-    featlen, featdim = feature.shape
-    if featlen == dst_len:
-        return feature
-    if featlen < dst_len:
-        return np.concatenate((np.zeros((dst_len - featlen, featdim)), feature), axis=0)
-    if featlen // dst_len == featlen / dst_len:
-        pad_len, pool_size = 0, featlen // dst_len
-    else:
-        pad_len, pool_size = dst_len - featlen % dst_len, featlen // dst_len + 1
-    feature = np.concatenate([np.zeros((pad_len, featdim)), feature]).reshape(dst_len, pool_size, featdim)
-    return np.mean(feature, axis=1)
+    assert read_type == 'feat', 'only pre-extracted features are on the hot path (SURVEY.md §2: e2e readers are out of scope)'
+    return load_all(feature_root, names, processes)
 
 
 def align_to_utt(audios, texts, videos):
-    for ii in range(len(audios)):
-        audios[ii] = np.mean(audios[ii], axis=0)
-        texts[ii] = np.mean(texts[ii], axis=0)
-        videos[ii] = np.mean(videos[ii], axis=0)
-    return audios, texts, videos
+    return regroup(audios, texts, videos, 'utt')
 
 
 def feature_scale_compress(audios, texts, videos, scale_factor=1):
-    for ii in range(len(audios)):
-        audios[ii] = func_mapping_feature(audios[ii], math.ceil(len(audios[ii]) / scale_factor))
-        texts[ii] = func_mapping_feature(texts[ii], math.ceil(len(texts[ii]) / scale_factor))
-        videos[ii] = func_mapping_feature(videos[ii], math.ceil(len(videos[ii]) / scale_factor))
-    return audios, texts, videos
+    return regroup(audios, texts, videos, 'compress', scale_factor)
 
 
 def align_to_text(audios, texts, videos):
-    for ii in range(len(audios)):
-        dst_len = len(texts[ii])
-        audios[ii] = func_mapping_feature(audios[ii], dst_len)
-        texts[ii] = func_mapping_feature(texts[ii], dst_len)
-        videos[ii] = func_mapping_feature(videos[ii], dst_len)
-    return audios, texts, videos
+    return regroup(audios, texts, videos, 'text')
 
 
 def pad_to_maxlen_pre_modality(audios, texts, videos):
-    amax, tmax, vmax = max(len(f) for f in audios), max(len(f) for f in texts), max(len(f) for f in videos)
-    for ii in range(len(audios)):
-        audios[ii] = func_mapping_feature(audios[ii], amax)
-        texts[ii] = func_mapping_feature(texts[ii], tmax)
-        videos[ii] = func_mapping_feature(videos[ii], vmax)
-    return audios, texts, videos
+    return regroup(audios, texts, videos, 'longest')

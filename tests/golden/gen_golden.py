@@ -121,6 +121,41 @@ def fusion_goldens():
                         **{f"att_{k}": v.numpy() for k, v in att.state_dict().items()})
 
 
+def fusion_frame_goldens():
+    """The reference's own frame-level model — toolkit.models.attention.Attention with feat_type='frm_align', i.e. three
+    LSTMEncoder branches (modules/encoder.py:45-72) — forward, one full backward and 3 Adam steps on seeded [B, T, D] inputs."""
+    ref_toolkit()
+    from toolkit.models.attention import Attention
+    from toolkit.utils.loss import CELoss, MSELoss
+    args = argparse.Namespace(text_dim=40, audio_dim=48, video_dim=32, output_dim1=6, output_dim2=1, dropout=0.0,
+                              hidden_dim=64, grad_clip=-1.0, feat_type="frm_align")
+    torch.manual_seed(4321)
+    model = Attention(args)
+    init = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    B, T, steps = 6, 9, 3
+    xs = dict(audios=torch.randn(steps, B, T, 48), texts=torch.randn(steps, B, T, 40), videos=torch.randn(steps, B, T, 32))
+    emos, vals = torch.randint(0, 6, (steps, B)), torch.randn(steps, B) * 2
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    cls_loss, reg_loss = CELoss(), MSELoss()
+    losses, grads0, out0 = [], None, None
+    for s in range(steps):
+        opt.zero_grad()
+        f, e, v, il = model({k: x[s] for k, x in xs.items()})
+        loss = il + cls_loss(e, emos[s]) + reg_loss(v, vals[s])
+        loss.backward()
+        if s == 0:
+            grads0 = {k: p.grad.clone().numpy() for k, p in model.named_parameters()}
+            out0 = dict(features=f.detach().numpy().copy(), emos_out=e.detach().numpy().copy(), vals_out=v.detach().numpy().copy())
+        opt.step()
+        losses.append(loss.item())
+    final = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "fusion_attention_frm_align.npz"), losses=np.array(losses, dtype=np.float64),
+                        emos=emos.numpy(), vals=vals.numpy(), **{f"x_{k}": v.numpy() for k, v in xs.items()},
+                        **{f"out_{k}": v for k, v in out0.items()}, **{f"init_{k}": v for k, v in init.items()},
+                        **{f"final_{k}": v for k, v in final.items()}, **{f"grad0_{k}": v for k, v in grads0.items()})
+
+
 def index_goldens():
     ref_toolkit()
     import math
@@ -227,5 +262,6 @@ def hf_goldens():
 if __name__ == "__main__":
     hf_goldens()
     fusion_goldens()
+    fusion_frame_goldens()
     index_goldens()
     print("wrote:", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

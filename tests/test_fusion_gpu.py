@@ -165,65 +165,43 @@ def test_lstm_last_matches_torch_lstm(dev, B, T, D, H):
         assert_close(getattr(dev_rnn, name).grad.cpu(), getattr(ref, name).grad, 2e-4, f"lstm d{name}")
 
 
-def test_attention_model_frame_level_matches_reference_modules(dev):
-    """toolkit.models.Attention with feat_type='frm_align' (LSTMEncoder x3) against the same wiring built from torch modules on
-    the CPU (the reference's attention.py:22-57 / encoder.py:45-72), same parameters: outputs and a full backward."""
-    import torch.nn as nn
+def test_attention_model_frame_level_matches_reference(dev):
+    """toolkit.models.Attention with feat_type='frm_align' (LSTMEncoder x3 on mer_lstm_fwd / mer_lstm_bwd) against vectors made by
+    RUNNING the reference's own Attention(feat_type='frm_align') / LSTMEncoder (attention.py:22-57, modules/encoder.py:45-72;
+    tests/golden/gen_golden.py:fusion_frame_goldens): first-step outputs and every gradient, then 3 Adam steps."""
     from types import SimpleNamespace
     from mertools_amd.toolkit.models import get_models
+    from mertools_amd.toolkit.utils.loss import CELoss, MSELoss
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fusion_attention_frm_align.npz"))
     args = SimpleNamespace(model="attention", feat_type="frm_align", audio_dim=48, text_dim=40, video_dim=32, output_dim1=6, output_dim2=1,
                            dropout=0.0, hidden_dim=64, grad_clip=-1.0)
-    torch.manual_seed(1)
     model = get_models(args)
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    keys = sorted(k[len("init_"):] for k in g.files if k.startswith("init_"))
+    assert sorted(k[len("model."):] for k in model.state_dict()) == keys          # same parameter names as the reference module
+    model.load_state_dict({"model." + k: torch.from_numpy(g["init_" + k]) for k in keys})
     model = model.to(dev).train()
-    B, T = 6, 9
-    batch = {"audios": torch.randn(B, T, 48), "texts": torch.randn(B, T, 40), "videos": torch.randn(B, T, 32)}
-    feats, emos, vals, inter = model({k: v.to(dev) for k, v in batch.items()})
-    (emos.square().sum() + vals.sum()).backward()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    cls_loss, reg_loss = CELoss(), MSELoss()
+    xs = {k: torch.from_numpy(g["x_" + k]).to(dev) for k in ("audios", "texts", "videos")}
+    emos, vals = torch.from_numpy(g["emos"]).to(dev), torch.from_numpy(g["vals"]).to(dev)
+    losses = []
+    for s in range(emos.shape[0]):
+        opt.zero_grad()
+        f, e, v, il = model({k: x[s] for k, x in xs.items()})
+        loss = il + cls_loss(e, emos[s]) + reg_loss(v, vals[s])
+        loss.backward()
+        if s == 0:
+            assert_close(f.detach().cpu(), torch.from_numpy(g["out_features"]), 2e-5, "frame-level fused features")
+            assert_close(e.detach().cpu(), torch.from_numpy(g["out_emos_out"]), 2e-5, "frame-level emos_out")
+            assert_close(v.detach().cpu(), torch.from_numpy(g["out_vals_out"]), 2e-5, "frame-level vals_out")
+            for k, p in model.named_parameters():
+                assert_close(p.grad.cpu(), torch.from_numpy(g["grad0_" + k[len("model."):]]), 5e-4, f"grad {k}")
+        opt.step()
+        losses.append(loss.item())
     torch.cuda.synchronize()
-
-    class RefLSTMEnc(nn.Module):               # encoder.py:45-72
-        def __init__(self, d, h):
-            super().__init__()
-            self.rnn = nn.LSTM(d, h, num_layers=1, batch_first=True)
-            self.linear_1 = nn.Linear(h, h)
-
-        def forward(self, x):
-            return self.linear_1(self.rnn(x)[1][0].squeeze(0))
-
-    class RefMLP(nn.Module):                   # encoder.py:9-41 (dropout 0)
-        def __init__(self, d, h):
-            super().__init__()
-            self.linear_1, self.linear_2, self.linear_3 = nn.Linear(d, h), nn.Linear(h, h), nn.Linear(h, h)
-
-        def forward(self, x):
-            return torch.relu(self.linear_3(torch.relu(self.linear_2(torch.relu(self.linear_1(x))))))
-
-    class RefAttention(nn.Module):             # attention.py:22-57
-        def __init__(self):
-            super().__init__()
-            self.audio_encoder, self.text_encoder, self.video_encoder = RefLSTMEnc(48, 64), RefLSTMEnc(40, 64), RefLSTMEnc(32, 64)
-            self.attention_mlp = RefMLP(192, 64)
-            self.fc_att, self.fc_out_1, self.fc_out_2 = nn.Linear(64, 3), nn.Linear(64, 6), nn.Linear(64, 1)
-
-        def forward(self, b):
-            hs = [self.audio_encoder(b["audios"]), self.text_encoder(b["texts"]), self.video_encoder(b["videos"])]
-            att = self.fc_att(self.attention_mlp(torch.cat(hs, dim=1))).unsqueeze(2)
-            fused = torch.matmul(torch.stack(hs, dim=2), att).squeeze(2)
-            return fused, self.fc_out_1(fused), self.fc_out_2(fused)
-
-    ref = RefAttention()
-    missing, unexpected = ref.load_state_dict({k.replace("model.", "", 1) if k.startswith("model.") else k: v for k, v in sd.items()}, strict=False)
-    assert not missing and not unexpected, (missing, unexpected)
-    rf, re, rv = ref(batch)
-    (re.square().sum() + rv.sum()).backward()
-    assert_close(feats.detach().cpu(), rf.detach(), 2e-5, "frame-level fused features")
-    assert_close(emos.detach().cpu(), re.detach(), 2e-5, "frame-level emos_out")
-    got = dict(model.named_parameters())
-    for k, p in ref.named_parameters():
-        g = got.get(k, got.get("model." + k))
-        assert_close(g.grad.cpu(), p.grad, 5e-4, f"grad {k}")
+    assert np.allclose(losses, g["losses"], rtol=2e-4), (losses, g["losses"])
+    for k, p in model.state_dict().items():
+        assert_close(p.cpu(), torch.from_numpy(g["final_" + k[len("model."):]]), 2e-3, f"final {k}")
 
 
 @pytest.mark.parametrize("feat_type", ["utt", "frm_align", "frm_unalign"])
