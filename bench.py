@@ -37,7 +37,16 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-GFLOP_PER_CLIP = {"hubert-base": 71.67, "clip-vit-b16-8f": 281.0, "roberta-base-64": 11.02}
+GFLOP_PER_CLIP = {"hubert-base": 71.67, "clip-vit-b16-8f": 281.0, "roberta-base-64": 11.02,
+                  "hubert-large": 185.48, "videomae-large-16f": 1193.7, "roberta-large-64": 39.06}
+# the two measured configurations: BASELINE.json configs[3] (base trio, the headline metric) and configs[4] (large trio)
+CONFIGS = {
+    "base": {"a": ("hubert", "base", "hubert-base"), "v": ("clip", "base16", "clip-vit-b16-8f"), "t": ("bert", "roberta-base", "roberta-base-64"),
+             "workload": "tri-modal base extract: HuBERT-base 5s@16kHz + CLIP-ViT-B/16 8x224^2 + RoBERTa-base 64 tok "
+                         "(BASELINE.json configs[3] extraction leg = configs[1]+[2]+text on each GPU)"},
+    "large": {"a": ("hubert", "large", "hubert-large"), "v": ("videomae", "large", "videomae-large-16f"), "t": ("bert", "roberta-large", "roberta-large-64"),
+              "workload": "tri-modal large extract: HuBERT-large 5s@16kHz + VideoMAE-L 16x224^2 + RoBERTa-large 64 tok (BASELINE.json configs[4])"},
+}
 PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -50,6 +59,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--config", default="base", choices=sorted(CONFIGS), help="base = BASELINE configs[3] (the headline metric); large = configs[4]")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="16-bit MFMA operand type; bf16 has no MX kernel: use --precision accurate (3 passes) for parity")
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
     ap.add_argument("--precision", default="mx", choices=["fast", "balanced", "mx", "accurate"],
                     help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo f16 planes, meets 1e-3 parity), mx=1 + MX-fp4 "
@@ -162,33 +173,40 @@ def respawn_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
-def parity_check(feats, inputs, mods, nclip=2):
-    """Features of the first `nclip` clips of the last timed step (computed inside the full batch, i.e. by the kernels the
-    timing selected) against the CPU oracle on the same weights and inputs.  north_star tolerance: 1e-3 (max-norm relative)."""
+def oracle_features(kind, size, x):
+    """The CPU oracle's UTT feature of one modality of CONFIGS (same synthetic weights as the HIP model)."""
     from oracle import encoders_ref as R
     from mertools_amd import synthetic as W
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    out = {}
-
-    def rel(a, b):
-        return float((a.double().cpu() - b.double()).abs().max() / b.double().abs().max())
-
     with torch.no_grad():
-        if "a" in mods:
-            hc = W.hubert_config("base")
-            ref = torch.stack(R.hubert_hidden_states(W.hubert_state_dict(hc, 0), vars(hc), inputs["a"][:nclip].cpu()))[[-4, -3, -2, -1]].sum(0).mean(1)
-            out["a"] = rel(feats["a"][:nclip], ref)
-        if "v" in mods:
-            cc = W.clip_config("base16")
-            ref = R.clip_image_features(W.clip_state_dict(cc, 0), dict(vars(cc.vision_config), projection_dim=cc.projection_dim),
-                                        inputs["v"][:nclip * 8].cpu()).view(nclip, 8, -1).mean(1)
-            out["v"] = rel(feats["v"][:nclip], ref)
-        if "t" in mods:
-            bc = W.bert_config("roberta-base")
-            ids = inputs["t"][:nclip].cpu()
-            ref = torch.stack(R.bert_hidden_states(W.bert_state_dict(bc, 0), dict(vars(bc), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
-            out["t"] = rel(feats["t"][:nclip], ref)
-    return {k: float(f"{v:.3e}") for k, v in out.items()}
+        if kind == "hubert":
+            hc = W.hubert_config(size)
+            return torch.stack(R.hubert_hidden_states(W.hubert_state_dict(hc, 0), vars(hc), x))[[-4, -3, -2, -1]].sum(0).mean(1)
+        if kind == "clip":
+            cc = W.clip_config(size)
+            return R.clip_image_features(W.clip_state_dict(cc, 0), dict(vars(cc.vision_config), projection_dim=cc.projection_dim), x).view(x.shape[0] // 8, 8, -1).mean(1)
+        if kind == "videomae":
+            vc = W.videomae_config(size)
+            return R.videomae_last_hidden_state(W.videomae_state_dict(vc, 0), vars(vc), x).mean(1)   # mean of equal-size segment means
+        bc = W.bert_config(size)
+        return torch.stack(R.bert_hidden_states(W.bert_state_dict(bc, 0), dict(vars(bc), roberta=True), x, torch.ones_like(x)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
+
+
+def parity_check(feats, inputs, mods, config="base", nclip=2):
+    """Features of the first `nclip` clips of the last timed step (computed inside the full batch, i.e. by the kernels the
+    timing selected) against the CPU oracle on the same weights and inputs.  north_star tolerance: 1e-3 (max-norm relative).
+    Returns (errors per modality, oracle seconds per clip per modality)."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    out, secs = {}, {}
+    for m in "avt":
+        if m not in mods:
+            continue
+        kind, size, _ = CONFIGS[config][m]
+        rows = nclip * (8 if kind == "clip" else 1)
+        t0 = time.perf_counter()
+        ref = oracle_features(kind, size, inputs[m][:rows].cpu())
+        secs[m] = (time.perf_counter() - t0) / nclip
+        out[m] = float((feats[m][:nclip].double().cpu() - ref.double()).abs().max() / ref.double().abs().max())
+    return {k: float(f"{v:.3e}") for k, v in out.items()}, secs
 
 
 def main():
@@ -213,22 +231,29 @@ def main():
     from mertools_amd import _lib, synthetic as W
     from mertools_amd.encoders import HipBertModel, HipCLIPModel, HipHubertModel
 
+    from mertools_amd.encoders import HipVideoMAEModel
     B = args.batch
     mods = set(args.modalities)
+    cfgset = CONFIGS[args.config]
     models, inputs = {}, {}
     # every rank: same weights (replicated), its own shard of synthetic clips (seed offset by rank)
-    if "a" in mods:
-        hc = W.hubert_config("base")
-        models["a"] = HipHubertModel(W.hubert_state_dict(hc, 0), hc, device=dev, precision=args.precision)
-        inputs["a"] = W.synth_audio(B, seed=1234 + rank).to(dev)
-    if "v" in mods:
-        cc = W.clip_config("base16")
-        models["v"] = HipCLIPModel(W.clip_state_dict(cc, 0), cc, device=dev, precision=args.precision)
-        inputs["v"] = W.synth_frames(B * 8, seed=1235 + rank).to(dev)
-    if "t" in mods:
-        bc = W.bert_config("roberta-base")
-        models["t"] = HipBertModel(W.bert_state_dict(bc, 0), bc, device=dev, precision=args.precision)
-        inputs["t"] = W.synth_tokens(B, seed=1236 + rank).to(dev)
+    for m in "avt":
+        if m not in mods:
+            continue
+        kind, size, _ = cfgset[m]
+        kw = dict(device=dev, precision=args.precision, dtype=args.dtype)
+        if kind == "hubert":
+            c = W.hubert_config(size)
+            models[m], inputs[m] = HipHubertModel(W.hubert_state_dict(c, 0), c, **kw), W.synth_audio(B, seed=1234 + rank).to(dev)
+        elif kind == "clip":
+            c = W.clip_config(size)
+            models[m], inputs[m] = HipCLIPModel(W.clip_state_dict(c, 0), c, **kw), W.synth_frames(B * 8, seed=1235 + rank).to(dev)
+        elif kind == "videomae":
+            c = W.videomae_config(size)
+            models[m], inputs[m] = HipVideoMAEModel(W.videomae_state_dict(c, 0), c, **kw), W.synth_video(B, seed=1235 + rank).to(dev)
+        else:
+            c = W.bert_config(size)
+            models[m], inputs[m] = HipBertModel(W.bert_state_dict(c, 0), c, **kw), W.synth_tokens(B, seed=1236 + rank).to(dev)
     frames_per_clip = [8] * B
     lengths = [64] * B
 
@@ -239,7 +264,7 @@ def main():
     Sm = {m: (max(1, args.split) if m in args.split_mods else 1) for m in "avt"}   # sub-batches per modality
     S = max(Sm.values())
     streams = {m: [torch.cuda.Stream(device=dev) for _ in range(Sm[m])] for m in "avt"} if (args.streams or S > 1) else None
-    per = {"a": 1, "v": 8, "t": 1}   # input rows per clip
+    per = {"a": 1, "v": 8 if cfgset["v"][0] == "clip" else 1, "t": 1}   # input rows per clip
     parts = {m: [inputs[m][i * (B // Sm[m]) * per[m]:(i + 1) * (B // Sm[m]) * per[m]] for i in range(Sm[m])] for m in mods}
 
     def run(m, i=None):
@@ -251,6 +276,8 @@ def main():
         if m == "a":
             return models["a"].extract_utterance(xa)
         if m == "v":
+            if cfgset["v"][0] == "videomae":
+                return models["v"].extract_utterance(xv)
             return models["v"].extract_utterance(xv, frames_per_clip[:n])
         return models["t"].extract_utterance(xt, lengths[:n], 1, -1)
 
@@ -323,13 +350,12 @@ def main():
         allgather = {"collective": "all_gather_into_tensor (RCCL), one per step, side stream", "ranks": world,
                      "rows_per_rank": B, "bytes_per_rank": int(B * sum(feats[m].shape[1] for m in "atv") * 4),
                      "ms_median": round(ms[len(ms) // 2], 4), "ms_max": round(ms[-1], 4)}
-    parity = None
+    parity, oracle_secs = None, None
     if rank == 0 and not args.no_parity:
-        parity = parity_check(feats, inputs, mods)
+        parity, oracle_secs = parity_check(feats, inputs, mods, args.config, nclip=2 if args.config == "base" else 1)
 
     clips = B * world * args.steps
-    gflop_clip = (GFLOP_PER_CLIP["hubert-base"] if "a" in mods else 0) + (GFLOP_PER_CLIP["clip-vit-b16-8f"] if "v" in mods else 0) + \
-                 (GFLOP_PER_CLIP["roberta-base-64"] if "t" in mods else 0)
+    gflop_clip = sum(GFLOP_PER_CLIP[cfgset[m][2]] for m in mods)
 
     roofline = None
     if not args.no_roofline:
@@ -346,18 +372,32 @@ def main():
         tot_ms = sum(r["ms"] for r in recs.values())
         dom = max(recs.values(), key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        traffic = None  # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh)
-        traffic_detail = None
-        pmc_file, pmc_key = {"gemm16_w2": ("r01_pmc_hbm_traffic.json", "gemm16<DF16_Li256>"),
-                             "gemm16_mx": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,4,2,1,1,1,3,1,0>"),
-                             "gemm16": ("r01_pmc_hbm_traffic_mx.json", "gemm16<f16,256,256,32,2,4,1,1,1,4,0,0>")}.get(dom["name"], (None, None))
-        pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
-        if pmc_file and os.path.exists(pmc):
-            k = json.load(open(pmc)).get(pmc_key)
+        # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh -> profiles/*pmc_hbm_traffic*.json).
+        # A stored figure is only quoted when it was collected on THIS kernel source (sha of csrc/gemm16_impl.h + gemm16.hip stamped by
+        # scripts/pmc_summarize.py); otherwise traffic is null and the note says why.
+        traffic, traffic_detail = None, None
+        import glob
+        import hashlib
+        hsh = hashlib.sha256()
+        for f in ("gemm16_impl.h", "gemm16.hip"):
+            hsh.update(open(os.path.join(ROOT, "mertools_amd", "csrc", f), "rb").read())
+        sha = hsh.hexdigest()[:16]
+        prefix = {"gemm16": "gemm16<f16,256,256,32,2,4,1,1,", "gemm16_mx": "gemm16<f16,256,256,32,4,2,1,1,", "gemm16_w2": "gemm16<f16,256,256,32,2,4,1,2,"}.get(dom["name"])
+        stale = []
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
+            d = json.load(open(pmc))
+            if d.get("_source_sha") != sha:
+                stale.append(os.path.basename(pmc))
+                continue
+            k = next((v for name, v in d.items() if prefix and name.startswith(prefix)), None)
             if k:
                 traffic_detail = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
-                                  "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/" + pmc_file.replace(".json", ".txt")}
+                                  "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/" + os.path.basename(pmc),
+                                  "kernel_source_sha": sha}
                 traffic = round((k["fetch_mb_x2"] + k["write_mb"]) * 1e6)   # HBM-side bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE)
+                break
+        if traffic is None:
+            traffic_detail = {"note": f"no PMC collection matches this kernel source (sha {sha}); older collections ignored: {stale}"}
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                     # the default 2-pass (weights hi+lo) kernel issues 2x the algorithmic MFMA work; 3-pass 3x
@@ -374,12 +414,11 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "clips/sec (A+V+T feature-extract, 5s/8-frame/64-tok)" if mods == set("avt") else f"clips/sec ({''.join(sorted(mods))} only)",
+            "metric": ("clips/sec (A+V+T feature-extract, 5s/8-frame/64-tok)" if args.config == "base" else "clips/sec (A+V+T feature-extract, large trio, 5s/16-frame/64-tok)") if mods == set("avt") else f"clips/sec ({''.join(sorted(mods))} only)",
             "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "tri-modal base extract: HuBERT-base 5s@16kHz + CLIP-ViT-B/16 8x224^2 + RoBERTa-base 64 tok "
-                                   "(BASELINE.json configs[3] extraction leg = configs[1]+[2]+text on each GPU)",
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": cfgset["workload"],
                        "clips_per_gpu_per_step": B, "modalities": "".join(sorted(mods)), "precision": args.precision,
                        "weights": "random-init (seed 0), HF architectures", "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": {m: Sm[m] for m in sorted(mods)}, "parallelism": f"clip-sharded x{world}, no data-path collective" + ("; one fused fusion-minibatch all-gather per step (side stream)" if comm is not None else ""),
                        "gflop_per_clip": gflop_clip},
@@ -390,7 +429,13 @@ def main():
             res["allgather"] = allgather
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline()
+                if args.config == "base":
+                    res["cpu_baseline"] = cpu_baseline()
+                elif oracle_secs:   # large trio: the oracle forward of the parity leg IS the bounded CPU sample (one clip per modality)
+                    res["cpu_baseline"] = {"value": round(1.0 / sum(oracle_secs.values()), 4), "unit": "clips/s", "cores": torch.get_num_threads(),
+                                           "cpu_model": _cpu_model(), "kind": "port",
+                                           "sample": "one clip per modality through oracle/encoders_ref.py (fp32 torch-CPU forward, batch 1), "
+                                                     "seconds per clip: " + ", ".join(f"{m}={v:.1f}" for m, v in oracle_secs.items())}
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

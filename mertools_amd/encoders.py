@@ -807,6 +807,13 @@ class HipVideoMAEModel(_HipModule):
     def __call__(self, pixel_values=None, **_):
         return EncoderOutput(last_hidden_state=self.forward_raw(pixel_values)[0])
 
+    def extract_utterance(self, pixel_values):
+        """UTTERANCE feature of the VideoMAE branch: the mean of the [F/ts, D] segment means (extract_vision_huggingface.py:156-158
+        then :183-189) == the mean over all patches of the video (segments are equally sized) -> [B, D]."""
+        B = pixel_values.shape[0]
+        return self.forward_raw(pixel_values, hidden=False, seg_start=[b * self.num_patches for b in range(B)],
+                                seg_len=[self.num_patches] * B)[1]
+
     def extract_segments(self, pixel_values):
         """Fused path of extract_vision_huggingface.py:156-158: view(F/ts, patches_per_frame, D).mean(1) per video
         -> [B * F/ts, D]."""

@@ -33,4 +33,11 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0])
     wmb = sum(wr) / max(len(wr), 1) * 1024 / 1e6
     out[k] = dict(launches=len(fe) or len(wr), fetch_mb=fmb, fetch_mb_x2=2 * fmb, write_mb=wmb)
     print(f"{k[:70]:70s} {len(fe) or len(wr):8d} {fmb:16.2f} {2 * fmb:12.2f} {wmb:16.2f}")
+# stamp the kernel sources the counters belong to: bench.py only quotes a traffic figure whose stamp matches the library it runs
+import hashlib
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mertools_amd", "csrc")
+h = hashlib.sha256()
+for f in ("gemm16_impl.h", "gemm16.hip"):
+    h.update(open(os.path.join(csrc, f), "rb").read())
+out["_source_sha"] = h.hexdigest()[:16]
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)

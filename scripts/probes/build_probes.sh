@@ -12,3 +12,6 @@ ls -la abi_selftest.bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -x hip gemm16_bench.cpp -I../../include -L../../mertools_amd -lmer_hip \
   -Wl,-rpath,'$ORIGIN/../../mertools_amd' -o gemm16_bench.bin
 ls -la gemm16_bench.bin
+# what bounds the GEMM epilogue's global stores (per-CU rate vs chip rate, store flavours)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o store_probe.bin store_probe.hip
+ls -la store_probe.bin
