@@ -51,7 +51,9 @@ int mer_abi_sizeof(const char* name);
 /* Tuning knobs (A/B testing): "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged. */
 int mer_set_option(const char* name, int value);
 /* Kernel-phase timing for tuning: when non-NULL, every mer_gemm16 workgroup writes 4 s_memtime stamps (start, first
- * slab ready, K loop done, end) at buffer[4*workgroup ..]; the caller sizes the device buffer. NULL disables. */
+ * slab ready, K loop done, end) at buffer[4*workgroup ..], per-phase counters at [4*W + 16*workgroup ..] (gemm_stamp builds)
+ * and (XCC id << 32 | HW_ID) of the CU it ran on at [20*W + workgroup], W = workgroups of the launch: the caller
+ * provides 21*W 8-byte words. NULL disables. */
 int mer_set_debug_buffer(void* device_u64_buffer);
 int mer_prof_enable(int on);
 int mer_prof_report(char* buf, int buflen);

@@ -21,6 +21,7 @@
 namespace mer {
 
 extern unsigned long long* g_gemm_dbg;
+int g_attn_waves = 8;      // mer_set_option("attn_waves", 4): 4-wave workgroups for every T (A/B testing)
 int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
 
 // BIAS: scores get an additive term gate[b,h,q] * bias[h,q,k] before the softmax — WavLM's gated relative position bias
@@ -35,8 +36,11 @@ __device__ __forceinline__ typename T16<T>::v4 tr_read4(const T* lds_ptr) {
   return __builtin_bit_cast(typename T16<T>::v4, r);
 }
 
-template <typename T, int NKT, bool BIAS = false>
-__global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
+// NW waves per workgroup share one staged K / V: 8 waves (NKT <= 16: the scores fit 128 VGPRs) give a CU 16 resident waves
+// on the same LDS footprint as 4 — the per-sub-tile chain (Q load -> 2 NKT MFMAs -> softmax -> 2 NKT MFMAs -> store) is
+// latency-bound, and a head's 13-16 sub-tiles take 2 rounds of a wave instead of 4.
+template <typename T, int NKT, bool BIAS = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                       long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg,
                                                       const float* __restrict__ bias = nullptr, long long ldb = 0,
@@ -68,12 +72,12 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
 
   // ---- stage K (row-major, padded) and V^T into LDS; rows >= klen are zero.  Loads are issued SG chunks at a time
   // ahead of their LDS writes: one memory round trip per SG*32 rows instead of one per 32 rows. ----
-  constexpr int SIT = TP * 8 / 256, SG = 4;
+  constexpr int NT = NW * 64, SIT = (TP * 8 + NT - 1) / NT, SG = 4;
   for (int g0 = 0; g0 < SIT; g0 += SG) {
     u32x4 kreg[SG], vreg[SG];
 #pragma unroll
     for (int it = 0; it < SG; ++it) {
-      const int c = tid + (g0 + it) * 256;
+      const int c = tid + (g0 + it) * NT;
       const int row = c >> 3, ch = c & 7;
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
       vreg[it] = u32x4{0u, 0u, 0u, 0u};
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
     }
 #pragma unroll
     for (int it = 0; it < SG; ++it) {
-      if (g0 + it < SIT) {
-        const int c = tid + (g0 + it) * 256;
-        const int row = c >> 3, ch = c & 7;
+      const int c = tid + (g0 + it) * NT;
+      const int row = c >> 3, ch = c & 7;
+      if (g0 + it < SIT && row < TP) {
         *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kreg[it];
         *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vreg[it];
       }
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_sp_kernel(const T* __restrict__ q, c
 
   // K / V^T of this (batch, head) are staged once; each wave then walks its 16-query sub-tiles
   // (qs = wave, wave+4, ...), so the staging cost is paid once per head instead of once per 64 queries.
-  for (int qs = qt * 4 + wave; qs * 16 < Tn; qs += 4 * (int)gridDim.x) {
+  for (int qs = qt * NW + wave; qs * 16 < Tn; qs += NW * (int)gridDim.x) {
   // K / V^T fragments are loop-invariant LDS reads: without this clobber hipcc hoists all of them out of the loop
   // (28 + 56 fragment registers -> 256 VGPR + ~90 AGPR, one workgroup per CU instead of two)
   asm volatile("" ::: "memory");
@@ -344,12 +348,19 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
                        int B, int Tn, int H, float scale, const int* kv_len, int hm, hipStream_t st,
                        const float* bias = nullptr, long long ldb = 0, const float* gate = nullptr) {
   const float sl2 = scale * 1.4426950408889634f;
-  dim3 grid(1, H, B), block(256);  // one workgroup per (batch, head): K/V staged once
+  dim3 grid(1, H, B), block(256), block8(512);  // one workgroup per (batch, head): K/V staged once
+  const bool w8 = g_attn_waves != 4;   // mer_set_option("attn_waves", 4): 4-wave workgroups everywhere (A/B)
   ProfScope prof(bias ? "attention_bias" : "attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
   if (bias) {
 #define MER_ATTN_BCASE(N)                                                                                            \
-  hipLaunchKernelGGL((attn_sp_kernel<T, N, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
-                     (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate)
+  do {                                                                                                               \
+    if (w8 && N >= 8 && N <= 16)                                                                                     \
+      hipLaunchKernelGGL((attn_sp_kernel<T, N, true, (N >= 8 && N <= 16) ? 8 : 4>), grid, (N >= 8 && N <= 16) ? block8 : block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate);                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((attn_sp_kernel<T, N, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate);                     \
+  } while (0)
     if (Tn <= 64) MER_ATTN_BCASE(4);
     else if (Tn <= 128) MER_ATTN_BCASE(8);
     else if (Tn <= 224) MER_ATTN_BCASE(14);
@@ -364,8 +375,14 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
     return check_launch("attention_bias");
   }
 #define MER_ATTN_CASE(N)                                                                                       \
-  hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld,   \
-                     (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg)
+  do {                                                                                                         \
+    if (w8 && N >= 8 && N <= 16)                                                                               \
+      hipLaunchKernelGGL((attn_sp_kernel<T, N, false, (N >= 8 && N <= 16) ? 8 : 4>), grid, (N >= 8 && N <= 16) ? block8 : block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg);                                \
+    else                                                                                                       \
+      hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg);                                \
+  } while (0)
   const int f = g_attn_force_nkt;
   if (f == 14 && Tn <= 224) MER_ATTN_CASE(14);
   else if (f == 18 && Tn <= 288) MER_ATTN_CASE(18);

@@ -9,6 +9,7 @@ int g_gemm_persist = 0;   // mer_set_option("gemm_persist", 1): persistent-tile 
 int g_gemm_glds = 1;
 int g_gemm_pkepi = 1;     // mer_set_option("gemm_pkepi", 0): 16-bit-only outputs take the generic fp32-staged epilogue (A/B testing)
 int g_gemm_stagger = 0;   // mer_set_option("gemm_stagger", R): phase-spread the CUs of 256x256 launches with >= R rounds of tiles (0 = off)
+int g_gemm_store = 0;     // mer_set_option("gemm_store", m): epilogue store flavour (0 plain, 1 sc1, 2 nt, 3 sc0 sc1)
 int g_gemm_wblk = 1;      // mer_set_option("gemm_wblk", 0): ignore pre-blocked weight planes (A/B testing)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
 
@@ -25,7 +26,7 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
   return MER_OK;
 }
 
-namespace mer { extern int g_attn_force_nkt; extern int g_tf_ablk; }
+namespace mer { extern int g_attn_force_nkt; extern int g_attn_waves; extern int g_tf_ablk; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
@@ -34,8 +35,10 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_wblk") == 0) { mer::g_gemm_wblk = value; return MER_OK; }
   if (name && strcmp(name, "gemm_pkepi") == 0) { mer::g_gemm_pkepi = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stagger") == 0) { mer::g_gemm_stagger = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_store") == 0) { mer::g_gemm_store = value; return MER_OK; }
   if (name && strcmp(name, "tf_ablk") == 0) { mer::g_tf_ablk = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
+  if (name && strcmp(name, "attn_waves") == 0) { mer::g_attn_waves = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
 }
@@ -180,6 +183,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   if (a->c16_hi) vec = vec && (a->ldc16 % 8 == 0) && (((uintptr_t)a->c16_hi & 15) == 0);
   if (a->c16_lo) vec = vec && (((uintptr_t)a->c16_lo & 15) == 0);
   p.vec_ok = vec ? 1 : 0;
+  p.st_mode = g_gemm_store;
   // packed-pair epilogue: 16-bit output only (no fp32 copy, residual or lo plane), row-major, every column group of 8 in range
   p.pk_epi = (g_gemm_pkepi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 && !a->c16_blocked) ? 1 : 0;
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,

@@ -49,6 +49,7 @@ struct Gemm16Params {
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
   int stagger_blocks; unsigned stagger_cycles;   // > 0: the first stagger_blocks workgroups (one per CU) start up to stagger_cycles late, see the kernel
+  int st_mode;    // epilogue store flavour: 0 plain, 1 sc1 (line not kept in the XCD's L2), 2 nt, 3 sc0 sc1 (tuning: gemm_store)
   int pk_epi;     // 16-bit-only outputs: activation on the accumulators, row pairs packed before the LDS transposition (half the LDS traffic)
   int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
   int hm_T, hm_H;  // > 0: 16-bit output scattered head-major [N/(64*hm_H)][M/hm_T][hm_H][hm_T][64] (QKV for attention)
@@ -66,6 +67,14 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 template <int C>
 __device__ __forceinline__ int swz_of(int row) {
   return C == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3);
+}
+
+// 16-byte global store with a cache-policy flavour (see Gemm16Params::st_mode)
+__device__ __forceinline__ void gstore16(void* ptr, u32x4 v, int mode) {
+  if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(v) : "memory");
+  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(ptr), "v"(v) : "memory");
+  else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ptr), "v"(v) : "memory");
+  else *reinterpret_cast<u32x4*>(ptr) = v;
 }
 
 template <int N>
@@ -157,7 +166,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)((blockIdx.x >> 3) & 31) * (p.stagger_cycles >> 5);
     while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(16);
   }
-  if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memtime();
+  if (p.dbg && tid == 0) {
+    const long long nb = (long long)gridDim.x * gridDim.y, bi = blockIdx.y * gridDim.x + blockIdx.x;
+    p.dbg[bi * 4 + 0] = __builtin_amdgcn_s_memtime();
+    // which CU ran this workgroup: HW_REG_XCC_ID[3:0] and the SE / SH / CU fields of HW_REG_HW_ID (timeline analysis, scripts/gemm_timeline.py)
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    p.dbg[nb * 20 + bi] = ((unsigned long long)xcc << 32) | hw;
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, lg = lane >> 4;
@@ -438,8 +453,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           }
           if (c32) {
             float* cp = c32 + (long long)row * p.ldc32 + col;
-            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            gstore16(cp, __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), p.st_mode);
+            gstore16(cp + 4, __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), p.st_mode);
           }
           if (c16h) {
             v8 h;
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
               const int rr = row & 255, lc = (col & 31) >> 3;
               o16 = ((((long long)(row >> 8) * p.c16_blk + (col >> 5)) * 256 + rr) << 5) + ((lc ^ swz_of<4>(rr)) << 3);
             }
-            *reinterpret_cast<v8*>(c16h + o16) = h;
+            gstore16(c16h + o16, __builtin_bit_cast(u32x4, h), p.st_mode);
             if (c16l) {  // lo plane only when a 3-pass consumer needs it (3 extra VALU per element otherwise wasted)
               v8 l;
 #pragma unroll
@@ -536,8 +551,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         ev[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); od[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u);
         ev[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u); od[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
         if (c16h) {
-          *reinterpret_cast<u32x4*>(c16h + (long long)row * p.ldc16 + col) = ev;
-          if (row + 1 < p.M) *reinterpret_cast<u32x4*>(c16h + (long long)(row + 1) * p.ldc16 + col) = od;
+          gstore16(c16h + (long long)row * p.ldc16 + col, ev, p.st_mode);
+          if (row + 1 < p.M) gstore16(c16h + (long long)(row + 1) * p.ldc16 + col, od, p.st_mode);
         }
       }
     }
@@ -772,7 +787,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_stagger;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_stagger, g_gemm_store;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>

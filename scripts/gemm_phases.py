@@ -22,7 +22,7 @@ for (name, M, N, K, act, passes) in [("fc1 gelu p2", 100864, 3072, 768, "gelu", 
     bias = torch.randn(N, device=dev)
     nblk = ((M + 255) // 256) * ((N + 255) // 256)
     STAMP = int(os.environ.get("STAMP", "0"))
-    buf = torch.zeros(nblk * 4 + nblk * 16, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nblk * 21, dtype=torch.int64, device=dev)   # 4 stamps + 16 phase counters + the CU id per workgroup
     kw = dict(w_lo=wl if passes >= 2 else None, w_mx=mx, passes=passes, dtype="f16", tile=3, bias=bias, act=act, out16=True)
     ops.gemm16(ah, wh, **kw); torch.cuda.synchronize()
     WARM = int(os.environ.get("WARM", "0"))   # > 0: stamp a launch that follows WARM back-to-back launches (sustained clocks)

@@ -206,3 +206,21 @@ def test_visual_extract_device_resize_equals_host_path(dev, tmp_path):
     for v in vids:
         a, b = np.load(tmp_path / "host" / f"{v}.npy"), np.load(tmp_path / "dev" / f"{v}.npy")
         assert a.shape == b.shape and np.abs(a - b).max() <= 2e-4 * np.abs(a).max(), v
+
+
+def test_model_on_second_gpu_while_first_is_current():
+    """A model built on cuda:1 and called while cuda:0 is the current device must launch on GPU 1 (the C ABI launches on the
+    current HIP device; every forward switches to the model's own device).  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    from mertools_amd.encoders import HipBertModel
+    cfg = W.bert_config("tiny")
+    sd = W.bert_state_dict(cfg, 4)
+    ids = W.synth_tokens(2, 16, vocab=300, seed=8, bos=0, eos=2)
+    ref = torch.stack(R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
+    torch.cuda.set_device(0)
+    m = HipBertModel(sd, cfg, device="cuda:1", precision="accurate")
+    out = m.extract_utterance(ids, [16, 16], 1, -1)
+    assert out.device == torch.device("cuda:1") and torch.cuda.current_device() == 0
+    torch.cuda.synchronize(1)
+    assert rel_err(out.cpu(), ref)[0] < 3e-4
