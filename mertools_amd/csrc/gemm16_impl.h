@@ -49,7 +49,9 @@ struct Gemm16Params {
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
   int stagger_blocks; unsigned stagger_cycles;   // > 0: the first stagger_blocks workgroups (one per CU) start up to stagger_cycles late, see the kernel
-  int st_mode;    // epilogue store flavour: 0 plain, 1 sc1 (line not kept in the XCD's L2), 2 nt, 3 sc0 sc1 (tuning: gemm_store)
+  int st_mode;    // store flavour of the 16-bit-only (packed-pair) epilogue: 0 plain, 1 sc1, 2 nt (default: streaming stores leave L2 / MALL to the operands), 3 sc0 sc1
+  int st_mode32;  // the same for the fp32-only epilogue
+  int epi32;      // fp32-only outputs (+ residual): 4 columns per lane, so that one store instruction covers whole 256-byte row runs
   int pk_epi;     // 16-bit-only outputs: activation on the accumulators, row pairs packed before the LDS transposition (half the LDS traffic)
   int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
   int hm_T, hm_H;  // > 0: 16-bit output scattered head-major [N/(64*hm_H)][M/hm_T][hm_H][hm_T][64] (QKV for attention)
@@ -453,8 +455,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           }
           if (c32) {
             float* cp = c32 + (long long)row * p.ldc32 + col;
-            gstore16(cp, __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), p.st_mode);
-            gstore16(cp + 4, __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), p.st_mode);
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
           }
           if (c16h) {
             v8 h;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
               const int rr = row & 255, lc = (col & 31) >> 3;
               o16 = ((((long long)(row >> 8) * p.c16_blk + (col >> 5)) * 256 + rr) << 5) + ((lc ^ swz_of<4>(rr)) << 3);
             }
-            gstore16(c16h + o16, __builtin_bit_cast(u32x4, h), p.st_mode);
+            *reinterpret_cast<v8*>(c16h + o16) = h;
             if (c16l) {  // lo plane only when a 3-pass consumer needs it (3 extra VALU per element otherwise wasted)
               v8 l;
 #pragma unroll
@@ -557,8 +559,66 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       }
     }
   };
+  // fp32-only outputs (attention output projection, fc2: + residual): the generic path's 8 columns per lane make every store /
+  // residual-load instruction touch 16 bytes out of every 32 (two instructions per 128-byte line).  Here a lane owns 4 columns:
+  // 16 lanes cover a wave's 256-byte row run, one instruction = 4 whole rows, loads and stores are whole lines (and may stream).
+  auto epilogue32 = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    constexpr int LPR = SN / 4, RIT = 64 / LPR, NIT4 = EROWS / RIT;
+    const int c4 = lane % LPR, rs = lane / LPR;
+    const int col4 = n0 + wn * SN + c4 * 4;
+    const bool ok4 = col4 < p.N;
+    float b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = (bias && ok4) ? bias[col4 + j] : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < SM / EROWS; ++ch) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int mt = 0; mt < EROWS / 16; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ct[(mt * 16 + lg * 4 + r) * CLD + nt * 16 + li] = acc[ch * (EROWS / 16) + mt][nt][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int row0 = m0 + wm * SM + ch * EROWS + rs;
+      f32x4 rr[NIT4];
+      if (res) {
+#pragma unroll
+        for (int it = 0; it < NIT4; ++it) {
+          const int row = row0 + it * RIT;
+          rr[it] = (row < p.M && ok4) ? *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT4; ++it) {
+        const int row = row0 + it * RIT;
+        if (row >= p.M || !ok4) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ct + (it * RIT + rs) * CLD + c4 * 4);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + b4[j], ACT);
+        if (res) v += rr[it];
+        if (c32) gstore16(c32 + (long long)row * p.ldc32 + col4, __builtin_bit_cast(u32x4, v), p.st_mode32);
+      }
+    }
+  };
   if ((p.dbg_skip & 3) == 2) {
     if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memtime();
+    return;
+  }
+  if (p.epi32) {   // host-checked: vector accesses, fp32 output only
+    if ((p.dbg_skip & 3) == 1) c32 = nullptr;
+    switch (p.act) {
+      case MER_ACT_GELU: epilogue32(std::integral_constant<int, MER_ACT_GELU>{}); break;
+      case MER_ACT_QUICK_GELU: epilogue32(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
+      case MER_ACT_RELU: epilogue32(std::integral_constant<int, MER_ACT_RELU>{}); break;
+      case MER_ACT_GELU_TANH: epilogue32(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
+      default: epilogue32(std::integral_constant<int, MER_ACT_NONE>{}); break;
+    }
     return;
   }
   if ((p.dbg_skip & 3) == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
@@ -787,7 +847,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_stagger, g_gemm_store;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_stagger, g_gemm_store, g_gemm_store32, g_gemm_epi32;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>
