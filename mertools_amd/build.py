@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libmer_hip.so")
 SOURCES = ["gemm16_t3_f16.hip", "gemm16_t3_bf16.hip", "gemm16_small_f16.hip", "gemm16_small_bf16.hip", "attention.hip",
            "common.cpp", "gemm16.hip", "gemm32.hip", "norm.hip", "frontend.hip", "fusion.hip", "encoders.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-x", "hip"]
+         "-fno-gpu-rdc", "-x", "hip", "-Rpass-analysis=kernel-resource-usage"]
 
 
 def _hipcc():
@@ -44,8 +44,13 @@ def _compile(src, hdr_mtime, verbose):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if verbose and r.stderr.strip():
-        print(r.stderr, file=sys.stderr)
+    # per-kernel VGPR / scratch / occupancy remarks: tests/test_abi.py checks that no hot kernel touches scratch memory
+    remarks = [l for l in r.stderr.splitlines() if "remark:" in l]
+    with open(o[:-2] + ".resources.txt", "w") as fh:
+        fh.write("\n".join(l.split("remark:", 1)[1].split("[-Rpass")[0].rstrip() for l in remarks) + "\n")
+    other = [l for l in r.stderr.splitlines() if "remark:" not in l and l.strip()]
+    if verbose and other:
+        print("\n".join(other), file=sys.stderr)
     return o
 
 

@@ -22,6 +22,7 @@ namespace mer {
 
 extern unsigned long long* g_gemm_dbg;
 int g_attn_waves = 8;      // mer_set_option("attn_waves", 4): 4-wave workgroups for every T (A/B testing)
+int g_attn_nt = 0;         // mer_set_option("attn_nt", 1): K / V staging with non-temporal loads
 int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
 
 // BIAS: scores get an additive term gate[b,h,q] * bias[h,q,k] before the softmax — WavLM's gated relative position bias
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ 
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                       long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg,
                                                       const float* __restrict__ bias = nullptr, long long ldb = 0,
-                                                      const float* __restrict__ gate = nullptr) {
+                                                      const float* __restrict__ gate = nullptr, int nt = 0) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
   constexpr int TP = NKT * 16;
@@ -82,8 +83,14 @@ __global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ 
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
       vreg[it] = u32x4{0u, 0u, 0u, 0u};
       if (g0 + it < SIT && row < klen) {
-        kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
-        vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
+        // nt: a head's K / V are read once per (batch, head)
+        if (nt) {
+          kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8));
+          vreg[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8));
+        } else {
+          kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
+          vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
+        }
       }
     }
 #pragma unroll
@@ -356,10 +363,10 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   do {                                                                                                               \
     if (w8 && N >= 8 && N <= 16)                                                                                     \
       hipLaunchKernelGGL((attn_sp_kernel<T, N, true, (N >= 8 && N <= 16) ? 8 : 4>), grid, (N >= 8 && N <= 16) ? block8 : block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate);                     \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate, g_attn_nt);                     \
     else                                                                                                             \
       hipLaunchKernelGGL((attn_sp_kernel<T, N, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate);                     \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate, g_attn_nt);                     \
   } while (0)
     if (Tn <= 64) MER_ATTN_BCASE(4);
     else if (Tn <= 128) MER_ATTN_BCASE(8);
@@ -378,10 +385,10 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   do {                                                                                                         \
     if (w8 && N >= 8 && N <= 16)                                                                               \
       hipLaunchKernelGGL((attn_sp_kernel<T, N, false, (N >= 8 && N <= 16) ? 8 : 4>), grid, (N >= 8 && N <= 16) ? block8 : block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg);                                \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, nullptr, 0, nullptr, g_attn_nt);                                \
     else                                                                                                       \
       hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg);                                \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, nullptr, 0, nullptr, g_attn_nt);                                \
   } while (0)
   const int f = g_attn_force_nkt;
   if (f == 14 && Tn <= 224) MER_ATTN_CASE(14);

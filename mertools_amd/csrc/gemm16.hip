@@ -5,12 +5,11 @@
 namespace mer {
 int g_gemm_skip = 0;
 int g_gemm_stamp = 0;
-int g_gemm_persist = 0;   // mer_set_option("gemm_persist", 1): persistent-tile variant of the 8-wave non-MX kernels
 int g_gemm_glds = 1;
 int g_gemm_pkepi = 1;     // mer_set_option("gemm_pkepi", 0): 16-bit-only outputs take the generic fp32-staged epilogue (A/B testing)
-int g_gemm_stagger = 0;   // mer_set_option("gemm_stagger", R): phase-spread the CUs of 256x256 launches with >= R rounds of tiles (0 = off)
 int g_gemm_store = 2;     // mer_set_option("gemm_store", m): store flavour of the 16-bit-only epilogue (0 plain, 1 sc1, 2 nt, 3 sc0 sc1)
 int g_gemm_store32 = 0;   // mer_set_option("gemm_store32", m): the same for the fp32-only epilogue
+int g_gemm_res_nt = 0;    // mer_set_option("gemm_res_nt", 1): the fp32-only epilogue streams its residual rows with non-temporal loads
 int g_gemm_epi32 = 1;     // mer_set_option("gemm_epi32", 0): fp32-only outputs take the generic 8-columns-per-lane epilogue (A/B testing)
 int g_gemm_wblk = 1;      // mer_set_option("gemm_wblk", 0): ignore pre-blocked weight planes (A/B testing)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
@@ -28,21 +27,22 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
   return MER_OK;
 }
 
-namespace mer { extern int g_attn_force_nkt; extern int g_attn_waves; extern int g_tf_ablk; }
+namespace mer { extern int g_attn_force_nkt; extern int g_attn_waves; extern int g_attn_nt; extern int g_ln_nt; extern int g_tf_ablk; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
   if (name && strcmp(name, "gemm_wblk") == 0) { mer::g_gemm_wblk = value; return MER_OK; }
   if (name && strcmp(name, "gemm_pkepi") == 0) { mer::g_gemm_pkepi = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_stagger") == 0) { mer::g_gemm_stagger = value; return MER_OK; }
   if (name && strcmp(name, "gemm_store") == 0) { mer::g_gemm_store = value; return MER_OK; }
   if (name && strcmp(name, "gemm_store32") == 0) { mer::g_gemm_store32 = value; return MER_OK; }
   if (name && strcmp(name, "gemm_epi32") == 0) { mer::g_gemm_epi32 = value; return MER_OK; }
   if (name && strcmp(name, "tf_ablk") == 0) { mer::g_tf_ablk = value; return MER_OK; }
   if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
   if (name && strcmp(name, "attn_waves") == 0) { mer::g_attn_waves = value; return MER_OK; }
+  if (name && strcmp(name, "attn_nt") == 0) { mer::g_attn_nt = value; return MER_OK; }
+  if (name && strcmp(name, "ln_nt") == 0) { mer::g_ln_nt = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_res_nt") == 0) { mer::g_gemm_res_nt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
 }
@@ -189,10 +189,12 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   p.vec_ok = vec ? 1 : 0;
   p.st_mode = g_gemm_store;
   p.st_mode32 = g_gemm_store32;
+  p.res_nt = g_gemm_res_nt;
   // fp32-only epilogue: whole-line residual loads / stores (4 columns per lane); N % 8 == 0 and 16-byte alignment are `vec`
-  p.epi32 = (g_gemm_epi32 && vec && a->c32 && !a->c16_hi && !a->c16_lo && a->headmajor_T == 0) ? 1 : 0;
+  p.epi32 = (g_gemm_epi32 && vec && a->c32 && !a->c16_hi && !a->c16_lo && a->headmajor_T == 0 && (a->act == MER_ACT_NONE || a->act == MER_ACT_GELU)) ? 1 : 0;
   // packed-pair epilogue: 16-bit output only (no fp32 copy, residual or lo plane), row-major, every column group of 8 in range
-  p.pk_epi = (g_gemm_pkepi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 && !a->c16_blocked) ? 1 : 0;
+  p.pk_epi = (g_gemm_pkepi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 && !a->c16_blocked &&
+              a->act != MER_ACT_RELU) ? 1 : 0;
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;
@@ -228,7 +230,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   }
   if (a->a_blocked) {
     // the plane has no row-major form to fall back to: the caller must only ask for what the 256x256 LDS-DMA kernels cover
-    MER_REQUIRE(tile == 3 && passes != 4 && passes != 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && a->a_rows_per_batch == 0 && !g_gemm_persist, MER_ESHAPE,
+    MER_REQUIRE(tile == 3 && passes != 4 && passes != 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && a->a_rows_per_batch == 0, MER_ESHAPE,
                 "mer_gemm16: a blocked A plane needs the 256x256 one-/two-pass kernel (tile %d, passes %d, K=%d)", tile, passes, a->K);
     p.a_blk = 1;
   }

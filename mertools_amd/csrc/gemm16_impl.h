@@ -48,9 +48,9 @@ struct Gemm16Params {
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
-  int stagger_blocks; unsigned stagger_cycles;   // > 0: the first stagger_blocks workgroups (one per CU) start up to stagger_cycles late, see the kernel
   int st_mode;    // store flavour of the 16-bit-only (packed-pair) epilogue: 0 plain, 1 sc1, 2 nt (default: streaming stores leave L2 / MALL to the operands), 3 sc0 sc1
   int st_mode32;  // the same for the fp32-only epilogue
+  int res_nt;     // fp32-only epilogue: residual rows loaded non-temporally
   int epi32;      // fp32-only outputs (+ residual): 4 columns per lane, so that one store instruction covers whole 256-byte row runs
   int pk_epi;     // 16-bit-only outputs: activation on the accumulators, row pairs packed before the LDS transposition (half the LDS traffic)
   int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
@@ -123,9 +123,9 @@ __device__ __forceinline__ f32x4 mx_mfma(i32x8 a, i32x8 b, f32x4 c, int sb) {
 // STAMP (tuning builds of the 8-wave kernels, mer_set_option("gemm_stamp", 1)): waves 0 and NW/2 accumulate, per K-loop
 // iteration, the cycles spent in LOAD work / waiting at the mid barrier / MATH work / waiting at the end barrier, split
 // into the MX-burst slabs and the others, into p.dbg[4 * nblk + (blk * 2 + group) * 8 ..].
-// PERSIST (8-wave non-MX kernels, mer_set_option("gemm_persist", 1)): one workgroup per CU walks tiles L = blockIdx.x + i*gridDim.x;
-// the first PF slabs of the next tile are DMA'd into stages 0..PF-1 while the epilogue of the current tile runs out of a
-// staging area placed behind them, so the next tile starts without the ~6-8k-cycle prologue.
+// PERSIST (8-wave non-MX kernels; NOT instantiated since round 2 — it gained 1-3 % in round 1 and its register set no longer fits
+// beside the specialised epilogues): one workgroup per CU walks tiles L = blockIdx.x + i*gridDim.x; the first PF slabs of the next tile
+// are DMA'd into stages 0..PF-1 while the epilogue of the current tile runs out of a staging area placed behind them.
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false, bool STAMP = false, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
@@ -158,16 +158,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x;
-  // Phase spreading.  Every tile of a launch costs the same time, so the CUs run in lockstep: all 256 finish their K loops
-  // together, all store their C tiles together — an HBM-write-bound burst (33 MB per round at ~5.8 TB/s) during which no CU
-  // computes — and then all sit in their K loops while the memory system idles (measured: the global stores alone are 22-24 %
-  // of the K = 768 GEMMs, profiles/r02_gemm16_bench_epilogue_split.txt).  The first workgroup of every CU therefore starts a
-  // different fraction of a tile time late (CU c of its XCD: c / 32 of stagger_cycles); from then on each CU's store phase
-  // falls into other CUs' K loops for the rest of the launch (workgroups are dispatched as CUs free up, so the offsets persist).
-  if (p.stagger_cycles && blockIdx.y == 0 && (int)blockIdx.x < p.stagger_blocks) {
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)((blockIdx.x >> 3) & 31) * (p.stagger_cycles >> 5);
-    while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(16);
-  }
   if (p.dbg && tid == 0) {
     const long long nb = (long long)gridDim.x * gridDim.y, bi = blockIdx.y * gridDim.x + blockIdx.x;
     p.dbg[bi * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -181,7 +171,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
   // ---- XCD-aware, bijective block -> tile map (L = linear workgroup / tile index) ----
   const int nblk = p.tiles_m * p.tiles_n;
-  auto tile_of = [&](int L, int& tm, int& tn) {
+  auto tile_of = [&](int L, int& tm, int& tn) __attribute__((always_inline)) {
     const int xcd = L & 7, loc = L >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -207,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const int ld_row0 = tid / C;
   long long a_off[CA], w_off[CW];
   long long a_src[CA], w_src[CW];   // GLDS: the same with the XOR swizzle folded into the source address (see below)
-  auto setup_loads = [&](int m0_, int n0_) {
+  auto setup_loads = [&](int m0_, int n0_) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       int m = m0_ + ld_row0 + i * ROWS_PER_IT;
@@ -236,7 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   u32x4 ra[AP][CA], rw[WP][CW];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  auto gload = [&](int k0) {
+  auto gload = [&](int k0) __attribute__((always_inline)) {
     const int k = k0 + ld_ch * 8;
     const bool kin = k < p.K;
 #pragma unroll
@@ -250,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       for (int i = 0; i < CW; ++i)
         rw[pl][i] = kin ? *reinterpret_cast<const u32x4*>(w_pl[pl] + w_off[i] + k) : zero4;
   };
-  auto lds_store = [&](int stage) {
+  auto lds_store = [&](int stage) __attribute__((always_inline)) {
     char* base = smem + stage * STAGE;
 #pragma unroll
     for (int pl = 0; pl < AP; ++pl)
@@ -288,7 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const long long w_kmul = p.w_blk ? BN : 1;   // element distance of consecutive k (row-major) or of consecutive k-slabs / BK (pre-blocked)
   const long long a_kmul = (!MX && p.a_blk) ? BM : 1;
   const char* mx_base = MX ? (const char*)p.w_mx + ((long long)tile_n * ((p.K + BK - 1) / BK)) * MX_BLOCK : nullptr;
-  auto glds_issue = [&](int k0, int stage) {
+  auto glds_issue = [&](int k0, int stage) __attribute__((always_inline)) {
     char* base = smem + stage * STAGE;
     if constexpr (MX) {
       const char* ab = (const char*)a_pl[0] + (long long)k0 * 2;
@@ -329,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
   // fragment registers of one 32-deep k-step (ks) and the two halves of a k-step: LDS -> registers, registers -> MFMA
   v8 af[AP][TM], wf[WP][TN];
-  auto load_frags = [&](const char* base, int ks) {
+  auto load_frags = [&](const char* base, int ks) __attribute__((always_inline)) {
     const int chunk = ks * 4 + lg;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -347,7 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         wf[pl][nt] = *reinterpret_cast<const v8*>(base + AP * A_PLANE + pl * W_PLANE + off);
     }
   };
-  auto math = [&]() {
+  auto math = [&]() __attribute__((always_inline)) {
     // one pass at a time over all TM x TN accumulators: back-to-back MFMAs never share an accumulator
     // (a dependent 16x16x32 MFMA would wait ~2 issue slots for its predecessor)
     if (AP == 2) {
@@ -367,7 +357,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = T16<T>::mfma(af[0][mt], wf[0][nt], acc[mt][nt]);
   };
-  auto compute = [&](const char* base) {
+  auto compute = [&](const char* base) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       load_frags(base, ks);
@@ -375,7 +365,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     }
   };
 
-  auto run_epilogue = [&]() {
+  auto run_epilogue = [&]() __attribute__((always_inline)) {
   // ---- epilogue: accumulators -> per-wave LDS staging (EROWS rows at a time) -> 8 consecutive columns per lane, so
   // that 16-bit outputs leave as one 16-byte store per lane (the store tail is issue-bound: half the instructions,
   // half the time) and fp32 outputs / residuals as two.  The stage buffers are dead here (the K loop ended on a
@@ -399,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   T* c16l = p.c16_lo ? (T*)p.c16_lo + c_boff : nullptr;
   const bool vec = p.vec_ok && (col + CPL <= p.N);
 
-  auto epilogue = [&](auto act_tag) {
+  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int ch = 0; ch < SM / EROWS; ++ch) {
@@ -507,7 +497,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // transposition, so the staging tile holds row PAIRS: half the ds_write_b32 (the LDS pipe's slowest instruction, 64 B/clk/CU:
   // 4096 of its cycles per 256x256 fp32 tile) and half the read-back; a lane then owns 8 columns of a row pair and un-zips
   // them with v_perm_b32 into two 16-byte stores.
-  auto epilogue_pk = [&](auto act_tag) {
+  auto epilogue_pk = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     constexpr int CLDP = SN + 8;                 // dwords per staged row pair; 2 * CLDP % 32 == 16: the two lg halves of a ds_write_b32 group never share a bank
     constexpr int PAIRS = EROWS / 2;
@@ -562,7 +552,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // fp32-only outputs (attention output projection, fc2: + residual): the generic path's 8 columns per lane make every store /
   // residual-load instruction touch 16 bytes out of every 32 (two instructions per 128-byte line).  Here a lane owns 4 columns:
   // 16 lanes cover a wave's 256-byte row run, one instruction = 4 whole rows, loads and stores are whole lines (and may stream).
-  auto epilogue32 = [&](auto act_tag) {
+  auto epilogue32 = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     constexpr int LPR = SN / 4, RIT = 64 / LPR, NIT4 = EROWS / RIT;
     const int c4 = lane % LPR, rs = lane / LPR;
@@ -590,19 +580,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
         for (int it = 0; it < NIT4; ++it) {
           const int row = row0 + it * RIT;
-          rr[it] = (row < p.M && ok4) ? *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          rr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (row < p.M && ok4)
+            rr[it] = p.res_nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4))
+                              : *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4);
         }
       }
 #pragma unroll
       for (int it = 0; it < NIT4; ++it) {
         const int row = row0 + it * RIT;
-        if (row >= p.M || !ok4) continue;
+        if (row < p.M && ok4) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ct + (it * RIT + rs) * CLD + c4 * 4);
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + b4[j], ACT);
         if (res) v += rr[it];
         if (c32) gstore16(c32 + (long long)row * p.ldc32 + col4, __builtin_bit_cast(u32x4, v), p.st_mode32);
+        }
       }
     }
   };
@@ -612,13 +606,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   }
   if (p.epi32) {   // host-checked: vector accesses, fp32 output only
     if ((p.dbg_skip & 3) == 1) c32 = nullptr;
-    switch (p.act) {
-      case MER_ACT_GELU: epilogue32(std::integral_constant<int, MER_ACT_GELU>{}); break;
-      case MER_ACT_QUICK_GELU: epilogue32(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
-      case MER_ACT_RELU: epilogue32(std::integral_constant<int, MER_ACT_RELU>{}); break;
-      case MER_ACT_GELU_TANH: epilogue32(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
-      default: epilogue32(std::integral_constant<int, MER_ACT_NONE>{}); break;
-    }
+    if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{});   // (the host routes other activations to the generic path)
+    else epilogue32(std::integral_constant<int, MER_ACT_NONE>{});
     return;
   }
   if ((p.dbg_skip & 3) == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
@@ -626,7 +615,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     switch (p.act) {
       case MER_ACT_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}); break;
       case MER_ACT_QUICK_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
-      case MER_ACT_RELU: epilogue_pk(std::integral_constant<int, MER_ACT_RELU>{}); break;
       case MER_ACT_GELU_TANH: epilogue_pk(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
       default: epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}); break;
     }
@@ -670,7 +658,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
     for (int i = 0; i < (MX ? TM : 1); ++i) aq[i] = i64x4{0, 0, 0, 0};
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto iter = [&](int kt) {
+    auto iter = [&](int kt) __attribute__((always_inline)) {
       unsigned long long t0 = 0, tL = 0, tB1 = 0, tM = 0;
       if (STAMP) t0 = __builtin_amdgcn_s_memtime();
       const bool more = kt + D < nk;
@@ -847,7 +835,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_persist, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_stagger, g_gemm_store, g_gemm_store32, g_gemm_epi32;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_store, g_gemm_store32, g_gemm_epi32, g_gemm_res_nt;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>
@@ -856,23 +844,6 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
   p.tiles_m = (int)cdiv(p.M, BM);
   p.tiles_n = (int)cdiv(p.N, BN);
   dim3 grid(p.tiles_m * p.tiles_n, nbatch, 1), block(WM * WN * 64, 1, 1);
-  p.stagger_blocks = 0;
-  p.stagger_cycles = 0;
-  if constexpr (WM * WN == 8) {   // 256x256 tiles, one workgroup per CU
-    static int ncu_s = 0;
-    if (!ncu_s) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu_s, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu_s <= 0) ncu_s = 256;
-    }
-    const long long nblk = (long long)p.tiles_m * p.tiles_n;
-    // worth it from ~4 rounds of tiles on: the spread costs up to one tile time at the end of the launch
-    if (g_gemm_stagger > 0 && nbatch == 1 && nblk >= (long long)g_gemm_stagger * ncu_s) {
-      const long long nk = (p.K + BK - 1) / BK;
-      const long long per_slab = MX ? 2700 : (AP == 2 ? 3600 : (WP == 2 ? 2400 : 1500));   // measured K-loop cycles per 32-deep slab
-      p.stagger_blocks = ncu_s;
-      p.stagger_cycles = (unsigned)(nk * per_slab + 20000);                                // + prologue and epilogue
-    }
-  }
   // algorithmic work of this launch: 2*M*N*K flops (one pass, whatever AP/WP execute), A + W read once,
   // outputs (+ residual) touched once
   const double mn = (double)p.M * p.N * nbatch;
@@ -885,19 +856,6 @@ static int launch(const Gemm16Params& p0, int nbatch, hipStream_t st) {
     else hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, true>), grid, block, 0, st, p);
     return check_launch("gemm16_mx");
   } else {
-    if constexpr (WM * WN == 8) {
-      if (g_gemm_persist && g_gemm_glds == 1 && p.K % BK == 0 && nbatch == 1 && !p.dbg) {
-        static int ncu = 0;
-        if (!ncu) {
-          int dev = 0;
-          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        }
-        const int nb = p.tiles_m * p.tiles_n;
-        dim3 pgrid(nb < ncu ? nb : ncu, 1, 1);
-        hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, false, false, true>), pgrid, block, 0, st, p);
-        return check_launch("gemm16");
-      }
-    }
     if constexpr (WM * WN == 8 && AP == 1 && std::is_same<T, f16>::value) {
       if (g_gemm_stamp && g_gemm_glds == 1 && p.K % BK == 0) {
         hipLaunchKernelGGL((gemm16_kernel<T, BM, BN, BK, WM, WN, AP, WP, true, NS, false, true>), grid, block, 0, st, p);

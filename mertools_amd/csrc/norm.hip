@@ -7,6 +7,8 @@
 #include "common.h"
 
 namespace mer {
+int g_ln_nt = 0;   // mer_set_option("ln_nt", 1): LayerNorm streams its fp32 input with non-temporal loads
+
 
 template <typename T, int NV>
 struct RowLN {
@@ -82,7 +84,7 @@ struct RowLN {
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long long ldx, const float* gamma,
                                                         const float* beta, float eps, int M, int D, int act,
-                                                        float* out32, long long ld32, T* ohi, T* olo, long long ld16) {
+                                                        float* out32, long long ld32, T* ohi, T* olo, long long ld16, int nt) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63, nv4 = D >> 2;
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long lon
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int idx = lane + 64 * j;
-    v[j] = idx < nv4 ? *reinterpret_cast<const f32x4*>(xr + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // nt: the fp32 row is streamed (it is not read again before ~1 GB of other traffic has passed), so it should not push
+    // the 16-bit plane written here — the next GEMM's A operand — out of L2 / the Infinity Cache
+    if (idx < nv4) v[j] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + idx * 4)) : *reinterpret_cast<const f32x4*>(xr + idx * 4);
+    else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   RowLN<T, NV>::run(v, lane, nv4, D, gamma, beta, eps, act, out32 ? out32 + (long long)row * ld32 : nullptr,
                     ohi ? ohi + (long long)row * ld16 : nullptr, olo ? olo + (long long)row * ld16 : nullptr);
@@ -205,10 +210,10 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
   ProfScope prof("layernorm", 0.0, (double)M * D * (4 + (out32 ? 4 : 0) + (out16_hi ? 2 : 0) + (out16_lo ? 2 : 0)), st);
   if (dtype == MER_DT_F16) {
     MER_NV_SWITCH(nv, layernorm_kernel<f16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
-                                          act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16));
+                                          act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16, g_ln_nt));
   } else {
     MER_NV_SWITCH(nv, layernorm_kernel<bf16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
-                                          act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16));
+                                          act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16, g_ln_nt));
   }
   return check_launch("layernorm");
 }

@@ -81,3 +81,30 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, f"product files import the oracle: {bad}"
+
+
+def test_hot_kernels_use_no_scratch_memory():
+    """hipcc's per-kernel resource remarks (kept by mertools_amd.build next to the objects): the GEMM / attention / LayerNorm
+    kernels must not touch scratch (private) memory — a lambda that fails to inline, a dynamically indexed register array or a
+    spill puts the accumulators or the kernel arguments on the stack, which costs 2-10x and, inside the LDS-DMA pipelines with
+    their counted vmcnt waits, hung the GPU in round 2."""
+    import glob
+    import re
+    from mertools_amd import build as B
+    files = glob.glob(os.path.join(B.OBJ, "*.resources.txt"))
+    if not files:
+        pytest.skip("objects were built before the remarks were kept (python -m mertools_amd.build --force)")
+    seen = 0
+    for f in files:
+        name = None
+        for line in open(f):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and name and any(k in name for k in ("gemm16_kernel", "attn_sp_kernel", "attn_stream_kernel", "layernorm_kernel")):
+                seen += 1
+                # known exception: the 3-pass 256x256 kernel with the register-staged loader (K % 32 != 0 fallback) spills 8 VGPRs
+                fallback = "Li256ELi256ELi32ELi2ELi4ELi2ELi2ELb0E" in name
+                assert int(m.group(1)) <= (64 if fallback else 0), f"{name} uses {m.group(1)} bytes/lane of scratch ({os.path.basename(f)})"
+    assert seen >= 20, seen

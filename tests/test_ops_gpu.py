@@ -27,6 +27,8 @@ def _act_ref(x, act):
         return x * torch.sigmoid(1.702 * x)
     if act == "relu":
         return F.relu(x)
+    if act in ("gelu_new", "gelu_tanh"):
+        return F.gelu(x, approximate="tanh")
     return x
 
 
@@ -423,30 +425,47 @@ def test_image_normalize_u8_matches_clip_preprocess(dev):
     assert_close(out.cpu(), ref, 2e-6, "image_normalize_u8")
 
 
-@pytest.mark.parametrize("passes", [1, 2, 3])
-@pytest.mark.parametrize("M,N,K", [(10240, 2048, 256), (70000, 768, 96), (9000, 1100, 32)])
-def test_gemm16_persistent_tiles(dev, M, N, K, passes):
-    """mer_set_option("gemm_persist", 1): more 256x256 tiles than compute units, so workgroups walk several tiles and
-    prefetch the next tile's first slabs under the epilogue; results must equal the one-tile-per-workgroup kernel bit for bit."""
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(2304, 1536, 256), (1000, 776, 96), (70000, 768, 64), (515, 72, 32)])
+def test_gemm16_specialised_epilogues_equal_generic(dev, M, N, K, tile):
+    """The two specialised epilogues — packed row pairs + streaming stores for 16-bit-only outputs (gemm_pkepi), whole-line
+    4-columns-per-lane for fp32-only outputs with residual (gemm_epi32) — against the generic fp32-staged epilogue, bit for bit,
+    on every tile class, ragged M / N included; and the generic one against fp64."""
     from mertools_amd import _lib
     ops = _ops()
+    lib = _lib.lib()
     a = _rand((M, K), 71)
     w = _rand((N, K), 72) * 0.05
-    ah, al = ops.split16(a.to(dev), "f16")
-    wh, wl = ops.split16_host(w, "f16")
+    ah, _ = ops.split16(a.to(dev), "f16", lo=False)
+    wh = ops.split16_host(w, "f16")[0].to(dev)
     bias, res = _rand((N,), 73).to(dev), _rand((M, N), 74).to(dev)
-    kw = dict(a_lo=al if passes == 3 else None, w_lo=wl.to(dev) if passes >= 2 else None, bias=bias, act="gelu", residual=res, out32=True,
-              out16=True, passes=passes, tile=3)
-    ref32, ref16, _ = ops.gemm16(ah, wh.to(dev), **kw)
-    try:
-        _lib.lib().mer_set_option(b"gemm_persist", 1)
-        c32, c16, _ = ops.gemm16(ah, wh.to(dev), **kw)
+    z = a.double() @ w.double().T + bias.cpu().double()
+    for act in (None, "gelu", "quick_gelu", "gelu_new", "relu"):
+        kw16 = dict(bias=bias, act=act, out16=True, passes=1, tile=tile)
+        kw32 = dict(bias=bias, act=act, residual=res, out32=True, passes=1, tile=tile)
+        try:
+            lib.mer_set_option(b"gemm_pkepi", 0)
+            lib.mer_set_option(b"gemm_epi32", 0)
+            _, ref16, _ = ops.gemm16(ah, wh, **kw16)
+            ref32, _, _ = ops.gemm16(ah, wh, **kw32)
+        finally:
+            lib.mer_set_option(b"gemm_pkepi", 1)
+            lib.mer_set_option(b"gemm_epi32", 1)
+        _, c16, _ = ops.gemm16(ah, wh, **kw16)
+        c32, _, _ = ops.gemm16(ah, wh, **kw32)
+        inplace = res.clone()                                   # residual updated in place (the ABI allows residual == c32)
+        g = ops.GemmArgs()
+        g.M, g.N, g.K, g.dtype = M, N, K, ops.dt_code("f16")
+        g.a_hi, g.lda, g.w_hi, g.ldw = ah.data_ptr(), K, wh.data_ptr(), K
+        g.bias, g.act, g.residual, g.ldr, g.c32, g.ldc32 = bias.data_ptr(), ops.ACT[act], inplace.data_ptr(), N, inplace.data_ptr(), N
+        g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, 1, tile
+        ops.gemm16_raw(g)
         torch.cuda.synchronize()
-    finally:
-        _lib.lib().mer_set_option(b"gemm_persist", 0)
-    assert torch.equal(c32, ref32) and torch.equal(c16, ref16)
-    true = F.gelu(a.double() @ w.double().T + bias.cpu().double()) + res.cpu().double()
-    assert_close(c32.cpu(), true.float(), {1: 1e-3, 2: 5e-4, 3: 2e-5}[passes], "persistent gemm16 vs fp64")
+        assert torch.equal(c16, ref16), f"packed-pair epilogue differs from the generic one (act={act})"
+        assert torch.equal(c32, ref32) and torch.equal(inplace, ref32), f"fp32-only epilogue differs from the generic one (act={act})"
+        true = _act_ref(z, act or "none")
+        assert_close(ref16.float().cpu(), true.float(), 1.5e-3, f"generic 16-bit epilogue vs fp64 (act={act})")
+        assert_close(ref32.cpu(), (true + res.cpu().double()).float(), 1e-3, f"generic fp32 epilogue vs fp64 (act={act})")
 
 
 @pytest.mark.parametrize("passes", [1, 2, 3, 4])
