@@ -677,31 +677,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       if (more) wait_vmcnt<LPS*(D - 1)>();
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (MX) {
+        // The bf8 copies are made HERE, at the end of the LOAD phase (the fragments have just landed), not in the MATH phase: LOAD is
+        // the shorter phase of the MX loop (570 vs 745 cycles per plain slab), and every VALU instruction beside
+        // the MFMAs of the MATH phase costs ~5 cycles of matrix-pipe time.
+      // 8 f16 -> 8 bf8 (RNE) per 16-row tile; the group's window shifts by one slab (oldest slab in dwords 0-1) so that
+      // one loop body serves all four slab positions.  Tried and measured worse or spilling: the 4x-unrolled loop with
+      // static indices (21 spills), per-position uniform branches (the conversions get hoisted into temporaries + 16
+      // copies), in-place inline-asm conversions (16 copies), a 64-bit window (the whole window gets copied).
+      {
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+          const v8 a = af[0][mt];
+          i16x2 r0, r1;   // both halves get written below (deliberately uninitialised: no false dependency on the window)
+          asm volatile("" : "=v"(r0), "=v"(r1));
+          r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[0], a[1]}, 1.0f, false);
+          r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[2], a[3]}, 1.0f, true);
+          r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[4], a[5]}, 1.0f, false);
+          r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[6], a[7]}, 1.0f, true);
+          // 64-bit window elements: the shift is three v_mov_b64 per tile instead of six v_mov_b32
+          aq[mt] = i64x4{aq[mt][1], aq[mt][2], aq[mt][3],
+                         __builtin_bit_cast(long long, i32x2{__builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)})};
+        }
+      }
+        __builtin_amdgcn_sched_barrier(0);   // keep the conversions on this side of the barrier
+      }
       if (STAMP) tL = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
       if (STAMP) tB1 = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_setprio(1);
       math();
       if constexpr (MX) {
-        // 8 f16 -> 8 bf8 (RNE) per 16-row tile; the group's window shifts by one slab (oldest slab in dwords 0-1) so that
-        // one loop body serves all four slab positions.  Tried and measured worse or spilling: the 4x-unrolled loop with
-        // static indices (21 spills), per-position uniform branches (the conversions get hoisted into temporaries + 16
-        // copies), in-place inline-asm conversions (16 copies), a 64-bit window (the whole window gets copied).
-        {
-#pragma unroll
-          for (int mt = 0; mt < TM; ++mt) {
-            const v8 a = af[0][mt];
-            i16x2 r0, r1;   // both halves get written below (deliberately uninitialised: no false dependency on the window)
-            asm volatile("" : "=v"(r0), "=v"(r1));
-            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[0], a[1]}, 1.0f, false);
-            r0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r0, f16x2{a[2], a[3]}, 1.0f, true);
-            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[4], a[5]}, 1.0f, false);
-            r1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(r1, f16x2{a[6], a[7]}, 1.0f, true);
-            // 64-bit window elements: the shift is three v_mov_b64 per tile instead of six v_mov_b32
-            aq[mt] = i64x4{aq[mt][1], aq[mt][2], aq[mt][3],
-                           __builtin_bit_cast(long long, i32x2{__builtin_bit_cast(int, r0), __builtin_bit_cast(int, r1)})};
-          }
-        }
         if (mx_slab) {   // the group's fp4 residual fragments straight from the group buffer, one column tile at a time
           // two column tiles ahead (the LDS is busy with the other wave group's fragment reads: one tile ahead stalled),
           // no further: the compiler would otherwise pull all 8 reads to the top (32 live registers the kernel lacks)
