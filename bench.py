@@ -373,13 +373,13 @@ def main():
         dom = max(recs.values(), key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh -> profiles/*pmc_hbm_traffic*.json).
-        # A stored figure is only quoted when it was collected on THIS kernel source (sha of csrc/gemm16_impl.h + gemm16.hip stamped by
+        # A stored figure is only quoted when it was collected on THIS kernel source (sha of csrc/gemm16_impl.h stamped by
         # scripts/pmc_summarize.py); otherwise traffic is null and the note says why.
         traffic, traffic_detail = None, None
         import glob
         import hashlib
         hsh = hashlib.sha256()
-        for f in ("gemm16_impl.h", "gemm16.hip"):
+        for f in ("gemm16_impl.h",):   # the kernel template itself (gemm16.hip only holds the C ABI and the option table)
             hsh.update(open(os.path.join(ROOT, "mertools_amd", "csrc", f), "rb").read())
         sha = hsh.hexdigest()[:16]
         prefix = {"gemm16": "gemm16<f16,256,256,32,2,4,1,1,", "gemm16_mx": "gemm16<f16,256,256,32,4,2,1,1,", "gemm16_w2": "gemm16<f16,256,256,32,2,4,1,2,"}.get(dom["name"])

@@ -22,6 +22,7 @@ namespace mer {
 
 extern unsigned long long* g_gemm_dbg;
 int g_attn_waves = 8;      // mer_set_option("attn_waves", 4): 4-wave workgroups for every T (A/B testing)
+int g_attn_stream_qs = 2;  // mer_set_option("attn_stream_qs", 1): the streaming kernel with one 16-query sub-tile per wave (A/B testing)
 int g_attn_nt = 0;         // mer_set_option("attn_nt", 1): K / V staging with non-temporal loads
 int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
 
@@ -219,11 +220,14 @@ __global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ 
   if (dbg && tid == 0) dbg[dbi + 2] = __builtin_amdgcn_s_memtime();
 }
 
-// Streaming (online-softmax) kernel for T > 512 (VideoMAE: 1568 tokens).  One workgroup = (batch, head, 64
+// Streaming (online-softmax) kernel for T > 512 (VideoMAE: 1568 tokens).  One workgroup = (batch, head, 64 * QS
 // queries); keys/values are walked in blocks of 64 through LDS.  Same swapped-operand trick as above: a lane owns one
 // query, so the running max m / normaliser l and the rescale factor are per-lane scalars and apply directly to the
 // lane's O^T accumulator columns (HF:videomae/modeling_videomae.py eager_attention_forward).
-template <typename T>
+// QS = 16-query sub-tiles per wave: with QS = 2 every K fragment (ds_read_b128) and every V^T fragment (two transpose reads)
+// pulled out of LDS feeds two MFMAs, and a key block staged through LDS serves 128 queries — half the L2 -> LDS staging
+// traffic and half the LDS reads per FLOP of the QS = 1 form (which staged 401 KB of K / V per head 25 times at T = 1568).
+template <typename T, int QS>
 __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                           long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm) {
@@ -247,15 +251,21 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
   const T* kb = k + hbase;
   const T* vb = v + hbase;
   const T* qb = q + hbase;
-  const int qi = qt * 64 + wave * 16 + li;
-  const int qrow = qi < Tn ? qi : Tn - 1;
-  v8 qf[2];
+  int qi[QS];
+  v8 qf[QS][2];
+  f32x4 o[QS][4];
+  float m[QS], lsum[QS];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const v8*>(qb + (long long)qrow * ld + kk * 32 + lg * 8);
-  f32x4 o[4];
+  for (int u = 0; u < QS; ++u) {
+    qi[u] = (qt * 4 + wave) * (16 * QS) + u * 16 + li;
+    const int qrow = qi[u] < Tn ? qi[u] : Tn - 1;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, lsum = 0.f;
+    for (int kk = 0; kk < 2; ++kk) qf[u][kk] = *reinterpret_cast<const v8*>(qb + (long long)qrow * ld + kk * 32 + lg * 8);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[u] = -INFINITY;
+    lsum[u] = 0.f;
+  }
   for (int k0 = 0; k0 < klen; k0 += KB) {
     __syncthreads();  // previous block fully consumed
     for (int c = tid; c < KB * 8; c += 256) {
@@ -269,51 +279,61 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
       *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vv;
     }
     __syncthreads();
-    f32x4 s[4];
-    float bmax = -INFINITY;
+    f32x4 s[QS][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QS; ++u) s[u][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const v8 kf = *reinterpret_cast<const v8*>(Ks + (kt * 16 + li) * KS + kk * 32 + lg * 8);
-        a = T16<T>::mfma(kf, qf[kk], a);
-      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + kt * 16 + lg * 4 + r;
-        a[r] = key < klen ? a[r] * scale_log2e : -INFINITY;
-        bmax = fmaxf(bmax, a[r]);
+        for (int u = 0; u < QS; ++u) s[u][kt] = T16<T>::mfma(kf, qf[u][kk], s[u][kt]);
       }
-      s[kt] = a;
     }
-    bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
-    bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
-    const float mnew = fmaxf(m, bmax);                 // finite: every block holds at least one unmasked key
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);  // first block: exp2(-inf) = 0
-    m = mnew;
-    float psum = 0.f;
+    float alpha[QS];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int u = 0; u < QS; ++u) {
+      float bmax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pe = __builtin_amdgcn_exp2f(s[kt][r] - mnew);
-        s[kt][r] = pe;
-        psum += pe;
-      }
-    lsum = lsum * alpha + psum;  // per-lane partial of the query's normaliser (4 lanes share a query and its alpha)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + kt * 16 + lg * 4 + r;
+          const float x = key < klen ? s[u][kt][r] * scale_log2e : -INFINITY;
+          s[u][kt][r] = x;
+          bmax = fmaxf(bmax, x);
+        }
+      bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
+      bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
+      const float mnew = fmaxf(m[u], bmax);                 // finite: every block holds at least one unmasked key
+      alpha[u] = __builtin_amdgcn_exp2f(m[u] - mnew);      // first block: exp2(-inf) = 0
+      m[u] = mnew;
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pe = __builtin_amdgcn_exp2f(s[u][kt][r] - mnew);
+          s[u][kt][r] = pe;
+          psum += pe;
+        }
+      lsum[u] = lsum[u] * alpha[u] + psum;  // per-lane partial of the query's normaliser (4 lanes share a query and its alpha)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha[u];
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      v8 pf;
+      v8 pf[QS];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pf[j] = T16<T>::from_f32(s[2 * c][j]);
-        pf[4 + j] = T16<T>::from_f32(s[2 * c + 1][j]);
-      }
+      for (int u = 0; u < QS; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pf[u][j] = T16<T>::from_f32(s[u][2 * c][j]);
+          pf[u][4 + j] = T16<T>::from_f32(s[u][2 * c + 1][j]);
+        }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const T* vr = Vs + ((2 * c) * 16 + lg * 4 + (li >> 2)) * KS + dt * 16 + (li & 3) * 4;
@@ -325,27 +345,32 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
           vf[j] = v0[j];
           vf[4 + j] = v1[j];
         }
-        o[dt] = T16<T>::mfma(vf, pf, o[dt]);
+#pragma unroll
+        for (int u = 0; u < QS; ++u) o[u][dt] = T16<T>::mfma(vf, pf[u], o[u][dt]);
       }
     }
   }
-  lsum += __shfl_xor(lsum, 16);
-  lsum += __shfl_xor(lsum, 32);
-  const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-  if (qi < Tn) {
-    const long long orow = (row0 + qi) * ldo + h * 64;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      v4 hh, ll;
+  for (int u = 0; u < QS; ++u) {
+    float l = lsum[u];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (qi[u] < Tn) {
+      const long long orow = (row0 + qi[u]) * ldo + h * 64;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        T a, c;
-        split16<T>(o[dt][r] * inv, a, c);
-        hh[r] = a;
-        ll[r] = c;
+      for (int dt = 0; dt < 4; ++dt) {
+        v4 hh, ll;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T a, c;
+          split16<T>(o[u][dt][r] * inv, a, c);
+          hh[r] = a;
+          ll[r] = c;
+        }
+        *reinterpret_cast<v4*>(oh + orow + dt * 16 + lg * 4) = hh;
+        if (ol) *reinterpret_cast<v4*>(ol + orow + dt * 16 + lg * 4) = ll;
       }
-      *reinterpret_cast<v4*>(oh + orow + dt * 16 + lg * 4) = hh;
-      if (ol) *reinterpret_cast<v4*>(ol + orow + dt * 16 + lg * 4) = ll;
     }
   }
 }
@@ -401,9 +426,15 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   else if (Tn <= 288) MER_ATTN_CASE(18);
   else if (Tn <= 512) MER_ATTN_CASE(32);
   else {
-    dim3 sgrid((unsigned)cdiv(Tn, 64), H, B);
-    hipLaunchKernelGGL((attn_stream_kernel<T>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
-                       ldo, Tn, sl2, kv_len, hm);
+    if (g_attn_stream_qs >= 2) {   // 128 queries per workgroup (two 16-query sub-tiles per wave)
+      dim3 sgrid((unsigned)cdiv(Tn, 128), H, B);
+      hipLaunchKernelGGL((attn_stream_kernel<T, 2>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
+                         ldo, Tn, sl2, kv_len, hm);
+    } else {
+      dim3 sgrid((unsigned)cdiv(Tn, 64), H, B);
+      hipLaunchKernelGGL((attn_stream_kernel<T, 1>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
+                         ldo, Tn, sl2, kv_len, hm);
+    }
   }
 #undef MER_ATTN_CASE
   return check_launch("attention");
