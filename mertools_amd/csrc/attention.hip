@@ -23,6 +23,7 @@ namespace mer {
 extern unsigned long long* g_gemm_dbg;
 int g_attn_waves = 8;      // mer_set_option("attn_waves", 4): 4-wave workgroups for every T (A/B testing)
 int g_attn_stream_qs = 2;  // mer_set_option("attn_stream_qs", 1): the streaming kernel with one 16-query sub-tile per wave (A/B testing)
+int g_attn_stream_pf = 1;  // mer_set_option("attn_stream_pf", 0): no register prefetch of the next key block
 int g_attn_nt = 0;         // mer_set_option("attn_nt", 1): K / V staging with non-temporal loads
 int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
 
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ 
 // QS = 16-query sub-tiles per wave: with QS = 2 every K fragment (ds_read_b128) and every V^T fragment (two transpose reads)
 // pulled out of LDS feeds two MFMAs, and a key block staged through LDS serves 128 queries — half the L2 -> LDS staging
 // traffic and half the LDS reads per FLOP of the QS = 1 form (which staged 401 KB of K / V per head 25 times at T = 1568).
-template <typename T, int QS>
+template <typename T, int QS, bool PF>
 __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                           long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm) {
@@ -266,19 +267,36 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
     m[u] = -INFINITY;
     lsum[u] = 0.f;
   }
+  // register prefetch: the next key block's global loads are issued before this block's MFMAs and land in LDS after them
+  // (KB * 8 = 512 16-byte chunks per operand = 2 per thread and operand), so the L2 round trip overlaps the compute
+  constexpr int PER = KB * 8 / 256;
+  u32x4 kreg[PER], vreg[PER];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int c = tid + it * 256;
+      const int row = c >> 3, ch = c & 7;
+      kreg[it] = u32x4{0u, 0u, 0u, 0u};
+      vreg[it] = u32x4{0u, 0u, 0u, 0u};
+      if (k0 + row < klen) {
+        kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)(k0 + row) * ld + ch * 8);
+        vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)(k0 + row) * ld + ch * 8);
+      }
+    }
+  };
+  if (PF) fetch(0);
   for (int k0 = 0; k0 < klen; k0 += KB) {
     __syncthreads();  // previous block fully consumed
-    for (int c = tid; c < KB * 8; c += 256) {
+    if (!PF) fetch(k0);
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int c = tid + it * 256;
       const int row = c >> 3, ch = c & 7;
-      u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-      if (k0 + row < klen) {
-        kv = *reinterpret_cast<const u32x4*>(kb + (long long)(k0 + row) * ld + ch * 8);
-        vv = *reinterpret_cast<const u32x4*>(vb + (long long)(k0 + row) * ld + ch * 8);
-      }
-      *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kv;
-      *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vv;
+      *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kreg[it];
+      *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vreg[it];
     }
     __syncthreads();
+    if (PF && k0 + KB < klen) fetch(k0 + KB);
     f32x4 s[QS][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -426,15 +444,18 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   else if (Tn <= 288) MER_ATTN_CASE(18);
   else if (Tn <= 512) MER_ATTN_CASE(32);
   else {
-    if (g_attn_stream_qs >= 2) {   // 128 queries per workgroup (two 16-query sub-tiles per wave)
-      dim3 sgrid((unsigned)cdiv(Tn, 128), H, B);
-      hipLaunchKernelGGL((attn_stream_kernel<T, 2>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
-                         ldo, Tn, sl2, kv_len, hm);
-    } else {
-      dim3 sgrid((unsigned)cdiv(Tn, 64), H, B);
-      hipLaunchKernelGGL((attn_stream_kernel<T, 1>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol,
-                         ldo, Tn, sl2, kv_len, hm);
-    }
+    // QS = 16-query sub-tiles per wave (64 * QS queries per workgroup), PF = register prefetch of the next key block
+#define MER_ATTN_STREAM(QS_, PF_)                                                                                          \
+  do {                                                                                                                     \
+    dim3 sgrid((unsigned)cdiv(Tn, 64 * QS_), H, B);                                                                        \
+    hipLaunchKernelGGL((attn_stream_kernel<T, QS_, PF_>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
+                       (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm);                                                          \
+  } while (0)
+    if (g_attn_stream_qs >= 2 && g_attn_stream_pf) MER_ATTN_STREAM(2, true);
+    else if (g_attn_stream_qs >= 2) MER_ATTN_STREAM(2, false);
+    else if (g_attn_stream_pf) MER_ATTN_STREAM(1, true);
+    else MER_ATTN_STREAM(1, false);
+#undef MER_ATTN_STREAM
   }
 #undef MER_ATTN_CASE
   return check_launch("attention");
