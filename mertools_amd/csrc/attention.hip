@@ -23,7 +23,7 @@ namespace mer {
 extern unsigned long long* g_gemm_dbg;
 int g_attn_waves = 8;      // mer_set_option("attn_waves", 4): 4-wave workgroups for every T (A/B testing)
 int g_attn_stream_qs = 2;  // mer_set_option("attn_stream_qs", 1): the streaming kernel with one 16-query sub-tile per wave (A/B testing)
-int g_attn_stream_pf = 1;  // mer_set_option("attn_stream_pf", 0): no register prefetch of the next key block
+int g_attn_stream_pf = 0;  // mer_set_option("attn_stream_pf", 1): register prefetch of the next key block (measured slower at QS = 2: 487 vs 507 TF — the 28 extra VGPRs cost a resident wave per SIMD)
 int g_attn_nt = 0;         // mer_set_option("attn_nt", 1): K / V staging with non-temporal loads
 int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
 
