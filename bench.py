@@ -62,9 +62,10 @@ def parse():
     ap.add_argument("--config", default="base", choices=sorted(CONFIGS), help="base = BASELINE configs[3] (the headline metric); large = configs[4]")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="16-bit MFMA operand type; bf16 has no MX kernel: use --precision accurate (3 passes) for parity")
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
-    ap.add_argument("--precision", default="mx", choices=["fast", "balanced", "mx", "accurate"],
+    ap.add_argument("--precision", default="mx", choices=["fast", "balanced", "mx", "mean", "accurate"],
                     help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo f16 planes, meets 1e-3 parity), mx=1 + MX-fp4 "
-                         "correction of the weight residual (default: same parity as balanced, cheaper), accurate=3")
+                         "correction of the weight residual, mean=1 + the weight residual applied to each sequence's mean token "
+                         "(a per-sequence bias table; same parity, < 1 %% extra work), accurate=3")
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--split", type=int, default=1, help="run each modality's batch as this many sub-batches on their own HIP streams "
                                                            "(kernels of one sub-batch fill the partial last wave of workgroups of the other)")

@@ -106,8 +106,21 @@ typedef struct {
    * ceil(M/256)*256 * N elements; N % 32 == 0); a_blocked != 0 reads a_hi in that form (K = the producer's N; only the
    * 256x256 one-/two-pass kernels: M >= 1024, N >= 192, K % 32 == 0, no batching — anything else is MER_ESHAPE). */
   int c16_blocked; int a_blocked;
+  /* bias_seg_rows > 0: `bias` is a per-segment table fp32 [ceil(M / bias_seg_rows), bias_ld] (bias_ld >= N, bias_ld % 4 == 0,
+   * 16-byte aligned) and row m adds bias[(m / bias_seg_rows) * bias_ld + n] — how the one-pass GEMM takes its weight-residual
+   * correction: table = bias + mean_rows(A of the segment) * (W - f16(W))^T, see mer_seg_mean16.  bias_seg_rows >= 4; not with batching. */
+  int bias_seg_rows; long long bias_ld;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
+
+/* Per-segment mean rows of a 16-bit activation plane: out[s, :] = mean over j of a[row(s * seg_rows + j * stride), 0..K) for
+ * j * stride < (valid_rows ? valid_rows[s] : seg_rows), rows addressed like mer_gemm16's A operand (a_rows_per_batch /
+ * a_batch_stride / lda; <= 0 -> plain row-major), accumulated in fp32, written as a 16-bit plane [nseg, ldo].  The rounding
+ * error of a weight matrix is the same perturbation for every token, so what it does to a clip's features goes almost entirely
+ * through the clip's MEAN activation (tests/studies/mean_correction.py: the per-clip mean — even of every 8th token — recovers
+ * the accuracy of the full second MFMA pass); mean * (W - f16(W))^T is a [nseg, N] GEMM, added as a per-segment bias. */
+int mer_seg_mean16(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
+                   int seg_rows, int stride, const int* valid_rows, void* out16, long long ldo, mer_stream_t stream);
 
 /* Pre-blocked weight plane: a DEVICE 16-bit plane w [N, K] (row stride ldw, K % 32 == 0) is re-laid as
  * [ceil(N/256)][K/32] blocks of 16 KB, each the exact LDS image (256 rows x 64 B, 16-byte chunks XOR-swizzled) of

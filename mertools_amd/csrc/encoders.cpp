@@ -49,9 +49,21 @@ struct HsMap {
 // the K = ffn GEMM, whose A traffic dominates: ceiling probe -15 % on CLIP's fc2).  Off by default until measured end to end.
 int g_tf_ablk = 0;
 
+// passes == 5: ONE f16 MFMA pass + the weight-rounding residual applied to the segment's MEAN activation only:
+//   table[s, :] = bias + mean_rows(A of segment s, every MEAN_STRIDE-th row) * (W - f16(W))^T     (a [nseg, N] GEMM on the `lo` plane)
+//   C = epi(A * f16(W)^T + table[row / seg_rows, :])
+// `mc` carries the segment geometry and two small scratch planes; without it (or without a `lo` plane) 5 degrades to 4 / 2.
+struct MeanCorr {
+  int seg_rows;          // rows per segment (tokens of a sequence / frame); 0 = not available
+  const int* valid;      // device int32 [nseg]: valid rows per segment (ragged batches) or NULL
+  void* mean16;          // [nseg, Kmax] 16-bit
+  float* table;          // [nseg, Nmax] fp32
+};
+constexpr int MEAN_STRIDE = 8;
+
 static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 a, long long lda, const mer_w16& w,
                 const float* bias, int act, const float* residual, long long ldr, float* c32, long long ldc32, P16 c16,
-                long long ldc16, int c16_blocked = 0, int a_blocked = 0) {
+                long long ldc16, int c16_blocked = 0, int a_blocked = 0, const MeanCorr* mc = nullptr) {
   mer_gemm16_args g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
@@ -62,6 +74,29 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
   g.c16_blocked = c16_blocked; g.a_blocked = a_blocked;
+  if (passes == 5) {
+    const bool ok = mc && mc->seg_rows >= 4 && w.lo && !a_blocked && N % 8 == 0 && K % 8 == 0;
+    if (!ok) {
+      g.passes = (w.mx || w.lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
+    } else {
+      const int nseg = (M + mc->seg_rows - 1) / mc->seg_rows;
+      int rc = mer_seg_mean16(a.hi, dtype, lda, 0, 0, M, K, mc->seg_rows, MEAN_STRIDE, mc->valid, mc->mean16, K, (mer_stream_t)st);
+      if (rc != MER_OK) return rc;
+      mer_gemm16_args t;
+      memset(&t, 0, sizeof(t));
+      t.M = nseg; t.N = N; t.K = K; t.dtype = dtype;
+      t.a_hi = mc->mean16; t.lda = K;
+      t.w_hi = w.lo; t.ldw = K;            // the residual plane f16(W - f16(W)) as the (only) weight operand
+      t.bias = bias; t.act = MER_ACT_NONE;
+      t.c32 = mc->table; t.ldc32 = N;
+      t.nbatch = 1; t.nb_inner = 1; t.passes = 1; t.tile = 0;
+      rc = mer_gemm16(&t, (mer_stream_t)st);
+      if (rc != MER_OK) return rc;
+      g.passes = 1;
+      g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
+      g.bias = mc->table; g.bias_seg_rows = mc->seg_rows; g.bias_ld = N;
+    }
+  }
   return mer_gemm16(&g, (mer_stream_t)st);
 }
 
@@ -78,9 +113,11 @@ struct TfBufs {
   float* ffn32;    // SwiGLU: fp32 [M, 2F] output of weights_in awaiting the gate
   float* gate;     // WavLM: [B, H, T] gate of the current layer
   float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
+  void* mean16;    // passes == 5: [nseq, max(D, F)] segment means (16-bit)
+  float* table;    // passes == 5: [nseq, max(3D, F)] per-segment bias table
 };
 
-static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
+static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b, long long nseq = 0) {
   const bool lo = c.passes == 3;
   const long long D = c.hidden, F = c.ffn;
   b.t32 = (float*)ar.take(M * D * 4);
@@ -93,6 +130,9 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
   b.ffn32 = c.ffn_swiglu ? (float*)ar.take(M * 2 * F * 4) : nullptr;
   b.gate = c.gated_rel_pos ? (float*)ar.take(M * c.heads * 4) : nullptr;
   b.gin32 = (c.gated_rel_pos && c.pre_ln) ? (float*)ar.take(M * D * 4) : nullptr;
+  const long long wide = F > 3 * D ? F : 3 * D;
+  b.mean16 = (c.passes == 5 && nseq > 0) ? ar.take(nseq * wide * 2) : nullptr;
+  b.table = (c.passes == 5 && nseq > 0) ? (float*)ar.take(nseq * wide * 4) : nullptr;
 }
 
 // Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
@@ -101,12 +141,16 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                       TfBufs& b, const int* kv_len, const float* pos_bias = nullptr, long long ldb = 0) {
   const int M = Bseq * T, D = c.hidden, F = c.ffn, H = c.heads;
   const int dt = c.dtype, ps = c.passes;
-  const int ps1 = (ps == 4 && (c.mx_skip & 2)) ? 1 : ps;   // fc1 without the correction
-  const int ps2 = (ps == 4 && (c.mx_skip & 4)) ? 1 : ps;   // fc2 without the correction
+  const bool sel = ps == 4 || ps == 5;                      // presets with a selective weight-residual correction (mx_skip)
+  const int ps1 = (sel && (c.mx_skip & 2)) ? 1 : ps;       // fc1 without the correction
+  const int ps2 = (sel && (c.mx_skip & 4)) ? 1 : ps;       // fc2 without the correction
+  // passes == 5: the correction goes through each sequence's mean token (gemm() above); a sequence = T rows, kv_len = its valid rows
+  const MeanCorr mcv = {T, kv_len, b.mean16, b.table};
+  const MeanCorr* mc = (ps == 5 && b.mean16) ? &mcv : nullptr;
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
   // blocked fc1 -> fc2 plane: only where fc2 runs the 256x256 one-/two-pass kernel (same test as mer_gemm16's tile choice)
-  const int ablk = (g_tf_ablk && !c.ffn_swiglu && ps != 3 && (ps2 == 1 || ps2 == 2) && M >= 1024 && D >= 192 && F % 32 == 0) ? 1 : 0;
+  const int ablk = (g_tf_ablk && !c.ffn_swiglu && ps != 3 && (ps2 == 1 || ps2 == 2) && M >= 1024 && D >= 192 && F % 32 == 0) ? 1 : 0;   // (not with passes 5)
   for (int l = 0; l < c.layers; ++l) {
     const mer_tf_layer& w = L[l];
     float* x = hs.at(l);
@@ -115,21 +159,21 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
       MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.gin32, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
-    if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx) {
+    if (sel && (c.mx_skip & 1) && (2 * D) % 256 == 0 && (ps == 4 ? w.wqkv.mx != nullptr : w.wqkv.lo != nullptr)) {
       // Q | K columns: one f16 pass (weight rounding there only perturbs softmax logits: no measurable effect on the features);
       // V columns: MX-corrected.  The MX plane is stored per 256-column tile, so the V block starts at tile 2D/256.
       const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr};
       MER_TRY(gemm(st, dt, 1, M, 2 * D, D, b.cur16, D, wqk, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
       const long long woff = (long long)2 * D * D * 2;   // bytes into the 16-bit planes
       const mer_w16 wv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
-                          (const char*)w.wqkv.mx + (long long)(2 * D / 256) * (D / 32) * 5120,
+                          w.wqkv.mx ? (const char*)w.wqkv.mx + (long long)(2 * D / 256) * (D / 32) * 5120 : nullptr,
                           // the pre-blocked planes are stored per 256-row tile as well: tile 2D/256 starts woff bytes in
                           w.wqkv.hi_blk ? (const char*)w.wqkv.hi_blk + woff : nullptr,
                           w.wqkv.lo_blk ? (const char*)w.wqkv.lo_blk + woff : nullptr};
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
-      MER_TRY(gemm(st, dt, 4, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D));
+      MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, 0, 0, mc));
     } else
-    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
+    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D, 0, 0, mc));
     const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
     if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
       const float* gate = nullptr;
@@ -142,19 +186,19 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     } else
     MER_TRY(mer_attention(b.qkv16.hi, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
                           b.ctx16.hi, b.ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, st));
-    MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0));
+    MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0, 0, 0, mc));
     if (c.pre_ln) {
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.h1_16.hi, b.h1_16.lo, D, dt, st));
       if (c.ffn_swiglu) {  // weights_in -> fp32 [M, 2F]; silu(first half) * second half -> 16-bit planes [M, F]
-        MER_TRY(gemm(st, dt, ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0));
+        MER_TRY(gemm(st, dt, ps1 == 5 ? 4 : ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0));
         MER_TRY(mer_swiglu(b.ffn32, 2 * F, M, F, b.f16.hi, b.f16.lo, dt, (mer_stream_t)st));
       } else
-      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0));
-      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0, 0, ablk));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0, mc));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0, 0, ablk, mc));
     } else {
       MER_TRY(mer_layernorm(b.t32, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.h1_32, D, b.h1_16.hi, b.h1_16.lo, D, dt, st));
-      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0));
-      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0, 0, ablk));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0, mc));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0, 0, ablk, mc));
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, y, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     }
   }
@@ -165,7 +209,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.hidden > 0 && c.heads > 0 && c.hidden % c.heads == 0, MER_EINVAL, "%s: bad hidden/heads", who);
   MER_REQUIRE(c.hidden / c.heads == 64, MER_EUNSUPPORTED, "%s: head_dim %d != 64 unsupported", who, c.hidden / c.heads);
   MER_REQUIRE(c.hidden % 8 == 0 && c.ffn % 8 == 0, MER_ESHAPE, "%s: hidden/ffn must be multiples of 8", who);
-  MER_REQUIRE(c.passes >= 1 && c.passes <= 4, MER_EINVAL, "%s: passes must be 1, 2, 3 or 4 (MX-corrected)", who);
+  MER_REQUIRE(c.passes >= 1 && c.passes <= 5, MER_EINVAL, "%s: passes must be 1, 2, 3, 4 (MX-corrected) or 5 (mean-corrected)", who);
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
   MER_REQUIRE(c.gated_rel_pos == 0 || c.gated_rel_pos == 1, MER_EINVAL, "%s: gated_rel_pos must be 0 or 1", who);
   MER_REQUIRE(c.mx_skip >= 0 && c.mx_skip <= 7, MER_EINVAL, "%s: mx_skip must be a 3-bit mask", who);
@@ -271,7 +315,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   p.pospack = take16(ar, (long long)B * (Tn + c.pos_k) * D, clo);
   p.posbuf = c.pos_layers > 0 ? (float*)ar.take(M * D * 4) : nullptr;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
-  tf_plan(ar, c.tf, M, p.tf);
+  tf_plan(ar, c.tf, M, p.tf, B);
   return ar.off;
 }
 
@@ -475,7 +519,7 @@ static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   p.x = (float*)ar.take(N * (P + 1) * D * 4);
   p.cls16 = take16(ar, (long long)N * D, lo);
   p.feats = (float*)ar.take((long long)N * c.proj_dim * 4);
-  tf_plan(ar, c.tf, N * (P + 1), p.tf);
+  tf_plan(ar, c.tf, N * (P + 1), p.tf, N);
   return ar.off;
 }
 
@@ -572,7 +616,7 @@ static long long vmae_plan(const mer_videomae* h, Arena& ar, int B, VmaePlan& p)
   const long long cols = (long long)c.channels * c.tubelet_size * c.patch_size * c.patch_size;
   p.patches = take16(ar, B * NP * cols, c.tf.passes == 3);
   p.x = (float*)ar.take(B * NP * D * 4);
-  tf_plan(ar, c.tf, B * NP, p.tf);
+  tf_plan(ar, c.tf, B * NP, p.tf, B);
   return ar.off;
 }
 extern "C" long long mer_videomae_workspace_bytes(const mer_videomae* h, int B) {
@@ -649,7 +693,7 @@ static long long bert_plan(const mer_bert* h, Arena& ar, int B, int T, bool want
   const int E = h->cfg.emb_dim;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
   p.emb16 = (E > 0 && E != D) ? take16(ar, M * E, h->cfg.tf.passes == 3) : P16{nullptr, nullptr};
-  tf_plan(ar, h->cfg.tf, M, p.tf);
+  tf_plan(ar, h->cfg.tf, M, p.tf, B);
   return ar.off;
 }
 extern "C" long long mer_bert_workspace_bytes(const mer_bert* h, int B, int T, int want_hidden_states) {

@@ -42,6 +42,7 @@ struct Gemm16Params {
   int a_blk;          // a_hi is a blocked activation plane written by a producer GEMM with c16_blk (same block geometry, rows = M)
   int c16_blk;        // > 0: the 16-bit output is written blocked for a consumer with K = N: value = N / 32 (k-slabs per row tile)
   const float* bias; int act;
+  int bias_seg; long long bias_ld;   // bias_seg > 0: bias is a table fp32 [ceil(M / bias_seg), bias_ld]: row m adds bias[(m / bias_seg) * bias_ld + n]
   const float* residual; long long ldr;
   float* c32; long long ldc32;
   void* c16_hi; void* c16_lo; long long ldc16;
@@ -380,9 +381,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const int col = n0 + wn * SN + c8 * CPL;
   const bool col_ok = col < p.N;
   const float* bias = p.bias ? p.bias + (long long)zi * p.bias_si : nullptr;
-  float bv[CPL];
+  // the static bias of this lane's 8 columns, as two vector registers (a float[8] that is later re-read as vectors ends up in scratch)
+  f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
+  if (bias && p.bias_seg == 0) {
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) bv[j] = (bias && col + j < p.N) ? bias[col + j] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      bv0[j] = col + j < p.N ? bias[col + j] : 0.f;
+      bv1[j] = col + 4 + j < p.N ? bias[col + 4 + j] : 0.f;
+    }
+  }
   const float* res = p.residual ? p.residual + c_boff : nullptr;
   float* c32 = p.c32 ? p.c32 + c_boff : nullptr;
   T* c16h = p.c16_hi ? (T*)p.c16_hi + c_boff : nullptr;
@@ -431,10 +438,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL);
           const f32x4 a1 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL + 4);
           float v[CPL];
+          f32x4 b0 = bv0, b1 = bv1;
+          if (p.bias_seg > 0) {   // per-segment bias table (one-pass GEMM + segment-mean weight-residual correction)
+            const float* bp = bias + (long long)(row / p.bias_seg) * p.bias_ld + col;
+            b0 = *reinterpret_cast<const f32x4*>(bp);
+            b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            v[j] = act_apply(a0[j] + bv[j], ACT);
-            v[4 + j] = act_apply(a1[j] + bv[4 + j], ACT);
+            v[j] = act_apply(a0[j] + b0[j], ACT);
+            v[4 + j] = act_apply(a1[j] + b1[j], ACT);
           }
           if (res) {
 #pragma unroll
@@ -478,7 +491,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           if (row >= p.M || !col_ok) continue;
           for (int j = 0; j < CPL; ++j) {
             if (col + j >= p.N) break;
-            float x = act_apply(ct[lr * CLD + c8 * CPL + j] + bv[j], ACT);
+            const float bsc = !bias ? 0.f : (p.bias_seg > 0 ? bias[(long long)(row / p.bias_seg) * p.bias_ld + col + j] : bias[col + j]);
+            float x = act_apply(ct[lr * CLD + c8 * CPL + j] + bsc, ACT);
             if (res) x += res[(long long)row * p.ldr + col + j];
             if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
             if (c16h) {
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
       const int c = n0 + wn * SN + nt * 16 + li;
-      bcol[nt] = (bias && c < p.N) ? bias[c] : 0.f;
+      bcol[nt] = (bias && p.bias_seg == 0 && c < p.N) ? bias[c] : 0.f;
     }
 #pragma unroll
     for (int ch = 0; ch < SM / EROWS; ++ch) {
@@ -521,8 +535,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         for (int nt = 0; nt < TN; ++nt) {
           const f32x4 a = acc[ch * (EROWS / 16) + mt][nt];
           typename T16<T>::v4 h;
+          float br[4] = {bcol[nt], bcol[nt], bcol[nt], bcol[nt]};
+          if (p.bias_seg > 0) {   // a lane's four rows span at most two segments (bias_seg >= 4)
+            const int rowb = m0 + wm * SM + ch * EROWS + mt * 16 + lg * 4;
+            const int rl = p.M - 1;
+            const int s0 = (rowb < rl ? rowb : rl) / p.bias_seg, s3 = (rowb + 3 < rl ? rowb + 3 : rl) / p.bias_seg;
+            const int c = n0 + wn * SN + nt * 16 + li;
+            const float v0 = c < p.N ? bias[(long long)s0 * p.bias_ld + c] : 0.f;
+            const float v3 = (s3 != s0 && c < p.N) ? bias[(long long)s3 * p.bias_ld + c] : v0;
+            const int edge = (s0 + 1) * p.bias_seg;   // first row of the next segment
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = T16<T>::from_f32(act_apply(a[r] + bcol[nt], ACT));
+            for (int r = 0; r < 4; ++r) br[r] = rowb + r < edge ? v0 : v3;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = T16<T>::from_f32(act_apply(a[r] + br[r], ACT));
           const u32x2 pk = __builtin_bit_cast(u32x2, h);
           cp[(mt * 8 + lg * 2 + 0) * CLDP + nt * 16 + li] = pk[0];   // rows 4 lg + {0, 1}
           cp[(mt * 8 + lg * 2 + 1) * CLDP + nt * 16 + li] = pk[1];   // rows 4 lg + {2, 3}
@@ -558,9 +584,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     const int c4 = lane % LPR, rs = lane / LPR;
     const int col4 = n0 + wn * SN + c4 * 4;
     const bool ok4 = col4 < p.N;
-    float b4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b4[j] = (bias && ok4) ? bias[col4 + j] : 0.f;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && p.bias_seg == 0 && ok4) b4 = *reinterpret_cast<const f32x4*>(bias + col4);   // (vec: N % 8 == 0; bias is 16-byte aligned: checked on the host)
 #pragma unroll
     for (int ch = 0; ch < SM / EROWS; ++ch) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -591,9 +616,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         const int row = row0 + it * RIT;
         if (row < p.M && ok4) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ct + (it * RIT + rs) * CLD + c4 * 4);
-        f32x4 v;
+        f32x4 v, bb = b4;
+        if (p.bias_seg > 0) bb = *reinterpret_cast<const f32x4*>(bias + (long long)(row / p.bias_seg) * p.bias_ld + col4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + b4[j], ACT);
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + bb[j], ACT);
         if (res) v += rr[it];
         if (c32) gstore16(c32 + (long long)row * p.ldc32 + col4, __builtin_bit_cast(u32x4, v), p.st_mode32);
         }

@@ -102,6 +102,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long lon
                     ohi ? ohi + (long long)row * ld16 : nullptr, olo ? olo + (long long)row * ld16 : nullptr);
 }
 
+// Per-segment mean rows of a 16-bit plane (see mer_seg_mean16 in the header): workgroup = (segment, 512-column slice); a lane
+// owns 8 consecutive columns (one 16-byte load per sampled row), the four waves take every fourth sampled row and meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void seg_mean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int seg_rows,
+                                                         int stride, const int* valid_rows, T* out, long long ldo) {
+  typedef typename T16<T>::v8 v8;
+  __shared__ float part[4][64 * 8];
+  const int seg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.y * 512 + lane * 8;
+  const int r0 = seg * seg_rows;
+  int nv = M - r0 < seg_rows ? M - r0 : seg_rows;
+  if (valid_rows) nv = valid_rows[seg] < nv ? valid_rows[seg] : nv;
+  const int cnt = nv > 0 ? (nv + stride - 1) / stride : 0;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (col < K) {
+    for (int i = wave; i < cnt; i += 4) {
+      const int r = r0 + i * stride;
+      const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
+      const v8 x = *reinterpret_cast<const v8*>(a + off + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += T16<T>::to_f32(x[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
+  __syncthreads();
+  if (wave == 0 && col < K) {
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    v8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane * 8 + j;
+      o[j] = T16<T>::from_f32(((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) * inv);
+    }
+    *reinterpret_cast<v8*>(out + (long long)seg * ldo + col) = o;
+  }
+}
+
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* patch, const float* cls, const float* pos,
                                                            const float* gamma, const float* beta, float eps, int N,
@@ -216,6 +256,26 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
                                           act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16, g_ln_nt));
   }
   return check_launch("layernorm");
+}
+
+extern "C" int mer_seg_mean16(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
+                              int seg_rows, int stride, const int* valid_rows, void* out16, long long ldo, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(a && out16 && M > 0 && K > 0 && seg_rows > 0 && stride > 0, MER_EINVAL, "mer_seg_mean16: bad argument");
+  MER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldo % 8 == 0 && a_batch_stride % 8 == 0 && ((((uintptr_t)a | (uintptr_t)out16) & 15) == 0), MER_ESHAPE,
+              "mer_seg_mean16: K, lda, ldo, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
+  MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_seg_mean16: bad dtype");
+  const int nseg = (int)cdiv(M, seg_rows);
+  dim3 grid(nseg, (unsigned)cdiv(K, 512)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof("seg_mean16", 0.0, (double)nseg * cdiv(seg_rows, stride) * K * 2 + (double)nseg * K * 2, st);
+  if (dtype == MER_DT_F16)
+    hipLaunchKernelGGL((seg_mean16_kernel<f16>), grid, block, 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, stride,
+                       valid_rows, (f16*)out16, ldo);
+  else
+    hipLaunchKernelGGL((seg_mean16_kernel<bf16>), grid, block, 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, stride,
+                       valid_rows, (bf16*)out16, ldo);
+  return check_launch("seg_mean16");
 }
 
 extern "C" int mer_vit_assemble(const float* patch, const float* cls, const float* pos, const float* gamma,

@@ -15,7 +15,12 @@ is no torch compute on the forward path and no CPU fallback.
 
 precision (see DESIGN.md §numerics for the measured parity of each):
     "fast"      every GEMM one fp16 MFMA pass (fp32 accumulate): ~1e-3 on the saved features
-    "mx"        default.  One fp16 pass + the weight-rounding residual w - f16(w) as an MX-fp4 plane (e2m1 + E8M0 per 32 k)
+    "mean"      One fp16 pass for EVERY block GEMM + the weight-rounding residual applied to each sequence's mean token only:
+                table[seq] = bias + mean_t(a) (w - f16(w))^T (a tiny [sequences, N] GEMM), added as a per-sequence bias in the
+                epilogue.  The rounding error of the weights is the same perturbation for every token, so almost all of what
+                reaches the features goes through the mean activation: same parity as "balanced" / "mx" (DESIGN.md §4,
+                tests/studies/mean_correction.py) for < 1 % extra work.  The HuBERT conv stack keeps the MX correction.
+    "mx"        One fp16 pass + the weight-rounding residual w - f16(w) as an MX-fp4 plane (e2m1 + E8M0 per 32 k)
                 applied through v_mfma_scale_f32_16x16x128_f8f6f4 against bf8 copies of the activations: removes the
                 weight-rounding error (coherent across tokens, so it survives the utterance mean) like "balanced",
                 at 1/2 f16-pass of extra MFMA work instead of a whole pass.  GEMMs the MX kernel does not cover
@@ -151,8 +156,13 @@ def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes, mx_s
 
 
 # precision preset -> (GEMM passes in the HuBERT conv stack, GEMM passes in the transformer blocks)
-_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2), "mx": (4, 4),
+_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2), "mx": (4, 4), "mean": (4, 5),
          "accurate": (3, 3), "x3": (3, 3)}
+
+
+def _planes(tf_passes):
+    """(carry the f16 residual plane `lo`, carry the MX-fp4 residual plane) for a transformer-block pass code."""
+    return tf_passes in (2, 3, 5), tf_passes == 4
 
 
 class _HipModule:
@@ -321,7 +331,7 @@ class HipHubertModel(_HipModule):
             w.pos_w = hold.w16(pos_layout(pw), clo)
             w.pos_b = hold.f32(sd[p + "bias"])
         w.enc_ln_g, w.enc_ln_b = hold.f32(sd["encoder.layer_norm.weight"]), hold.f32(sd["encoder.layer_norm.bias"])
-        tlo, tmx = tf_passes >= 2, tf_passes == 4
+        tlo, tmx = _planes(tf_passes)
         layers = (TfLayer * config.num_hidden_layers)()
         for l in range(config.num_hidden_layers):
             q = f"encoder.layers.{l}."
@@ -458,7 +468,7 @@ class HipCLIPModel(_HipModule):
         vc = config.vision_config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo, tmx = tf_passes >= 2, tf_passes == 4
+        lo, tmx = _planes(tf_passes)
         hold = self._hold = _Holder(device, dtype)
         act = MER_ACT_QUICK_GELU if vc.hidden_act == "quick_gelu" else MER_ACT_GELU
         cfg = VitConfig()
@@ -542,7 +552,7 @@ class HipDinov2Model(_HipModule):
         self.device = torch.device(device)
         swiglu = bool(getattr(config, "use_swiglu_ffn", False))   # dinov2-giant
         _, tf_passes = _PREC[precision]
-        lo, tmx = tf_passes >= 2, tf_passes == 4
+        lo, tmx = _planes(tf_passes)
         hold = self._hold = _Holder(device, dtype)
         D, Pz = config.hidden_size, config.patch_size
         ffn = int(D * config.mlp_ratio)
@@ -651,7 +661,7 @@ class HipData2VecVisionModel(HipDinov2Model):
         self.config = config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo, tmx = tf_passes >= 2, tf_passes == 4
+        lo, tmx = _planes(tf_passes)
         hold = self._hold = _Holder(device, dtype)
         D, Pz, Hn = config.hidden_size, config.patch_size, config.num_attention_heads
         win = config.image_size // Pz
@@ -746,7 +756,7 @@ class HipVideoMAEModel(_HipModule):
         self.config = config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo, tmx = tf_passes >= 2, tf_passes == 4
+        lo, tmx = _planes(tf_passes)
         hold = self._hold = _Holder(device, dtype)
         D = config.hidden_size
         cfg = VideoMAEConfig()
@@ -838,7 +848,7 @@ class HipBertModel(_HipModule):
         self.config = config
         self.device = torch.device(device)
         _, tf_passes = _PREC[precision]
-        lo, tmx = tf_passes >= 2, tf_passes == 4
+        lo, tmx = _planes(tf_passes)
         hold = self._hold = _Holder(device, dtype)
         acts = {"gelu": MER_ACT_GELU, "gelu_new": MER_ACT_GELU_TANH}
         if config.hidden_act not in acts:

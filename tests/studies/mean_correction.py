@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""CPU-only study: can the weight-rounding correction be applied to the per-clip MEAN activation only?
+out = f16(a) f16(w)^T + corr, with  corr = f16(a) w_lo^T (the 2-pass / MX schemes: +50-100 % MFMA work)  or
+corr = mean_t(f16(a)) w_lo^T per clip (one GEMV per clip and GEMM: < 1 % extra work, added like a per-clip bias).
+The rounding error of the weights is the same perturbation for every token, so what survives the utterance mean is
+mean_t(a) w_lo^T exactly; what is left per token is (a_t - mean) w_lo^T.  Prints UTT / FRAME errors of HuBERT-base, CLIP-B/16
+and RoBERTa-base features for: one pass, exact 2-pass, mean-corrected one pass (all GEMMs), mean-corrected with Q/K uncorrected."""
+import os, sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from mertools_amd import synthetic as W
+from oracle import encoders_ref as R
+
+MODE = {"corr": "none"}
+_lin, _conv = F.linear, F.conv1d
+
+
+def lin(x, w, b=None):
+    a16 = x.half().float(); wh = w.half().float(); wl = w - wh
+    out = _lin(a16, wh)
+    if MODE["corr"] == "exact":
+        out = out + _lin(a16, wl)
+    elif MODE["corr"] == "mean":
+        m = a16.mean(dim=-2, keepdim=True) if a16.dim() >= 3 else a16      # [B, 1, K]: the clip's (frame's) mean token
+        out = out + _lin(m, wl)
+    elif MODE["corr"].startswith("sub"):                                    # mean over every s-th token only
+        st = int(MODE["corr"][3:])
+        m = a16[..., ::st, :].mean(dim=-2, keepdim=True) if a16.dim() >= 3 else a16
+        out = out + _lin(m, wl)
+    return out if b is None else out + b
+
+
+def conv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+    if w.shape[1] == 1 or groups > 1:        # conv0 is fp32 VALU in the product; the grouped positional conv keeps its 2-pass form
+        if groups > 1:
+            a16 = x.half().float()
+            return _conv(a16, w, b, stride, padding, dilation, groups)
+        return _conv(x, w, b, stride, padding, dilation, groups)
+    a16 = x.half().float(); wh = w.half().float(); wl = w - wh
+    out = _conv(a16, wh, None, stride, padding, dilation, groups)
+    if MODE["corr"] == "exact":
+        out = out + _conv(a16, wl, None, stride, padding, dilation, groups)
+    elif MODE["corr"] == "mean" or MODE["corr"].startswith("sub"):
+        # mean over the output positions of the im2col rows == conv of the correction evaluated on the mean window
+        full = _conv(a16, wl, None, stride, padding, dilation, groups)       # [B, Co, T]
+        out = out + full.mean(dim=-1, keepdim=True)
+    return out if b is None else out + b[None, :, None]
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def main():
+    torch.manual_seed(0)
+    hc = W.hubert_config("base"); hsd = W.hubert_state_dict(hc, 0); wav = W.synth_audio(2, 48000)
+    cc = W.clip_config("base16"); csd = W.clip_state_dict(cc, 0); px = W.synth_frames(8)
+    ccfg = dict(vars(cc.vision_config), projection_dim=cc.projection_dim)
+    bc = W.bert_config("roberta-base"); bsd = W.bert_state_dict(bc, 0); ids = W.synth_tokens(4)
+    heavy = "--heavy" in sys.argv
+    if heavy:
+        hsd, csd, bsd = W.heavy_tailed(hsd), W.heavy_tailed(csd), W.heavy_tailed(bsd)
+    def run():
+        h = torch.stack(R.hubert_hidden_states(hsd, vars(hc), wav))[[-4, -3, -2, -1]].sum(0)
+        c = R.clip_image_features(csd, ccfg, px)
+        t = torch.stack(R.bert_hidden_states(bsd, dict(vars(bc), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1]
+        return h, c, t
+    with torch.no_grad():
+        h0, c0, t0 = run()
+        R.F.linear, R.F.conv1d = lin, conv
+        for mode in (sys.argv[1:] and [a for a in sys.argv[1:] if not a.startswith("--")] or ["none", "exact", "mean"]):
+            MODE["corr"] = mode
+            h, c, t = run()
+            print(f"{'heavy ' if heavy else ''}corr={mode:6s}: HuBERT utt {rel(h.mean(1), h0.mean(1)):.2e} frame {rel(h, h0):.2e} | "
+                  f"CLIP utt {rel(c.mean(0), c0.mean(0)):.2e} frames {rel(c, c0):.2e} | RoBERTa utt {rel(t.mean(1), t0.mean(1)):.2e} frame {rel(t, t0):.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

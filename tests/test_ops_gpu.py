@@ -581,3 +581,45 @@ def test_image_resize_crop_u8_matches_pillow(dev, h, w, size):
     for n in range(frames.shape[0]):
         ref = np.asarray(Image.fromarray(frames[n]).resize((nw, nh), resample=Image.BICUBIC))[top:top + crop, left:left + crop]
         assert np.array_equal(out[n], ref), n
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3])
+@pytest.mark.parametrize("M,N,K,seg", [(2304, 768, 256, 197), (1000, 520, 96, 64), (4096, 1536, 128, 249)])
+def test_gemm16_per_segment_bias_table(dev, M, N, K, seg, tile):
+    """bias_seg_rows: row m adds table[m // seg, n] — in all three epilogues (16-bit-only / fp32-only with residual / both outputs),
+    with an activation on top (the bias is added before it)."""
+    ops = _ops()
+    a = _rand((M, K), 81)
+    w = _rand((N, K), 82) * 0.05
+    nseg = (M + seg - 1) // seg
+    table = _rand((nseg, N), 83)
+    res = _rand((M, N), 84)
+    ah, _ = ops.split16(a.to(dev), "f16", lo=False)
+    wh = ops.split16_host(w, "f16")[0].to(dev)
+    z = ah.double().cpu() @ wh.double().cpu().T + table.double()[torch.arange(M) // seg]
+    for act in (None, "gelu"):
+        true = _act_ref(z, act or "none")
+        _, c16, _ = ops.gemm16(ah, wh, bias=table.to(dev), bias_seg_rows=seg, act=act, out16=True, passes=1, tile=tile)
+        c32, _, _ = ops.gemm16(ah, wh, bias=table.to(dev), bias_seg_rows=seg, act=act, residual=res.to(dev), out32=True, passes=1, tile=tile)
+        b32, b16, _ = ops.gemm16(ah, wh, bias=table.to(dev), bias_seg_rows=seg, act=act, out32=True, out16=True, passes=1, tile=tile)
+        torch.cuda.synchronize()
+        assert_close(c16.float().cpu(), true.float(), 1.5e-3, f"segment bias, 16-bit epilogue (act={act})")
+        assert_close(c32.cpu(), (true + res.double()).float(), 2e-5, f"segment bias, fp32 epilogue (act={act})")
+        assert_close(b32.cpu(), true.float(), 2e-5, f"segment bias, generic epilogue fp32 (act={act})")
+        assert torch.equal(b16, c16), "generic and packed 16-bit epilogues disagree under a segment bias"
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_seg_mean16(dev, dtype):
+    ops = _ops()
+    M, K, seg = 1000, 776, 197
+    x = _rand((M, K), 85).to(ops.torch16(dtype))
+    valid = torch.tensor([197, 50, 1, 197, 100, 15], dtype=torch.int32)
+    for stride in (1, 8):
+        out = ops.seg_mean16(x.to(dev), seg, stride=stride, valid_rows=valid.to(dev))
+        torch.cuda.synchronize()
+        assert out.shape == (6, K)
+        for s_ in range(6):
+            n = min(int(valid[s_]), M - s_ * seg)
+            ref = x[s_ * seg: s_ * seg + n: stride].double().mean(0)
+            assert_close(out[s_].float().cpu(), ref.float(), 5e-3 if dtype == "bf16" else 6e-4, f"segment {s_} mean (stride {stride})")
