@@ -162,7 +162,7 @@ _PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "ba
 
 def _planes(tf_passes):
     """(carry the f16 residual plane `lo`, carry the MX-fp4 residual plane) for a transformer-block pass code."""
-    return tf_passes in (2, 3, 5), tf_passes == 4
+    return tf_passes >= 2, tf_passes == 4   # `lo` also backs the MX preset's 2-pass fallback (shapes the MX kernel does not cover)
 
 
 class _HipModule:
