@@ -43,7 +43,8 @@ def conv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     elif MODE["corr"] == "mean" or MODE["corr"].startswith("sub"):
         # mean over the output positions of the im2col rows == conv of the correction evaluated on the mean window
         full = _conv(a16, wl, None, stride, padding, dilation, groups)       # [B, Co, T]
-        out = out + full.mean(dim=-1, keepdim=True)
+        st = int(MODE["corr"][3:]) if MODE["corr"].startswith("sub") else 1
+        out = out + full[..., ::st].mean(dim=-1, keepdim=True)
     return out if b is None else out + b[None, :, None]
 
 
