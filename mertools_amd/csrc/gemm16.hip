@@ -205,7 +205,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
              (!a->bias || ((((uintptr_t)a->bias) & 15) == 0 && a->bias_si % 4 == 0))) ? 1 : 0;   // its static bias is one 16-byte load per lane
   // packed-pair epilogue: 16-bit output only (no fp32 copy, residual or lo plane), row-major, every column group of 8 in range
   p.pk_epi = (g_gemm_pkepi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 && !a->c16_blocked &&
-              a->act != MER_ACT_RELU) ? 1 : 0;
+              a->act != MER_ACT_RELU && (a->bias_seg_rows == 0 || a->act == MER_ACT_NONE || a->act == MER_ACT_GELU)) ? 1 : 0;
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;

@@ -511,8 +511,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // transposition, so the staging tile holds row PAIRS: half the ds_write_b32 (the LDS pipe's slowest instruction, 64 B/clk/CU:
   // 4096 of its cycles per 256x256 fp32 tile) and half the read-back; a lane then owns 8 columns of a row pair and un-zips
   // them with v_perm_b32 into two 16-byte stores.
-  auto epilogue_pk = [&](auto act_tag) __attribute__((always_inline)) {
+  auto epilogue_pk = [&](auto act_tag, auto seg_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool SEG = decltype(seg_tag)::value;   // per-segment bias table (compile-time: the plain-bias path pays nothing for it)
     constexpr int CLDP = SN + 8;                 // dwords per staged row pair; 2 * CLDP % 32 == 16: the two lg halves of a ds_write_b32 group never share a bank
     constexpr int PAIRS = EROWS / 2;
     constexpr int PAIRS_IT = 64 / LANES_PER_ROW;
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           const f32x4 a = acc[ch * (EROWS / 16) + mt][nt];
           typename T16<T>::v4 h;
           float br[4] = {bcol[nt], bcol[nt], bcol[nt], bcol[nt]};
-          if (p.bias_seg > 0) {   // a lane's four rows span at most two segments (bias_seg >= 4)
+          if constexpr (SEG) {   // a lane's four rows span at most two segments (bias_seg >= 4)
             const int rowb = m0 + wm * SM + ch * EROWS + mt * 16 + lg * 4;
             const int rl = p.M - 1;
             const int s0 = (rowb < rl ? rowb : rl) / p.bias_seg, s3 = (rowb + 3 < rl ? rowb + 3 : rl) / p.bias_seg;
@@ -578,8 +579,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // fp32-only outputs (attention output projection, fc2: + residual): the generic path's 8 columns per lane make every store /
   // residual-load instruction touch 16 bytes out of every 32 (two instructions per 128-byte line).  Here a lane owns 4 columns:
   // 16 lanes cover a wave's 256-byte row run, one instruction = 4 whole rows, loads and stores are whole lines (and may stream).
-  auto epilogue32 = [&](auto act_tag) __attribute__((always_inline)) {
+  auto epilogue32 = [&](auto act_tag, auto seg_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool SEG = decltype(seg_tag)::value;
     constexpr int LPR = SN / 4, RIT = 64 / LPR, NIT4 = EROWS / RIT;
     const int c4 = lane % LPR, rs = lane / LPR;
     const int col4 = n0 + wn * SN + c4 * 4;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         if (row < p.M && ok4) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ct + (it * RIT + rs) * CLD + c4 * 4);
         f32x4 v, bb = b4;
-        if (p.bias_seg > 0) bb = *reinterpret_cast<const f32x4*>(bias + (long long)(row / p.bias_seg) * p.bias_ld + col4);
+        if constexpr (SEG) bb = *reinterpret_cast<const f32x4*>(bias + (long long)(row / p.bias_seg) * p.bias_ld + col4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + bb[j], ACT);
         if (res) v += rr[it];
@@ -632,17 +634,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   }
   if (p.epi32) {   // host-checked: vector accesses, fp32 output only
     if ((p.dbg_skip & 3) == 1) c32 = nullptr;
-    if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{});   // (the host routes other activations to the generic path)
-    else epilogue32(std::integral_constant<int, MER_ACT_NONE>{});
+    // (the host routes other activations to the generic path)
+    if (p.bias_seg > 0) {
+      if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{}, std::integral_constant<bool, true>{});
+      else epilogue32(std::integral_constant<int, MER_ACT_NONE>{}, std::integral_constant<bool, true>{});
+    } else {
+      if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{}, std::integral_constant<bool, false>{});
+      else epilogue32(std::integral_constant<int, MER_ACT_NONE>{}, std::integral_constant<bool, false>{});
+    }
     return;
   }
   if ((p.dbg_skip & 3) == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
-  if (p.pk_epi) {   // host-checked: vector stores, 16-bit output only, row-major
+  if (p.pk_epi) {   // host-checked: vector stores, 16-bit output only, row-major; a bias table only with act none / gelu
+    typedef std::integral_constant<bool, false> NoSeg;
+    typedef std::integral_constant<bool, true> Seg;
+    if (p.bias_seg > 0) {
+      if (p.act == MER_ACT_GELU) epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}, Seg{});
+      else epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}, Seg{});
+      return;
+    }
     switch (p.act) {
-      case MER_ACT_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}); break;
-      case MER_ACT_QUICK_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
-      case MER_ACT_GELU_TANH: epilogue_pk(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
-      default: epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}); break;
+      case MER_ACT_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}, NoSeg{}); break;
+      case MER_ACT_QUICK_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_QUICK_GELU>{}, NoSeg{}); break;
+      case MER_ACT_GELU_TANH: epilogue_pk(std::integral_constant<int, MER_ACT_GELU_TANH>{}, NoSeg{}); break;
+      default: epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}, NoSeg{}); break;
     }
     return;
   }
