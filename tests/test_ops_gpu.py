@@ -606,7 +606,8 @@ def test_gemm16_per_segment_bias_table(dev, M, N, K, seg, tile):
         assert_close(c16.float().cpu(), true.float(), 1.5e-3, f"segment bias, 16-bit epilogue (act={act})")
         assert_close(c32.cpu(), (true + res.double()).float(), 2e-5, f"segment bias, fp32 epilogue (act={act})")
         assert_close(b32.cpu(), true.float(), 2e-5, f"segment bias, generic epilogue fp32 (act={act})")
-        assert torch.equal(b16, c16), "generic and packed 16-bit epilogues disagree under a segment bias"
+        # (two differently compiled code paths: the fp32 value may differ in its last bit before the 16-bit rounding)
+        assert_close(b16.float().cpu(), c16.float().cpu(), 1e-3, "generic vs packed 16-bit epilogue under a segment bias")
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
