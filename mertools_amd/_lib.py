@@ -231,7 +231,7 @@ def lib():
                 continue  # checked by tests/test_abi.py against the header
             fn.restype = res
             fn.argtypes = args
-        # tuning switches: MER_OPTIONS="gemm_persist=1,gemm_glds=2" -> mer_set_option() at load time
+        # tuning switches: MER_OPTIONS="gemm_store=0,attn_waves=4" -> mer_set_option() at load time
         for kv in filter(None, os.environ.get("MER_OPTIONS", "").split(",")):
             k, _, v = kv.partition("=")
             if h.mer_set_option(k.strip().encode(), int(v or "1")) != MER_OK:

@@ -6,7 +6,7 @@
 // For every (shape, passes, epilogue) of the bench's dominant GEMMs it runs: row-major W, pre-blocked W (mer_w_block_pack), and —
 // for the K = ffn shapes — a blocked A plane produced by a c16_blocked producer.  One JSON line per configuration:
 // microseconds per launch (hipEvents around `reps` back-to-back launches after `warm` warm-up launches: sustained clocks) and
-// algorithmic TFLOP/s.  Options can be switched for a run with MER_SET="gemm_persist=1,gemm_wblk=0" (mer_set_option).
+// algorithmic TFLOP/s.  Options can be switched for a run with MER_SET="gemm_pkepi=0,gemm_wblk=0" (mer_set_option).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

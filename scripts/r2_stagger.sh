@@ -1,4 +1,5 @@
 #!/bin/bash
+# (HISTORICAL: the gemm_stagger option was removed after this A/B — negative result, profiles/r02_gemm_stagger_ab.txt.)
 # Phase-spreading A/B: real-kernel timings and the bench with gemm_stagger = 0 / 4 / 2, plus the new fusion golden test.
 set -u
 out=gpurun_out/r2_stagger
