@@ -42,8 +42,10 @@ __device__ __forceinline__ typename T16<T>::v4 tr_read4(const T* lds_ptr) {
 // NW waves per workgroup share one staged K / V: 8 waves (NKT <= 16: the scores fit 128 VGPRs) give a CU 16 resident waves
 // on the same LDS footprint as 4 — the per-sub-tile chain (Q load -> 2 NKT MFMAs -> softmax -> 2 NKT MFMAs -> store) is
 // latency-bound, and a head's 13-16 sub-tiles take 2 rounds of a wave instead of 4.
+// (NW = 8 without the bias table asks for 4 waves per SIMD = two resident workgroups per CU: the register allocator must stay
+// within 128 VGPRs; the bias variants need ~140 and would spill.)
 template <typename T, int NKT, bool BIAS = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 8 && !BIAS) ? 4 : 1))) void attn_sp_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                       long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg,
                                                       const float* __restrict__ bias = nullptr, long long ldb = 0,
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ 
   if (dbg && tid == 0) dbg[dbi + 1] = __builtin_amdgcn_s_memtime();
 
   // K / V^T of this (batch, head) are staged once; each wave then walks its 16-query sub-tiles
-  // (qs = wave, wave+4, ...), so the staging cost is paid once per head instead of once per 64 queries.
+  // (qs = wave, wave+NW, ...), so the staging cost is paid once per head instead of once per 64 queries.
   for (int qs = qt * NW + wave; qs * 16 < Tn; qs += NW * (int)gridDim.x) {
   // K / V^T fragments are loop-invariant LDS reads: without this clobber hipcc hoists all of them out of the loop
   // (28 + 56 fragment registers -> 256 VGPR + ~90 AGPR, one workgroup per CU instead of two)
@@ -136,37 +138,79 @@ __global__ __launch_bounds__(NW * 64) void attn_sp_kernel(const T* __restrict__ 
   }
 
   // ---- softmax over keys (fp32, base-2 exponent) ----
+  // The softmax is the VALU bulk of this kernel (the MFMAs of a sub-tile take ~900 clocks, the scalar-per-score code ~2500),
+  // so every score costs as few issue slots as possible: the max is taken over the RAW scores (scale > 0 commutes with max),
+  // scale and max fold into one packed FMA per two scores, the key mask only touches tiles that can hold keys >= klen.
   float mx = -INFINITY;
-  const float* brow = nullptr;
-  float gq = 1.4426950408889634f;   // the bias is added in the base-2 domain too
-  if (BIAS) {
-    brow = bias + ((long long)h * Tn + qrow) * ldb;
-    if (gate) gq *= gate[((long long)b * gridDim.y + h) * Tn + qrow];
-  }
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (BIAS && kt * 16 + lg * 4 < Tn) bv = *reinterpret_cast<const f32x4*>(brow + kt * 16 + lg * 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + lg * 4 + r;
-      const float x = key < klen ? (BIAS ? fmaf(gq, bv[r], s[kt][r] * scale_log2e) : s[kt][r] * scale_log2e) : -INFINITY;
-      s[kt][r] = x;
-      mx = fmaxf(mx, x);
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  if (!(mx > -INFINITY)) mx = 0.f;  // klen == 0: all keys masked -> zeros out
   float sum = 0.f;
+  if (BIAS) {
+    const float* brow = bias + ((long long)h * Tn + qrow) * ldb;
+    float gq = 1.4426950408889634f;   // the bias is added in the base-2 domain too
+    if (gate) gq *= gate[((long long)b * gridDim.y + h) * Tn + qrow];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (kt * 16 + lg * 4 < Tn) bv = *reinterpret_cast<const f32x4*>(brow + kt * 16 + lg * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float pexp = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-      s[kt][r] = pexp;
-      sum += pexp;
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + lg * 4 + r;
+        const float x = key < klen ? fmaf(gq, bv[r], s[kt][r] * scale_log2e) : -INFINITY;
+        s[kt][r] = x;
+        mx = fmaxf(mx, x);
+      }
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (!(mx > -INFINITY)) mx = 0.f;  // klen == 0: all keys masked -> zeros out
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pexp = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+        s[kt][r] = pexp;
+        sum += pexp;
+      }
+  } else {
+    // keys >= klen (their K rows are zero in LDS: raw score 0) must leave the max and the sum.  The dispatcher picks the
+    // smallest even NKT >= ceil(T / 16), so with klen == T only the last two tiles can hold such keys; a shorter row of a
+    // ragged batch (wave-uniform test) masks the earlier tiles too.  `kl` is opaque to the optimiser so that those
+    // 4 (NKT - 2) compares stay inside the rare branch instead of being hoisted into (spilled) SGPR pairs.
+    if (NKT > 2 && klen <= (NKT - 2) * 16) {
+      int kl = __builtin_amdgcn_readfirstlane(klen);
+      asm volatile("" : "+s"(kl));
+#pragma unroll
+      for (int kt = 0; kt < NKT - 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * 16 + lg * 4 + r >= kl) s[kt][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int kt = (NKT > 2 ? NKT - 2 : 0); kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kt * 16 + lg * 4 + r >= klen) s[kt][r] = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (!(mx > -INFINITY)) mx = 0.f;  // klen == 0: all keys masked -> zeros out
+    const f32x2 sc2 = {scale_log2e, scale_log2e};
+    const f32x2 off2 = {-mx * scale_log2e, -mx * scale_log2e};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const f32x2 x01 = __builtin_elementwise_fma(f32x2{s[kt][0], s[kt][1]}, sc2, off2);   // v_pk_fma_f32
+      const f32x2 x23 = __builtin_elementwise_fma(f32x2{s[kt][2], s[kt][3]}, sc2, off2);
+      const f32x2 p01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
+      const f32x2 p23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+      s[kt] = f32x4{p01[0], p01[1], p23[0], p23[1]};
+      sum2 += p01;                                                                         // v_pk_add_f32
+      sum2 += p23;
+    }
+    sum = sum2[0] + sum2[1];
+  }
   sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
@@ -309,38 +353,45 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
         for (int u = 0; u < QS; ++u) s[u][kt] = T16<T>::mfma(kf, qf[u][kk], s[u][kt]);
       }
     }
+    // softmax bookkeeping in as few VALU slots as possible (see attn_sp_kernel): raw-score max, one packed FMA per two scores,
+    // and the key mask only in the last key block (wave-uniform test) — the running max m[] is kept in the RAW domain
     float alpha[QS];
+    const bool tail = k0 + KB > klen;
 #pragma unroll
     for (int u = 0; u < QS; ++u) {
+      if (tail) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + lg * 4 + r >= klen) s[u][kt][r] = -INFINITY;
+      }
       float bmax = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + kt * 16 + lg * 4 + r;
-          const float x = key < klen ? s[u][kt][r] * scale_log2e : -INFINITY;
-          s[u][kt][r] = x;
-          bmax = fmaxf(bmax, x);
-        }
+        for (int r = 0; r < 4; ++r) bmax = fmaxf(bmax, s[u][kt][r]);
       bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
       bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
       const float mnew = fmaxf(m[u], bmax);                 // finite: every block holds at least one unmasked key
-      alpha[u] = __builtin_amdgcn_exp2f(m[u] - mnew);      // first block: exp2(-inf) = 0
+      alpha[u] = __builtin_amdgcn_exp2f((m[u] - mnew) * scale_log2e);      // first block: exp2(-inf) = 0
       m[u] = mnew;
-      float psum = 0.f;
+      const f32x2 sc2 = {scale_log2e, scale_log2e};
+      const f32x2 off2 = {-mnew * scale_log2e, -mnew * scale_log2e};
+      f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        const f32x2 x01 = __builtin_elementwise_fma(f32x2{s[u][kt][0], s[u][kt][1]}, sc2, off2);
+        const f32x2 x23 = __builtin_elementwise_fma(f32x2{s[u][kt][2], s[u][kt][3]}, sc2, off2);
+        const f32x2 p01 = {__builtin_amdgcn_exp2f(x01[0]), __builtin_amdgcn_exp2f(x01[1])};
+        const f32x2 p23 = {__builtin_amdgcn_exp2f(x23[0]), __builtin_amdgcn_exp2f(x23[1])};
+        s[u][kt] = f32x4{p01[0], p01[1], p23[0], p23[1]};
+        psum2 += p01;
+        psum2 += p23;
+      }
+      lsum[u] = lsum[u] * alpha[u] + (psum2[0] + psum2[1]);  // per-lane partial of the query's normaliser (4 lanes share a query and its alpha)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pe = __builtin_amdgcn_exp2f(s[u][kt][r] - mnew);
-          s[u][kt][r] = pe;
-          psum += pe;
-        }
-      lsum[u] = lsum[u] * alpha[u] + psum;  // per-lane partial of the query's normaliser (4 lanes share a query and its alpha)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha[u];
+      for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha[u];
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {

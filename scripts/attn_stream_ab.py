@@ -26,9 +26,13 @@ for qs in (1, 2):
         us, tf, out = run(64, 1568, 16)
         if ref is None: ref = out.clone()
         print(json.dumps({"kernel": "attn_stream", "QS": qs, "PF": pf, "us": round(us, 1), "TFLOPs": round(tf, 1), "max_abs_diff_vs_first": float((out.float() - ref.float()).abs().max())}), flush=True)
-lib.mer_set_option(b"attn_stream_qs", 2); lib.mer_set_option(b"attn_stream_pf", 1)
+lib.mer_set_option(b"attn_stream_qs", 2); lib.mer_set_option(b"attn_stream_pf", 0)
 for w in (4, 8):
     lib.mer_set_option(b"attn_waves", w)
     us, tf, _ = run(512, 197, 12)
     print(json.dumps({"kernel": "attn_sp T=197", "waves": w, "us": round(us, 1), "TFLOPs": round(tf, 1)}), flush=True)
 lib.mer_set_option(b"attn_waves", 8)
+# the other single-pass shapes of the bench: HuBERT (T = 249, 16 key tiles) and RoBERTa (T = 64, 4-wave kernel)
+for shape in ((64, 249, 12), (64, 64, 12)):
+    us, tf, _ = run(*shape, reps=50)
+    print(json.dumps({"kernel": "attn_sp B=%d T=%d H=%d" % shape, "us": round(us, 1), "TFLOPs": round(tf, 1)}), flush=True)

@@ -184,11 +184,16 @@ def test_qkv_headmajor_gemm_and_attention(dev, B, T, H, tile):
     assert torch.equal(o_rm, o_hm)
 
 
-def test_attention_kv_len_mask(dev):
+@pytest.mark.parametrize("T,lens", [(64, [64, 17, 40]),               # 4-wave single-pass kernel
+                                    (197, [197, 30, 180, 100, 192, 193]),   # 8-wave kernel: masks in the last two tiles only / in every tile (short rows)
+                                    (249, [249, 1, 225, 224, 16]),
+                                    (600, [600, 64, 65, 300, 599]),      # streaming kernel: the mask lives in the last key block of each row
+                                    (1568, [1568, 1000])])
+def test_attention_kv_len_mask(dev, T, lens):
     ops = _ops()
-    B, T, H = 3, 64, 2
+    B, H = len(lens), 2
     D = H * 64
-    lens = torch.tensor([64, 17, 40], dtype=torch.int32)
+    lens = torch.tensor(lens, dtype=torch.int32)
     qkv = _rand((B * T, 3 * D), 16).half()
     q, k, v = [t.float().view(B, T, H, 64).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
     s = q @ k.transpose(2, 3) / 8.0
