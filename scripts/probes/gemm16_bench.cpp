@@ -42,6 +42,22 @@ static float time_gemm(const mer_gemm16_args& g, int warm, int reps) {
   return ms * 1e3f / reps;
 }
 
+// the same launch cycling through `n` argument sets (different A / output planes): the working set leaves the 256-MB Infinity Cache,
+// which is what a GEMM meets inside the encoder (its A plane was just written by the producer, nothing of it is cached from a previous launch)
+static float time_gemm_rot(const mer_gemm16_args* g, int n, int warm, int reps) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < warm; ++i) MER(mer_gemm16(&g[i % n], nullptr));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) MER(mer_gemm16(&g[i % n], nullptr));
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1e3f / reps;
+}
+
 static void run_shape(const Shape& s, int warm, int reps) {
   const int Mp = (s.M + 255) / 256 * 256;
   // operands: 0x3c bytes = f16 1.0-ish patterns are irrelevant for timing; zero planes would let the hardware clock higher
@@ -84,6 +100,21 @@ static void run_shape(const Shape& s, int warm, int reps) {
   report("row-major W", time_gemm(g, warm, reps));
   g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk;
   report("pre-blocked W", time_gemm(g, warm, reps));
+  {   // cold operands: 4 rotating sets of A / residual / output planes (weights stay: they are small and shared by all row tiles)
+    constexpr int R = 4;
+    mer_gemm16_args gr[R];
+    std::vector<void*> extra;
+    for (int r = 0; r < R; ++r) {
+      gr[r] = g;
+      if (r == 0) continue;
+      void* a2 = dev_alloc((size_t)Mp * s.K * 2, 0x2e); extra.push_back(a2); gr[r].a_hi = a2;
+      if (s.residual) { void* p = dev_alloc((size_t)s.M * s.N * 4, 0); extra.push_back(p); gr[r].residual = (float*)p; }
+      if (s.out32) { void* p = dev_alloc((size_t)s.M * s.N * 4, 0); extra.push_back(p); gr[r].c32 = (float*)p; }
+      if (s.out16) { void* p = dev_alloc((size_t)Mp * s.N * 2, 0); extra.push_back(p); gr[r].c16_hi = p; }
+    }
+    report("pre-blocked W, 4 rotating A / output planes (cold operands)", time_gemm_rot(gr, R, warm, reps));
+    for (void* p : extra) CK(hipFree(p));
+  }
   if (s.out16 && s.N % 32 == 0 && !s.out32) {   // producer side of a blocked activation plane (fc1)
     g.c16_blocked = 1;
     report("pre-blocked W, blocked 16-bit output", time_gemm(g, warm, reps));
