@@ -53,6 +53,19 @@ for (name, M, N, K, act, passes, res) in [("clip Q|K p1", 100864, 1536, 768, Non
     late = t[:, 0] > 0.5 * span
     ph = (t[late, 0] % period) / period
     hist = torch.histc(ph.float(), bins=8, min=0, max=1).int().tolist()
+    # does the hardware hand workgroup L to XCD L % 8 (what the kernel's tile map assumes), and do the column tiles of one A row tile
+    # run on ONE XCD (sharing its L2) close together in time?
+    xcc = (ids >> 32).long()
+    L = torch.arange(nblk)
+    tiles_n = (N + 255) // 256
+    q8, r8 = nblk >> 3, nblk & 7
+    xa, loc = L & 7, L >> 3
+    swz = torch.where(xa < r8, xa * (q8 + 1), r8 * (q8 + 1) + (xa - r8) * q8) + loc       # the kernel's tile_of()
+    tm = swz // tiles_n
+    nx = [len(xcc[tm == r].unique()) for r in tm.unique().tolist()[::7]]   # (start times are not compared: s_memtime bases differ between XCDs)
+    print(f"{name:18s} XCDs seen {len(xcc.unique())}; workgroups with xcc == L % 8: {(xcc == (L & 7)).float().mean():.3f}; "
+          f"xcc == (L % 8 + c) % 8 for the best c: {max(((xcc == ((L + c) & 7)).float().mean().item(), c) for c in range(8))}; "
+          f"XCDs per A row tile ({tiles_n} column tiles): {sum(nx) / len(nx):.2f}")
     print(f"{name:18s} wall {wall_us:.1f} us = {2.0 * M * N * K / wall_us / 1e6:.0f} TF | CUs seen {len(per_cu)} tiles/CU {min(per_cu.values())}-{max(per_cu.values())} | "
           f"cycles: prologue {pro.median():.0f} kloop {loop.median():.0f} epilogue {epi.median():.0f} (p10 {q(epi, .1):.0f} p90 {q(epi, .9):.0f}) | "
           f"gap end->next start on the CU: median {gaps.median():.0f} p10 {q(gaps, .1):.0f} p90 {q(gaps, .9):.0f} | span {span:.0f} | "
