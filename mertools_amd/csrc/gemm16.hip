@@ -27,7 +27,7 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
   return MER_OK;
 }
 
-namespace mer { extern int g_attn_force_nkt; extern int g_attn_waves; extern int g_attn_nt; extern int g_attn_stream_qs; extern int g_attn_stream_pf; extern int g_ln_nt; extern int g_tf_ablk; }
+namespace mer { extern int g_attn_force_nkt; extern int g_attn_waves; extern int g_attn_nt; extern int g_attn_stream_qs; extern int g_attn_stream_pf; extern int g_ln_nt; extern int g_ln_rows; extern int g_tf_ablk; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
@@ -44,6 +44,7 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "attn_stream_qs") == 0) { mer::g_attn_stream_qs = value; return MER_OK; }
   if (name && strcmp(name, "attn_stream_pf") == 0) { mer::g_attn_stream_pf = value; return MER_OK; }
   if (name && strcmp(name, "ln_nt") == 0) { mer::g_ln_nt = value; return MER_OK; }
+  if (name && strcmp(name, "ln_rows") == 0) { mer::g_ln_rows = value; return MER_OK; }
   if (name && strcmp(name, "gemm_res_nt") == 0) { mer::g_gemm_res_nt = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;

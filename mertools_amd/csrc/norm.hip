@@ -8,6 +8,7 @@
 
 namespace mer {
 int g_ln_nt = 0;   // mer_set_option("ln_nt", 1): LayerNorm streams its fp32 input with non-temporal loads
+int g_ln_rows = 1; // mer_set_option("ln_rows", 0): one row per wave for every M (A/B testing of the multi-row kernel)
 
 
 template <typename T, int NV>
@@ -15,6 +16,17 @@ struct RowLN {
   // v[j] holds columns (lane + 64*j)*4 .. +3 of the row; entries past D/4 are zero.
   static __device__ __forceinline__ void run(f32x4 (&v)[NV], int lane, int nv4, int D, const float* gamma,
                                              const float* beta, float eps, int act, float* o32, T* ohi, T* olo) {
+    run_with(v, lane, nv4, D, [&](int idx, f32x4& g, f32x4& b) __attribute__((always_inline)) {
+      g = f32x4{1.f, 1.f, 1.f, 1.f};
+      b = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
+      if (beta) b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
+    }, eps, act, o32, ohi, olo);
+  }
+  // `affine(idx, g, b)` hands out gamma / beta of columns 4 idx .. 4 idx + 3 (from global memory, or from the LDS copy of the multi-row kernel)
+  template <typename Affine>
+  static __device__ __forceinline__ void run_with(f32x4 (&v)[NV], int lane, int nv4, int D, Affine affine,
+                                                  float eps, int act, float* o32, T* ohi, T* olo) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
@@ -36,10 +48,8 @@ struct RowLN {
     for (int j = 0; j < NV; ++j) {
       const int idx = lane + 64 * j;
       if (idx < nv4) {
-        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + idx * 4);
-        if (beta) b = *reinterpret_cast<const f32x4*>(beta + idx * 4);
-        f32x4 y;
+        f32x4 g, b, y;
+        affine(idx, g, b);
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = act_apply((v[j][e] - mean) * rstd * g[e] + b[e], act);
         if (o32) *reinterpret_cast<f32x4*>(o32 + idx * 4) = y;
@@ -100,6 +110,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long lon
   }
   RowLN<T, NV>::run(v, lane, nv4, D, gamma, beta, eps, act, out32 ? out32 + (long long)row * ld32 : nullptr,
                     ohi ? ohi + (long long)row * ld16 : nullptr, olo ? olo + (long long)row * ld16 : nullptr);
+}
+
+// Multi-row form for large M: a wave walks rows wave, wave + W, wave + 2W, ... of a fixed-size grid, keeps gamma / beta in LDS
+// (the one-row kernel re-reads 2 D floats of affine parameters through L1 for every D floats of input) and has the next row's
+// loads in flight while it reduces and writes the current one.  Same arithmetic per row as layernorm_kernel (bit-identical outputs).
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, long long ldx, const float* gamma, const float* beta, float eps,
+                                                             int M, int D, int act, float* out32, long long ld32, T* ohi, T* olo,
+                                                             long long ld16, int nt) {
+  const int lane = threadIdx.x & 63, nv4 = D >> 2;
+  const int nwaves = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // gamma / beta once per workgroup into LDS (ds_read_b128 per use: no L1 traffic, no long-lived registers)
+  __shared__ f32x4 sg[64 * NV], sb[64 * NV];
+  for (int i = threadIdx.x; i < 64 * NV; i += 256) {
+    sg[i] = (gamma && i < nv4) ? *reinterpret_cast<const f32x4*>(gamma + i * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+    sb[i] = (beta && i < nv4) ? *reinterpret_cast<const f32x4*>(beta + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  if (row >= M) return;
+  f32x4 cur[NV], nxt[NV];
+  auto load_row = [&](f32x4 (&v)[NV], int r) __attribute__((always_inline)) {
+    const float* xr = x + (long long)r * ldx;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = lane + 64 * j;
+      if (idx < nv4) v[j] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + idx * 4)) : *reinterpret_cast<const f32x4*>(xr + idx * 4);
+      else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  load_row(cur, row);
+  for (; row < M; row += nwaves) {
+    const int rn = row + nwaves;
+    if (rn < M) load_row(nxt, rn);
+    RowLN<T, NV>::run_with(cur, lane, nv4, D, [&](int idx, f32x4& g, f32x4& b) __attribute__((always_inline)) { g = sg[idx]; b = sb[idx]; },
+                           eps, act, out32 ? out32 + (long long)row * ld32 : nullptr,
+                           ohi ? ohi + (long long)row * ld16 : nullptr, olo ? olo + (long long)row * ld16 : nullptr);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) cur[j] = nxt[j];
+  }
 }
 
 // Per-segment mean rows of a 16-bit plane (see mer_seg_mean16 in the header): workgroup = (segment, 512-column slice); a lane
@@ -227,6 +277,34 @@ static int pick_nv(int D) {
 
 }  // namespace mer
 
+namespace mer {
+// workgroups of layernorm_rows_kernel<T, NV> that fit the device at once (occupancy x CUs), cached per instantiation
+template <typename T, int NV>
+static int ln_rows_grid_nv() {
+  static int grid = 0;
+  if (grid == 0) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, layernorm_rows_kernel<T, NV>, 256, 0) != hipSuccess || cus * per <= 0) {
+      (void)hipGetLastError();
+      grid = -1;   // fall back to the one-row kernel
+    } else {
+      grid = cus * per;
+    }
+  }
+  return grid;
+}
+template <typename T>
+static int ln_rows_grid(int nv) {
+  switch (nv) {
+    case 2: return ln_rows_grid_nv<T, 2>();
+    case 3: return ln_rows_grid_nv<T, 3>();
+    case 4: return ln_rows_grid_nv<T, 4>();
+    default: return -1;
+  }
+}
+}  // namespace mer
+
 #define MER_NV_SWITCH(NVVAR, ...)                        \
   switch (NVVAR) {                                       \
     case 2: { constexpr int NV = 2; __VA_ARGS__; } break;  \
@@ -248,6 +326,19 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
   dim3 grid((unsigned)cdiv(M, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof("layernorm", 0.0, (double)M * D * (4 + (out32 ? 4 : 0) + (out16_hi ? 2 : 0) + (out16_lo ? 2 : 0)), st);
+  // many rows of <= 1024 columns (the encoders' block LayerNorms): the multi-row kernel on exactly the grid that is resident at once
+  const int rows_grid = (g_ln_rows && nv <= 4) ? (dtype == MER_DT_F16 ? ln_rows_grid<f16>(nv) : ln_rows_grid<bf16>(nv)) : 0;
+  if (rows_grid > 0 && M >= 8 * rows_grid) {   // at least two rows per wave
+    dim3 rgrid(rows_grid);
+    if (dtype == MER_DT_F16) {
+      MER_NV_SWITCH(nv, layernorm_rows_kernel<f16, NV><<<rgrid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
+                                            act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16, g_ln_nt));
+    } else {
+      MER_NV_SWITCH(nv, layernorm_rows_kernel<bf16, NV><<<rgrid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
+                                            act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16, g_ln_nt));
+    }
+    return check_launch("layernorm");
+  }
   if (dtype == MER_DT_F16) {
     MER_NV_SWITCH(nv, layernorm_kernel<f16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
                                           act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16, g_ln_nt));

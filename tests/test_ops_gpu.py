@@ -148,6 +148,33 @@ def test_layernorm(dev, D):
     assert_close(o32g.cpu(), F.gelu(ref).float(), 2e-6, "layernorm+gelu")
 
 
+@pytest.mark.parametrize("D", [512, 768, 1024])
+def test_layernorm_many_rows(dev, D):
+    """M large enough for the multi-row kernel (a wave walks several rows, gamma / beta in LDS): agrees with the one-row kernel
+    (mer_set_option("ln_rows", 0)) to fp32 rounding, and both with the reference."""
+    from mertools_amd import _lib
+    ops, lib = _ops(), _lib.lib()
+    M = 33003                                                     # > 8 rows per resident wave slot, not a multiple of anything
+    x = (_rand((M, D), 12, 3.0) + 0.5).to(dev)
+    g, b = (_rand((D,), 13) * 0.1 + 1.0).to(dev), (_rand((D,), 14) * 0.1).to(dev)
+    ref = F.layer_norm(x.cpu().double(), (D,), g.cpu().double(), b.cpu().double(), 1e-5).float()
+    outs = {}
+    try:
+        for rows in (1, 0):
+            lib.mer_set_option(b"ln_rows", rows)
+            o32, oh, ol = ops.layernorm(x, g, b, 1e-5, out32=True, out16=True, out16_lo=True)
+            og, _, _ = ops.layernorm(x, g, b, 1e-5, act="gelu")
+            torch.cuda.synchronize()
+            outs[rows] = (o32.clone(), oh.clone(), ol.clone(), og.clone())
+    finally:
+        lib.mer_set_option(b"ln_rows", 1)
+    for a, c in zip(outs[1][:1] + outs[1][3:], outs[0][:1] + outs[0][3:]):   # fp32 outputs: the same arithmetic up to FMA contraction
+        assert_close(a.cpu(), c.cpu(), 1e-6, "multi-row vs one-row LayerNorm")
+    assert_close(outs[1][0].cpu(), ref, 2e-6, "layernorm fp32 (multi-row)")
+    assert_close((outs[1][1].float() + outs[1][2].float()).cpu(), ref, 2e-6, "layernorm planes (multi-row)")
+    assert_close(outs[1][3].cpu(), F.gelu(ref.double()).float(), 2e-6, "layernorm+gelu (multi-row)")
+
+
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("B,T,H", [(2, 64, 2), (2, 50, 3), (1, 197, 12), (2, 249, 4), (1, 257, 2), (1, 499, 2), (1, 600, 2), (2, 1568, 1)])
 def test_attention(dev, dtype, B, T, H):
