@@ -159,6 +159,39 @@ def cpu_baseline():
     return res
 
 
+
+def kernel_source_sha(root=ROOT):
+    """sha256[:16] of the GEMM kernel template (csrc/gemm16_impl.h; gemm16.hip only holds the C ABI and the option table) — the stamp
+    scripts/pmc_summarize.py writes into a PMC collection."""
+    import hashlib
+    return hashlib.sha256(open(os.path.join(root, "mertools_amd", "csrc", "gemm16_impl.h"), "rb").read()).hexdigest()[:16]
+
+
+PMC_KERNEL_PREFIX = {"gemm16": "gemm16<f16,256,256,32,2,4,1,1,", "gemm16_mx": "gemm16<f16,256,256,32,4,2,1,1,", "gemm16_w2": "gemm16<f16,256,256,32,2,4,1,2,"}
+
+
+def pmc_traffic(kernel, algorithmic_bytes_per_launch, root=ROOT):
+    """HBM-side bytes per launch of `kernel` from the PMC passes (scripts/pmc_traffic.sh -> profiles/*pmc_hbm_traffic*.json).
+    A stored figure is only quoted when it was collected on THIS kernel source (the collection's `_source_sha` equals
+    kernel_source_sha()); otherwise traffic is None and the detail says which collections were ignored.  -> (traffic, detail)"""
+    import glob
+    sha = kernel_source_sha(root)
+    prefix = PMC_KERNEL_PREFIX.get(kernel)
+    stale = []
+    for pmc in sorted(glob.glob(os.path.join(root, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
+        d = json.load(open(pmc))
+        if d.get("_source_sha") != sha:
+            stale.append(os.path.basename(pmc))
+            continue
+        k = next((v for name, v in d.items() if prefix and name.startswith(prefix)), None)
+        if k:
+            detail = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
+                      "algorithmic_MB_per_launch": round(algorithmic_bytes_per_launch / 1e6, 1), "source": "profiles/" + os.path.basename(pmc),
+                      "kernel_source_sha": sha}
+            return round((k["fetch_mb_x2"] + k["write_mb"]) * 1e6), detail   # FETCH_SIZE x2-corrected + WRITE_SIZE
+    return None, {"note": f"no PMC collection matches this kernel source (sha {sha}); older collections ignored: {stale}"}
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: one rank per GPU via torch.distributed.run, same flags."""
     n = torch.cuda.device_count()
@@ -373,32 +406,7 @@ def main():
         tot_ms = sum(r["ms"] for r in recs.values())
         dom = max(recs.values(), key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch of the dominant kernel from the PMC passes (scripts/pmc_traffic.sh -> profiles/*pmc_hbm_traffic*.json).
-        # A stored figure is only quoted when it was collected on THIS kernel source (sha of csrc/gemm16_impl.h stamped by
-        # scripts/pmc_summarize.py); otherwise traffic is null and the note says why.
-        traffic, traffic_detail = None, None
-        import glob
-        import hashlib
-        hsh = hashlib.sha256()
-        for f in ("gemm16_impl.h",):   # the kernel template itself (gemm16.hip only holds the C ABI and the option table)
-            hsh.update(open(os.path.join(ROOT, "mertools_amd", "csrc", f), "rb").read())
-        sha = hsh.hexdigest()[:16]
-        prefix = {"gemm16": "gemm16<f16,256,256,32,2,4,1,1,", "gemm16_mx": "gemm16<f16,256,256,32,4,2,1,1,", "gemm16_w2": "gemm16<f16,256,256,32,2,4,1,2,"}.get(dom["name"])
-        stale = []
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic*.json")), reverse=True):
-            d = json.load(open(pmc))
-            if d.get("_source_sha") != sha:
-                stale.append(os.path.basename(pmc))
-                continue
-            k = next((v for name, v in d.items() if prefix and name.startswith(prefix)), None)
-            if k:
-                traffic_detail = {"fetch_MB_per_launch_x2_corrected": round(k["fetch_mb_x2"], 1), "write_MB_per_launch": round(k["write_mb"], 1),
-                                  "algorithmic_MB_per_launch": round(dom["bytes"] / dom["calls"] / 1e6, 1), "source": "profiles/" + os.path.basename(pmc),
-                                  "kernel_source_sha": sha}
-                traffic = round((k["fetch_mb_x2"] + k["write_mb"]) * 1e6)   # HBM-side bytes per launch (FETCH_SIZE x2-corrected + WRITE_SIZE)
-                break
-        if traffic is None:
-            traffic_detail = {"note": f"no PMC collection matches this kernel source (sha {sha}); older collections ignored: {stale}"}
+        traffic, traffic_detail = pmc_traffic(dom["name"], dom["bytes"] / dom["calls"])
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                     # the default 2-pass (weights hi+lo) kernel issues 2x the algorithmic MFMA work; 3-pass 3x
