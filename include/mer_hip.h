@@ -106,21 +106,22 @@ typedef struct {
    * ceil(M/256)*256 * N elements; N % 32 == 0); a_blocked != 0 reads a_hi in that form (K = the producer's N; only the
    * 256x256 one-/two-pass kernels: M >= 1024, N >= 192, K % 32 == 0, no batching — anything else is MER_ESHAPE). */
   int c16_blocked; int a_blocked;
-  /* bias_seg_rows > 0: `bias` is a per-segment table fp32 [ceil(M / bias_seg_rows), bias_ld] (bias_ld >= N, bias_ld % 4 == 0,
-   * 16-byte aligned) and row m adds bias[(m / bias_seg_rows) * bias_ld + n] — how the one-pass GEMM takes its weight-residual
-   * correction: table = bias + mean_rows(A of the segment) * (W - f16(W))^T, see mer_seg_mean16.  bias_seg_rows >= 4; not with batching. */
-  int bias_seg_rows; long long bias_ld;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
-/* Per-segment mean rows of a 16-bit activation plane: out[s, :] = mean over j of a[row(s * seg_rows + j * stride), 0..K) for
- * j * stride < (valid_rows ? valid_rows[s] : seg_rows), rows addressed like mer_gemm16's A operand (a_rows_per_batch /
- * a_batch_stride / lda; <= 0 -> plain row-major), accumulated in fp32, written as a 16-bit plane [nseg, ldo].  The rounding
- * error of a weight matrix is the same perturbation for every token, so what it does to a clip's features goes almost entirely
- * through the clip's MEAN activation (tests/studies/mean_correction.py: the per-clip mean — even of every 8th token — recovers
- * the accuracy of the full second MFMA pass); mean * (W - f16(W))^T is a [nseg, N] GEMM, added as a per-segment bias. */
-int mer_seg_mean16(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
-                   int seg_rows, int stride, const int* valid_rows, void* out16, long long ldo, mer_stream_t stream);
+/* Batch-mean weight-residual correction of a one-pass GEMM (precision "mean"): out[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k],
+ * w_lo = the 16-bit plane of W - f16(W) ([N, K], row stride ldw).  mean_rows runs over about 2048 evenly spaced rows of the A
+ * plane (every row when M <= 2048), addressed like mer_gemm16's A operand (a_rows_per_batch / a_batch_stride / lda; <= 0 ->
+ * plain row-major), fp32 accumulation in a fixed order (deterministic).  valid_rows (device int32 [ceil(M / seg_rows)], or NULL):
+ * rows r with r % seg_rows >= valid_rows[r / seg_rows] are padding and do not count.  The rounding error of a weight matrix
+ * is the same perturbation for every token, so what it does to the features goes almost entirely through the MEAN activation
+ * (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass) — i.e. it
+ * is a bias, and the GEMM that follows runs passes = 1 with `out` as its bias.  scratch: device, mer_bias_corr_scratch_bytes(K)
+ * bytes, 16-byte aligned; out: device fp32 [N].  Two small launches on `stream`. */
+long long mer_bias_corr_scratch_bytes(int K);
+int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
+                  int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
+                  void* scratch, float* out, mer_stream_t stream);
 
 /* Pre-blocked weight plane: a DEVICE 16-bit plane w [N, K] (row stride ldw, K % 32 == 0) is re-laid as
  * [ceil(N/256)][K/32] blocks of 16 KB, each the exact LDS image (256 rows x 64 B, 16-byte chunks XOR-swizzled) of
@@ -301,11 +302,12 @@ typedef struct {
   int act;        /* MER_ACT_GELU | MER_ACT_QUICK_GELU */
   float ln_eps;
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
-  int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split) or 4 (MX-corrected, see mer_gemm16) */
+  int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split), 4 (MX-corrected, see mer_gemm16) or
+                   * 5 (one pass + the batch-mean weight-residual bias correction, see mer_bias_corr; needs the `lo` planes) */
   int gated_rel_pos;  /* 1: WavLM — every layer carries gru_* and the forward call must be given the position-bias table */
   int ffn_swiglu;     /* 1: DINOv2-giant SwiGLU feed-forward (HF:dinov2/modeling_dinov2.py Dinov2SwiGLUFFN): w1 = weights_in [2*ffn, D],
                        * h = silu(y[:, :ffn]) * y[:, ffn:], w2 = weights_out [D, ffn]; `ffn` is the post-gate width, `act` is ignored */
-  int mx_skip;        /* passes == 4 only: GEMMs that run WITHOUT the weight-residual correction (plain one-pass f16) because
+  int mx_skip;        /* passes == 4 / 5: GEMMs that run WITHOUT the weight-residual correction (plain one-pass f16) because
                        * their rounding error does not reach the saved features (tests/studies/mx_selective.py):
                        * bit 0 = the Q and K projections (their error only perturbs softmax logits), bit 1 = FFN fc1, bit 2 = FFN fc2 */
 } mer_tf_config;
@@ -324,7 +326,7 @@ typedef struct {
   int feat_proj_layer_norm;
   int pos_k, pos_groups;
   int stable_layer_norm;    /* 1: HubertEncoderStableLayerNorm (large) */
-  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1, 2, 3 or 4 */
+  int conv_passes;          /* GEMM passes in the conv stack + projection + positional conv: 1 .. 5 (as mer_tf_config.passes) */
   int pos_layers;           /* 0: HuBERT / wav2vec2 — one weight-normed conv, x + GELU(conv(x));
                              * n >= 1: data2vec-audio (HF:data2vec/modeling_data2vec_audio.py Data2VecAudioPositionalConvEmbedding) —
                              * n x [grouped conv (kernel pos_k, padding pos_k/2) -> LayerNorm without affine (eps 1e-5) -> GELU],

@@ -38,7 +38,6 @@ class GemmArgs(C.Structure):
         ("w_mx", c_void_p),
         ("w_hi_blk", c_void_p), ("w_lo_blk", c_void_p),
         ("c16_blocked", c_int), ("a_blocked", c_int),
-        ("bias_seg_rows", c_int), ("bias_ld", c_ll),
     ]
 
 
@@ -170,7 +169,9 @@ _PROTOS = {
                                    c_void_p, c_int, c_void_p, c_void_p]),
     "mer_hubert_forward_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
-    "mer_seg_mean16": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
+    "mer_bias_corr_scratch_bytes": (c_ll, [c_int]),
+    "mer_bias_corr": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p]),
     "mer_hubert_forward_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     "mer_hubert_conv0_gn_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,

@@ -49,21 +49,38 @@ struct HsMap {
 // the K = ffn GEMM, whose A traffic dominates: ceiling probe -15 % on CLIP's fc2).  Off by default until measured end to end.
 int g_tf_ablk = 0;
 
-// passes == 5: ONE f16 MFMA pass + the weight-rounding residual applied to the segment's MEAN activation only:
-//   table[s, :] = bias + mean_rows(A of segment s, every MEAN_STRIDE-th row) * (W - f16(W))^T     (a [nseg, N] GEMM on the `lo` plane)
-//   C = epi(A * f16(W)^T + table[row / seg_rows, :])
-// `mc` carries the segment geometry and two small scratch planes; without it (or without a `lo` plane) 5 degrades to 4 / 2.
-struct MeanCorr {
-  int seg_rows;          // rows per segment (tokens of a sequence / frame); 0 = not available
-  const int* valid;      // device int32 [nseg]: valid rows per segment (ragged batches) or NULL
-  void* mean16;          // [nseg, Kmax] 16-bit
-  float* table;          // [nseg, Nmax] fp32
+// passes == 5: ONE f16 MFMA pass + the weight-rounding residual applied through the batch's MEAN activation:
+//   c[n] = bias[n] + mean_rows(A)[k] * (W - f16(W))[n, k]     (mer_bias_corr: sampled column means + a GEMV on the `lo` plane)
+//   C = epi(A * f16(W)^T + c)
+// `cw` carries the scratch of the two helper kernels; without it (or without a `lo` plane) 5 degrades to 4 / 2.
+struct CorrWs {
+  void* scratch;         // mer_bias_corr_scratch_bytes(Kmax); NULL = not available
+  float* cvec;           // [Nmax] fp32: the corrected bias of the GEMM that is about to run
+  int seg_rows;          // ragged batches: rows per sequence ...
+  const int* valid;      // ... and device int32 [nseq] valid rows of each (NULL: every row counts)
 };
-constexpr int MEAN_STRIDE = 8;
+
+// mer_gemm16 with the passes == 5 preamble; `g` is complete except for the pass code handling
+static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
+  if (g.passes == 5) {
+    const bool ok = cw && cw->scratch && g.w_lo && !g.a_blocked && g.N % 8 == 0 && g.K % 8 == 0 && g.nbatch <= 1;
+    if (!ok) {
+      g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
+    } else {
+      int rc = mer_bias_corr(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->valid ? cw->seg_rows : 0, cw->valid,
+                             g.w_lo, g.ldw, g.bias, g.N, cw->scratch, cw->cvec, (mer_stream_t)st);
+      if (rc != MER_OK) return rc;
+      g.passes = 1;
+      g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
+      g.bias = cw->cvec;
+    }
+  }
+  return mer_gemm16(&g, (mer_stream_t)st);
+}
 
 static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 a, long long lda, const mer_w16& w,
                 const float* bias, int act, const float* residual, long long ldr, float* c32, long long ldc32, P16 c16,
-                long long ldc16, int c16_blocked = 0, int a_blocked = 0, const MeanCorr* mc = nullptr) {
+                long long ldc16, int c16_blocked = 0, int a_blocked = 0, const CorrWs* cw = nullptr) {
   mer_gemm16_args g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
@@ -74,30 +91,7 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
   g.c16_blocked = c16_blocked; g.a_blocked = a_blocked;
-  if (passes == 5) {
-    const bool ok = mc && mc->seg_rows >= 4 && w.lo && !a_blocked && N % 8 == 0 && K % 8 == 0;
-    if (!ok) {
-      g.passes = (w.mx || w.lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
-    } else {
-      const int nseg = (M + mc->seg_rows - 1) / mc->seg_rows;
-      int rc = mer_seg_mean16(a.hi, dtype, lda, 0, 0, M, K, mc->seg_rows, MEAN_STRIDE, mc->valid, mc->mean16, K, (mer_stream_t)st);
-      if (rc != MER_OK) return rc;
-      mer_gemm16_args t;
-      memset(&t, 0, sizeof(t));
-      t.M = nseg; t.N = N; t.K = K; t.dtype = dtype;
-      t.a_hi = mc->mean16; t.lda = K;
-      t.w_hi = w.lo; t.ldw = K;            // the residual plane f16(W - f16(W)) as the (only) weight operand
-      t.bias = bias; t.act = MER_ACT_NONE;
-      t.c32 = mc->table; t.ldc32 = N;
-      t.nbatch = 1; t.nb_inner = 1; t.passes = 1; t.tile = 0;
-      rc = mer_gemm16(&t, (mer_stream_t)st);
-      if (rc != MER_OK) return rc;
-      g.passes = 1;
-      g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
-      g.bias = mc->table; g.bias_seg_rows = mc->seg_rows; g.bias_ld = N;
-    }
-  }
-  return mer_gemm16(&g, (mer_stream_t)st);
+  return run_gemm(st, g, cw);
 }
 
 #define MER_TRY(expr)        \
@@ -113,11 +107,11 @@ struct TfBufs {
   float* ffn32;    // SwiGLU: fp32 [M, 2F] output of weights_in awaiting the gate
   float* gate;     // WavLM: [B, H, T] gate of the current layer
   float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
-  void* mean16;    // passes == 5: [nseq, max(D, F)] segment means (16-bit)
-  float* table;    // passes == 5: [nseq, max(3D, F)] per-segment bias table
+  void* corr;      // passes == 5: scratch of mer_bias_corr for K <= max(D, F)
+  float* cvec;     // passes == 5: [max(3D, 2F)] corrected bias of the GEMM about to run
 };
 
-static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b, long long nseq = 0) {
+static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
   const bool lo = c.passes == 3;
   const long long D = c.hidden, F = c.ffn;
   b.t32 = (float*)ar.take(M * D * 4);
@@ -130,9 +124,9 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b, l
   b.ffn32 = c.ffn_swiglu ? (float*)ar.take(M * 2 * F * 4) : nullptr;
   b.gate = c.gated_rel_pos ? (float*)ar.take(M * c.heads * 4) : nullptr;
   b.gin32 = (c.gated_rel_pos && c.pre_ln) ? (float*)ar.take(M * D * 4) : nullptr;
-  const long long wide = F > 3 * D ? F : 3 * D;
-  b.mean16 = (c.passes == 5 && nseq > 0) ? ar.take(nseq * wide * 2) : nullptr;
-  b.table = (c.passes == 5 && nseq > 0) ? (float*)ar.take(nseq * wide * 4) : nullptr;
+  const long long wide = 2 * F > 3 * D ? 2 * F : 3 * D;
+  b.corr = c.passes == 5 ? ar.take(mer_bias_corr_scratch_bytes((int)(F > D ? F : D))) : nullptr;
+  b.cvec = c.passes == 5 ? (float*)ar.take(wide * 4) : nullptr;
 }
 
 // Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
@@ -144,9 +138,9 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
   const bool sel = ps == 4 || ps == 5;                      // presets with a selective weight-residual correction (mx_skip)
   const int ps1 = (sel && (c.mx_skip & 2)) ? 1 : ps;       // fc1 without the correction
   const int ps2 = (sel && (c.mx_skip & 4)) ? 1 : ps;       // fc2 without the correction
-  // passes == 5: the correction goes through each sequence's mean token (gemm() above); a sequence = T rows, kv_len = its valid rows
-  const MeanCorr mcv = {T, kv_len, b.mean16, b.table};
-  const MeanCorr* mc = (ps == 5 && b.mean16) ? &mcv : nullptr;
+  // passes == 5: the correction goes through the batch's mean token (run_gemm() above); a sequence = T rows, kv_len = its valid rows
+  const CorrWs cwv = {b.corr, b.cvec, T, kv_len};
+  const CorrWs* mc = (ps == 5 && b.corr) ? &cwv : nullptr;
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
   // blocked fc1 -> fc2 plane: only where fc2 runs the 256x256 one-/two-pass kernel (same test as mer_gemm16's tile choice)
@@ -159,7 +153,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
       MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.gin32, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
-    if (sel && (c.mx_skip & 1) && (2 * D) % 256 == 0 && (ps == 4 ? w.wqkv.mx != nullptr : w.wqkv.lo != nullptr)) {
+    if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx != nullptr) {
       // Q | K columns: one f16 pass (weight rounding there only perturbs softmax logits: no measurable effect on the features);
       // V columns: MX-corrected.  The MX plane is stored per 256-column tile, so the V block starts at tile 2D/256.
       const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr};
@@ -190,7 +184,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     if (c.pre_ln) {
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.h1_16.hi, b.h1_16.lo, D, dt, st));
       if (c.ffn_swiglu) {  // weights_in -> fp32 [M, 2F]; silu(first half) * second half -> 16-bit planes [M, F]
-        MER_TRY(gemm(st, dt, ps1 == 5 ? 4 : ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0));
+        MER_TRY(gemm(st, dt, ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0, 0, 0, mc));
         MER_TRY(mer_swiglu(b.ffn32, 2 * F, M, F, b.f16.hi, b.f16.lo, dt, (mer_stream_t)st));
       } else
       MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0, mc));
@@ -247,7 +241,7 @@ extern "C" int mer_hubert_create(const mer_hubert_config* cfg, const mer_hubert_
   MER_TRY(check_tf(cfg->tf, "mer_hubert_create"));
   MER_REQUIRE(cfg->n_conv >= 2 && cfg->n_conv <= MER_MAX_CONV, MER_EINVAL, "mer_hubert_create: n_conv=%d", cfg->n_conv);
   MER_REQUIRE(cfg->conv_dim % 8 == 0, MER_ESHAPE, "mer_hubert_create: conv_dim %% 8 != 0");
-  MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 4, MER_EINVAL, "mer_hubert_create: conv_passes must be 1, 2, 3 or 4");
+  MER_REQUIRE(cfg->conv_passes >= 1 && cfg->conv_passes <= 5, MER_EINVAL, "mer_hubert_create: conv_passes must be 1 .. 5");
   MER_REQUIRE(cfg->tf.hidden % cfg->pos_groups == 0 && (cfg->tf.hidden / cfg->pos_groups) % 8 == 0, MER_ESHAPE,
               "mer_hubert_create: hidden/pos_groups must be a multiple of 8");
   MER_REQUIRE(cfg->pos_layers >= 0 && cfg->pos_layers <= MER_MAX_POS, MER_EINVAL, "mer_hubert_create: pos_layers=%d", cfg->pos_layers);
@@ -293,6 +287,8 @@ struct HubertPlan {
   float* posbuf;       // data2vec-audio: output of a positional conv layer (input of the next)
   float* ring;
   int* vlen;           // ragged batches: t0_len[B] | tn_len[B] (device int32)
+  void* ccorr;         // conv_passes == 5: mer_bias_corr scratch for the conv GEMMs / the projection
+  float* ccvec;        //                   and their corrected bias [max(C, D)]
   TfBufs tf;
   int T[MER_MAX_CONV];
 };
@@ -315,7 +311,11 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   p.pospack = take16(ar, (long long)B * (Tn + c.pos_k) * D, clo);
   p.posbuf = c.pos_layers > 0 ? (float*)ar.take(M * D * 4) : nullptr;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
-  tf_plan(ar, c.tf, M, p.tf, B);
+  int kmax = (int)C;
+  for (int i = 1; i < c.n_conv; ++i) kmax = c.conv_kernel[i] * (int)C > kmax ? c.conv_kernel[i] * (int)C : kmax;
+  p.ccorr = c.conv_passes == 5 ? ar.take(mer_bias_corr_scratch_bytes(kmax)) : nullptr;
+  p.ccvec = c.conv_passes == 5 ? (float*)ar.take((C > D ? C : D) * 4) : nullptr;
+  tf_plan(ar, c.tf, M, p.tf);
   return ar.off;
 }
 
@@ -362,6 +362,10 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   MER_REQUIRE(Tn >= 1, MER_ESHAPE, "mer_hubert_forward: input too short");
   const int M = B * Tn;
   const P16 none = {nullptr, nullptr};
+  // conv_passes == 5: batch-mean correction of the conv GEMMs (padded rows of a ragged batch are not excluded here: the conv
+  // stack's frames of the zero tail are a small share of the sampled windows)
+  const CorrWs ccw = {p.ccorr, p.ccvec, 0, nullptr};
+  const CorrWs* cw = p.ccorr ? &ccw : nullptr;
 
   // ragged batch: per-row valid frame counts after conv 0 (GroupNorm statistics) and after the stack (positional conv zeros,
   // attention key mask), derived on the device from the rows' sample counts
@@ -402,11 +406,11 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
       g.act = MER_ACT_GELU;
       if (last) { g.c32 = p.conv_last32; g.ldc32 = C; }
       if (!last || !c.feat_proj_layer_norm) { g.c16_hi = (last ? p.fp16.hi : dst.hi); g.c16_lo = (last ? p.fp16.lo : dst.lo); g.ldc16 = C; }
-      MER_TRY(mer_gemm16(&g, stream));
+      MER_TRY(run_gemm(st, g, cw));
     } else {
       g.act = MER_ACT_NONE;
       g.c32 = p.conv32; g.ldc32 = C;
-      MER_TRY(mer_gemm16(&g, stream));
+      MER_TRY(run_gemm(st, g, cw));
       const bool want32 = last && c.feat_proj_layer_norm;
       P16 o = last ? p.fp16 : dst;
       MER_TRY(mer_layernorm(p.conv32, C, w.conv_norm_g[i], w.conv_norm_b[i], 1e-5f, B * p.T[i], C, MER_ACT_GELU,
@@ -417,7 +421,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   // feature projection: LayerNorm(C) -> Linear(C -> D)   (HF:hubert/modeling_hubert.py:216-231)
   if (c.feat_proj_layer_norm)
     MER_TRY(mer_layernorm(p.conv_last32, C, w.fp_ln_g, w.fp_ln_b, c.tf.ln_eps, M, C, MER_ACT_NONE, nullptr, 0, p.fp16.hi, p.fp16.lo, C, dt, st));
-  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0));
+  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, 0, 0, cw));
 
   // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
   HsMap hs;
@@ -441,7 +445,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
       g.a_so = (long long)G * (Tn + K) * Dg; g.a_si = (long long)(Tn + K) * Dg;
       g.w_si = (long long)Dg * K * Dg; g.bias_si = Dg;
       g.c_so = (long long)Tn * D; g.c_si = Dg;
-      g.passes = cps == 4 ? 2 : cps;   // batched narrow GEMM: the MX kernel does not cover it, say so up front
+      g.passes = (cps == 4 || cps == 5) ? 2 : cps;   // batched narrow GEMM: neither the MX kernel nor the mean correction covers it, say so up front
       if (!d2v) {  // HuBERT / wav2vec2: GELU and the residual ride in the epilogue
         g.act = MER_ACT_GELU;
         g.residual = p.hproj; g.ldr = D;
@@ -519,7 +523,7 @@ static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   p.x = (float*)ar.take(N * (P + 1) * D * 4);
   p.cls16 = take16(ar, (long long)N * D, lo);
   p.feats = (float*)ar.take((long long)N * c.proj_dim * 4);
-  tf_plan(ar, c.tf, N * (P + 1), p.tf, N);
+  tf_plan(ar, c.tf, N * (P + 1), p.tf);
   return ar.off;
 }
 
@@ -553,8 +557,9 @@ extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int
   const P16 none = {nullptr, nullptr};
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
+  const CorrWs pcw = {p.tf.corr, p.tf.cvec, 0, nullptr};   // (scratch sized for K <= max(D, F): the patch rows qualify when cols <= that)
   MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, c.variant == 1 ? w.patch_b : nullptr, MER_ACT_NONE, nullptr, 0,
-               p.patch32, D, none, 0));
+               p.patch32, D, none, 0, 0, 0, (p.tf.corr && cols <= (c.tf.ffn > D ? c.tf.ffn : D)) ? &pcw : nullptr));
   // [CLS] + position embeddings (+ pre_layrnorm for CLIP; DINOv2 has no embedding LayerNorm: gamma == NULL stores the plain sum)
   MER_TRY(mer_vit_assemble(p.patch32, w.cls, w.pos, c.variant == 0 ? w.pre_ln_g : nullptr, c.variant == 0 ? w.pre_ln_b : nullptr,
                            c.tf.ln_eps, N, P, D, p.x, nullptr, nullptr, dt, st));
@@ -616,7 +621,7 @@ static long long vmae_plan(const mer_videomae* h, Arena& ar, int B, VmaePlan& p)
   const long long cols = (long long)c.channels * c.tubelet_size * c.patch_size * c.patch_size;
   p.patches = take16(ar, B * NP * cols, c.tf.passes == 3);
   p.x = (float*)ar.take(B * NP * D * 4);
-  tf_plan(ar, c.tf, B * NP, p.tf, B);
+  tf_plan(ar, c.tf, B * NP, p.tf);
   return ar.off;
 }
 extern "C" long long mer_videomae_workspace_bytes(const mer_videomae* h, int B) {
@@ -645,7 +650,9 @@ extern "C" int mer_videomae_forward(const mer_videomae* h, const float* pixels, 
   // tubelet embedding: Conv3d(stride == kernel, bias) == GEMM over tubelet rows; + fixed sin-cos positions
   MER_TRY(mer_video_patchify(pixels, B, c.num_frames, c.channels, c.image_size, c.image_size, c.patch_size, c.tubelet_size,
                              p.patches.hi, p.patches.lo, dt, st));
-  MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0));
+  const CorrWs pcw = {p.tf.corr, p.tf.cvec, 0, nullptr};
+  MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0, 0, 0,
+               (p.tf.corr && cols <= (c.tf.ffn > D ? c.tf.ffn : D)) ? &pcw : nullptr));
   MER_TRY(mer_add_pos(x, w.pos, (long long)B * NP, NP, D, st));
   HsMap hs;
   hs.base = x; hs.stride = 0; hs.ring = 1;
@@ -693,7 +700,7 @@ static long long bert_plan(const mer_bert* h, Arena& ar, int B, int T, bool want
   const int E = h->cfg.emb_dim;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
   p.emb16 = (E > 0 && E != D) ? take16(ar, M * E, h->cfg.tf.passes == 3) : P16{nullptr, nullptr};
-  tf_plan(ar, h->cfg.tf, M, p.tf, B);
+  tf_plan(ar, h->cfg.tf, M, p.tf);
   return ar.off;
 }
 extern "C" long long mer_bert_workspace_bytes(const mer_bert* h, int B, int T, int want_hidden_states) {

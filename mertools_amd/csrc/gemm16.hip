@@ -176,12 +176,6 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
   p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0; p.a_blk = 0; p.c16_blk = 0;
   p.bias = a->bias; p.act = a->act;
-  p.bias_seg = 0; p.bias_ld = 0;
-  if (a->bias_seg_rows > 0) {
-    MER_REQUIRE(a->bias && a->bias_seg_rows >= 4 && a->bias_ld >= a->N && a->bias_ld % 4 == 0 && (((uintptr_t)a->bias) & 15) == 0 && nbatch_of(a) == 1,
-                MER_ESHAPE, "mer_gemm16: a per-segment bias table needs bias, bias_seg_rows >= 4, bias_ld >= N, bias_ld %% 4 == 0, 16-byte alignment, no batching");
-    p.bias_seg = a->bias_seg_rows; p.bias_ld = a->bias_ld;
-  }
   p.residual = a->residual; p.ldr = a->ldr;
   p.c32 = a->c32; p.ldc32 = a->ldc32;
   p.c16_hi = a->c16_hi; p.c16_lo = a->c16_lo; p.ldc16 = a->ldc16;
@@ -206,7 +200,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
              (!a->bias || ((((uintptr_t)a->bias) & 15) == 0 && a->bias_si % 4 == 0))) ? 1 : 0;   // its static bias is one 16-byte load per lane
   // packed-pair epilogue: 16-bit output only (no fp32 copy, residual or lo plane), row-major, every column group of 8 in range
   p.pk_epi = (g_gemm_pkepi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 && !a->c16_blocked &&
-              a->act != MER_ACT_RELU && (a->bias_seg_rows == 0 || a->act == MER_ACT_NONE || a->act == MER_ACT_GELU)) ? 1 : 0;
+              a->act != MER_ACT_RELU) ? 1 : 0;
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;

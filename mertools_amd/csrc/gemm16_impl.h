@@ -42,7 +42,6 @@ struct Gemm16Params {
   int a_blk;          // a_hi is a blocked activation plane written by a producer GEMM with c16_blk (same block geometry, rows = M)
   int c16_blk;        // > 0: the 16-bit output is written blocked for a consumer with K = N: value = N / 32 (k-slabs per row tile)
   const float* bias; int act;
-  int bias_seg; long long bias_ld;   // bias_seg > 0: bias is a table fp32 [ceil(M / bias_seg), bias_ld]: row m adds bias[(m / bias_seg) * bias_ld + n]
   const float* residual; long long ldr;
   float* c32; long long ldc32;
   void* c16_hi; void* c16_lo; long long ldc16;
@@ -383,7 +382,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const float* bias = p.bias ? p.bias + (long long)zi * p.bias_si : nullptr;
   // the static bias of this lane's 8 columns, as two vector registers (a float[8] that is later re-read as vectors ends up in scratch)
   f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
-  if (bias && p.bias_seg == 0) {
+  if (bias) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bv0[j] = col + j < p.N ? bias[col + j] : 0.f;
@@ -438,12 +437,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL);
           const f32x4 a1 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL + 4);
           float v[CPL];
-          f32x4 b0 = bv0, b1 = bv1;
-          if (p.bias_seg > 0) {   // per-segment bias table (one-pass GEMM + segment-mean weight-residual correction)
-            const float* bp = bias + (long long)(row / p.bias_seg) * p.bias_ld + col;
-            b0 = *reinterpret_cast<const f32x4*>(bp);
-            b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-          }
+          const f32x4 b0 = bv0, b1 = bv1;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             v[j] = act_apply(a0[j] + b0[j], ACT);
@@ -491,7 +485,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           if (row >= p.M || !col_ok) continue;
           for (int j = 0; j < CPL; ++j) {
             if (col + j >= p.N) break;
-            const float bsc = !bias ? 0.f : (p.bias_seg > 0 ? bias[(long long)(row / p.bias_seg) * p.bias_ld + col + j] : bias[col + j]);
+            const float bsc = !bias ? 0.f : bias[col + j];
             float x = act_apply(ct[lr * CLD + c8 * CPL + j] + bsc, ACT);
             if (res) x += res[(long long)row * p.ldr + col + j];
             if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
@@ -511,9 +505,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // transposition, so the staging tile holds row PAIRS: half the ds_write_b32 (the LDS pipe's slowest instruction, 64 B/clk/CU:
   // 4096 of its cycles per 256x256 fp32 tile) and half the read-back; a lane then owns 8 columns of a row pair and un-zips
   // them with v_perm_b32 into two 16-byte stores.
-  auto epilogue_pk = [&](auto act_tag, auto seg_tag) __attribute__((always_inline)) {
+  auto epilogue_pk = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
-    constexpr bool SEG = decltype(seg_tag)::value;   // per-segment bias table (compile-time: the plain-bias path pays nothing for it)
     constexpr int CLDP = SN + 8;                 // dwords per staged row pair; 2 * CLDP % 32 == 16: the two lg halves of a ds_write_b32 group never share a bank
     constexpr int PAIRS = EROWS / 2;
     constexpr int PAIRS_IT = 64 / LANES_PER_ROW;
@@ -524,7 +517,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
       const int c = n0 + wn * SN + nt * 16 + li;
-      bcol[nt] = (bias && p.bias_seg == 0 && c < p.N) ? bias[c] : 0.f;
+      bcol[nt] = (bias && c < p.N) ? bias[c] : 0.f;
     }
 #pragma unroll
     for (int ch = 0; ch < SM / EROWS; ++ch) {
@@ -536,20 +529,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         for (int nt = 0; nt < TN; ++nt) {
           const f32x4 a = acc[ch * (EROWS / 16) + mt][nt];
           typename T16<T>::v4 h;
-          float br[4] = {bcol[nt], bcol[nt], bcol[nt], bcol[nt]};
-          if constexpr (SEG) {   // a lane's four rows span at most two segments (bias_seg >= 4)
-            const int rowb = m0 + wm * SM + ch * EROWS + mt * 16 + lg * 4;
-            const int rl = p.M - 1;
-            const int s0 = (rowb < rl ? rowb : rl) / p.bias_seg, s3 = (rowb + 3 < rl ? rowb + 3 : rl) / p.bias_seg;
-            const int c = n0 + wn * SN + nt * 16 + li;
-            const float v0 = c < p.N ? bias[(long long)s0 * p.bias_ld + c] : 0.f;
-            const float v3 = (s3 != s0 && c < p.N) ? bias[(long long)s3 * p.bias_ld + c] : v0;
-            const int edge = (s0 + 1) * p.bias_seg;   // first row of the next segment
 #pragma unroll
-            for (int r = 0; r < 4; ++r) br[r] = rowb + r < edge ? v0 : v3;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = T16<T>::from_f32(act_apply(a[r] + br[r], ACT));
+          for (int r = 0; r < 4; ++r) h[r] = T16<T>::from_f32(act_apply(a[r] + bcol[nt], ACT));
           const u32x2 pk = __builtin_bit_cast(u32x2, h);
           cp[(mt * 8 + lg * 2 + 0) * CLDP + nt * 16 + li] = pk[0];   // rows 4 lg + {0, 1}
           cp[(mt * 8 + lg * 2 + 1) * CLDP + nt * 16 + li] = pk[1];   // rows 4 lg + {2, 3}
@@ -579,15 +560,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // fp32-only outputs (attention output projection, fc2: + residual): the generic path's 8 columns per lane make every store /
   // residual-load instruction touch 16 bytes out of every 32 (two instructions per 128-byte line).  Here a lane owns 4 columns:
   // 16 lanes cover a wave's 256-byte row run, one instruction = 4 whole rows, loads and stores are whole lines (and may stream).
-  auto epilogue32 = [&](auto act_tag, auto seg_tag) __attribute__((always_inline)) {
+  auto epilogue32 = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
-    constexpr bool SEG = decltype(seg_tag)::value;
     constexpr int LPR = SN / 4, RIT = 64 / LPR, NIT4 = EROWS / RIT;
     const int c4 = lane % LPR, rs = lane / LPR;
     const int col4 = n0 + wn * SN + c4 * 4;
     const bool ok4 = col4 < p.N;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (bias && p.bias_seg == 0 && ok4) b4 = *reinterpret_cast<const f32x4*>(bias + col4);   // (vec: N % 8 == 0; bias is 16-byte aligned: checked on the host)
+    if (bias && ok4) b4 = *reinterpret_cast<const f32x4*>(bias + col4);   // (vec: N % 8 == 0; bias is 16-byte aligned: checked on the host)
 #pragma unroll
     for (int ch = 0; ch < SM / EROWS; ++ch) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -618,8 +598,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         const int row = row0 + it * RIT;
         if (row < p.M && ok4) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ct + (it * RIT + rs) * CLD + c4 * 4);
-        f32x4 v, bb = b4;
-        if constexpr (SEG) bb = *reinterpret_cast<const f32x4*>(bias + (long long)(row / p.bias_seg) * p.bias_ld + col4);
+        f32x4 v;
+        const f32x4 bb = b4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + bb[j], ACT);
         if (res) v += rr[it];
@@ -635,29 +615,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   if (p.epi32) {   // host-checked: vector accesses, fp32 output only
     if ((p.dbg_skip & 3) == 1) c32 = nullptr;
     // (the host routes other activations to the generic path)
-    if (p.bias_seg > 0) {
-      if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{}, std::integral_constant<bool, true>{});
-      else epilogue32(std::integral_constant<int, MER_ACT_NONE>{}, std::integral_constant<bool, true>{});
-    } else {
-      if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{}, std::integral_constant<bool, false>{});
-      else epilogue32(std::integral_constant<int, MER_ACT_NONE>{}, std::integral_constant<bool, false>{});
-    }
+    if (p.act == MER_ACT_GELU) epilogue32(std::integral_constant<int, MER_ACT_GELU>{});
+    else epilogue32(std::integral_constant<int, MER_ACT_NONE>{});
     return;
   }
   if ((p.dbg_skip & 3) == 1) { c32 = nullptr; c16h = nullptr; c16l = nullptr; }
-  if (p.pk_epi) {   // host-checked: vector stores, 16-bit output only, row-major; a bias table only with act none / gelu
-    typedef std::integral_constant<bool, false> NoSeg;
-    typedef std::integral_constant<bool, true> Seg;
-    if (p.bias_seg > 0) {
-      if (p.act == MER_ACT_GELU) epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}, Seg{});
-      else epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}, Seg{});
-      return;
-    }
+  if (p.pk_epi) {   // host-checked: vector stores, 16-bit output only, row-major
     switch (p.act) {
-      case MER_ACT_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}, NoSeg{}); break;
-      case MER_ACT_QUICK_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_QUICK_GELU>{}, NoSeg{}); break;
-      case MER_ACT_GELU_TANH: epilogue_pk(std::integral_constant<int, MER_ACT_GELU_TANH>{}, NoSeg{}); break;
-      default: epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}, NoSeg{}); break;
+      case MER_ACT_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_GELU>{}); break;
+      case MER_ACT_QUICK_GELU: epilogue_pk(std::integral_constant<int, MER_ACT_QUICK_GELU>{}); break;
+      case MER_ACT_GELU_TANH: epilogue_pk(std::integral_constant<int, MER_ACT_GELU_TANH>{}); break;
+      default: epilogue_pk(std::integral_constant<int, MER_ACT_NONE>{}); break;
     }
     return;
   }

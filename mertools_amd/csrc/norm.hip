@@ -152,43 +152,101 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, lon
   }
 }
 
-// Per-segment mean rows of a 16-bit plane (see mer_seg_mean16 in the header): workgroup = (segment, 512-column slice); a lane
-// owns 8 consecutive columns (one 16-byte load per sampled row), the four waves take every fourth sampled row and meet in LDS.
+// Batch-mean weight-residual correction (precision "mean", passes == 5).  The rounding error of a weight matrix
+// is the same perturbation a (W - f16(W))^T for every token, and nearly all of it acts through the MEAN activation of the batch
+// (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass), i.e. it is a
+// bias:  c[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k].  Two tiny kernels in front of the one-pass GEMM, both latency-bound, so
+// both are shaped for loads in flight rather than for bytes:
+//   colmean16_kernel   workgroup = a 64-column slice of the 16-bit A plane, 16 waves; one wave-load = 8 sampled rows x 128 B (whole
+//                      lines), every lane's loads independent (CM_ROWS / 128 of them in flight); rows addressed like mer_gemm16's A
+//                      operand, padded rows of ragged batches skipped; the slice's column means leave as fp32, no cross-workgroup step
+//   bias_corr_kernel   the mean vector into LDS, then one wave per 4 output columns takes the dot products with the residual
+//                      plane rows (a GEMV over [N, K])
+constexpr int CM_ROWS = 2048;   // sampled rows (every row when M is smaller)
 template <typename T>
-__global__ __launch_bounds__(256) void seg_mean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int seg_rows,
-                                                         int stride, const int* valid_rows, T* out, long long ldo) {
+__global__ __launch_bounds__(1024) void colmean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int stride,
+                                                         int seg_rows, const int* valid_rows, float* mean) {
   typedef typename T16<T>::v8 v8;
-  __shared__ float part[4][64 * 8];
-  const int seg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.y * 512 + lane * 8;
-  const int r0 = seg * seg_rows;
-  int nv = M - r0 < seg_rows ? M - r0 : seg_rows;
-  if (valid_rows) nv = valid_rows[seg] < nv ? valid_rows[seg] : nv;
-  const int cnt = nv > 0 ? (nv + stride - 1) / stride : 0;
+  __shared__ float red[16][64];
+  __shared__ int rcnt[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 3, cg = lane & 7;
+  const int col = blockIdx.x * 64 + cg * 8;
+  const bool cin = col < K;
+  const int R = (M + stride - 1) / stride;   // sampled rows
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (col < K) {
-    for (int i = wave; i < cnt; i += 4) {
-      const int r = r0 + i * stride;
+  int n = 0;
+#pragma unroll 4
+  for (int i = wave * 8 + sub; i < R; i += 128) {
+    const int r = i * stride;
+    if (valid_rows && (r % seg_rows) >= valid_rows[r / seg_rows]) continue;
+    ++n;
+    if (cin) {
       const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
       const v8 x = *reinterpret_cast<const v8*>(a + off + col);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += T16<T>::to_f32(x[j]);
     }
   }
+  // the 8 row groups of a wave (lanes cg, cg + 8, ...), then the 16 waves through LDS — fixed order: deterministic
 #pragma unroll
-  for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 8);
+    acc[j] += __shfl_xor(acc[j], 16);
+    acc[j] += __shfl_xor(acc[j], 32);
+  }
+  int nn = cg == 0 ? n : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o);
+  if (sub == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][cg * 8 + j] = acc[j];
+  }
+  if (lane == 0) rcnt[wave] = nn;
   __syncthreads();
-  if (wave == 0 && col < K) {
-    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
-    v8 o;
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    int total = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = lane * 8 + j;
-      o[j] = T16<T>::from_f32(((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) * inv);
+    for (int w = 0; w < 16; ++w) {
+      s += red[w][threadIdx.x];
+      total += rcnt[w];
     }
-    *reinterpret_cast<v8*>(out + (long long)seg * ldo + col) = o;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < K) mean[c] = total > 0 ? s / (float)total : 0.f;
+  }
+}
+
+constexpr int BC_COLS = 16;   // output columns per workgroup (4 per wave)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_corr_kernel(const float* mean_g, int K, const T* w_lo, long long ldw,
+                                                        const float* bias, int N, float* out) {
+  typedef typename T16<T>::v8 v8;
+  extern __shared__ __attribute__((aligned(16))) float mean[];   // [K]
+  for (int k = threadIdx.x * 4; k < K; k += 1024) *reinterpret_cast<f32x4*>(mean + k) = *reinterpret_cast<const f32x4*>(mean_g + k);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s[BC_COLS / 4];
+#pragma unroll
+  for (int j = 0; j < BC_COLS / 4; ++j) {
+    const int n = blockIdx.x * BC_COLS + wave * (BC_COLS / 4) + j;
+    s[j] = 0.f;
+    if (n >= N) continue;   // wave-uniform
+    const T* wr = w_lo + (long long)n * ldw;
+    for (int k = lane * 8; k < K; k += 512) {
+      const v8 w = *reinterpret_cast<const v8*>(wr + k);
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + k), m1 = *reinterpret_cast<const f32x4*>(mean + k + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[j] += T16<T>::to_f32(w[e]) * m0[e] + T16<T>::to_f32(w[4 + e]) * m1[e];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BC_COLS / 4; ++j) {
+    const int n = blockIdx.x * BC_COLS + wave * (BC_COLS / 4) + j;
+    const float t = wave_sum(s[j]);
+    if (lane == 0 && n < N) out[n] = t + (bias ? bias[n] : 0.f);
   }
 }
 
@@ -349,24 +407,37 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
   return check_launch("layernorm");
 }
 
-extern "C" int mer_seg_mean16(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
-                              int seg_rows, int stride, const int* valid_rows, void* out16, long long ldo, mer_stream_t stream) {
+extern "C" long long mer_bias_corr_scratch_bytes(int K) {
+  if (K <= 0) return 0;
+  return ((long long)K * 4 + 255) / 256 * 256;   // the mean vector [K] fp32
+}
+
+extern "C" int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
+                             int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
+                             void* scratch, float* out, mer_stream_t stream) {
   using namespace mer;
-  MER_REQUIRE(a && out16 && M > 0 && K > 0 && seg_rows > 0 && stride > 0, MER_EINVAL, "mer_seg_mean16: bad argument");
-  MER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldo % 8 == 0 && a_batch_stride % 8 == 0 && ((((uintptr_t)a | (uintptr_t)out16) & 15) == 0), MER_ESHAPE,
-              "mer_seg_mean16: K, lda, ldo, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
-  MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_seg_mean16: bad dtype");
-  const int nseg = (int)cdiv(M, seg_rows);
-  dim3 grid(nseg, (unsigned)cdiv(K, 512)), block(256);
+  MER_REQUIRE(a && w_lo && scratch && out && M > 0 && K > 0 && N > 0, MER_EINVAL, "mer_bias_corr: bad argument");
+  MER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && a_batch_stride % 8 == 0 && ((((uintptr_t)a | (uintptr_t)w_lo | (uintptr_t)scratch) & 15) == 0), MER_ESHAPE,
+              "mer_bias_corr: K, lda, ldw, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
+  MER_REQUIRE(K <= 16384, MER_EUNSUPPORTED, "mer_bias_corr: K=%d > 16384", K);
+  MER_REQUIRE(!valid_rows || seg_rows > 0, MER_EINVAL, "mer_bias_corr: valid_rows needs seg_rows");
+  MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_bias_corr: bad dtype");
   hipStream_t st = (hipStream_t)stream;
-  ProfScope prof("seg_mean16", 0.0, (double)nseg * cdiv(seg_rows, stride) * K * 2 + (double)nseg * K * 2, st);
-  if (dtype == MER_DT_F16)
-    hipLaunchKernelGGL((seg_mean16_kernel<f16>), grid, block, 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, stride,
-                       valid_rows, (f16*)out16, ldo);
-  else
-    hipLaunchKernelGGL((seg_mean16_kernel<bf16>), grid, block, 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, stride,
-                       valid_rows, (bf16*)out16, ldo);
-  return check_launch("seg_mean16");
+  float* mean = (float*)scratch;
+  // about CM_ROWS evenly spaced rows (every row below that): the mean of >= 2048 tokens is far inside what the correction needs
+  const int stride = M > CM_ROWS ? M / CM_ROWS : 1;
+  dim3 g1((unsigned)cdiv(K, 64)), g2((unsigned)cdiv(N, BC_COLS));
+  {
+    ProfScope prof("bias_corr", 2.0 * N * K, (double)cdiv(M, stride) * K * 2 + (double)N * K * 2, st);
+    if (dtype == MER_DT_F16) {
+      hipLaunchKernelGGL((colmean16_kernel<f16>), g1, dim3(1024), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, mean);
+      hipLaunchKernelGGL((bias_corr_kernel<f16>), g2, dim3(256), (size_t)K * 4, st, mean, K, (const f16*)w_lo, ldw, bias, N, out);
+    } else {
+      hipLaunchKernelGGL((colmean16_kernel<bf16>), g1, dim3(1024), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, mean);
+      hipLaunchKernelGGL((bias_corr_kernel<bf16>), g2, dim3(256), (size_t)K * 4, st, mean, K, (const bf16*)w_lo, ldw, bias, N, out);
+    }
+  }
+  return check_launch("bias_corr");
 }
 
 extern "C" int mer_vit_assemble(const float* patch, const float* cls, const float* pos, const float* gamma,

@@ -57,7 +57,7 @@ def split16_host(x, dtype="f16", lo=True):
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
            out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
-           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, c16_blocked=False, a_blocked=False, bias_seg_rows=0):
+           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, c16_blocked=False, a_blocked=False):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -73,8 +73,6 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.w_hi_blk, g.w_lo_blk = _p(w_hi_blk), _p(w_lo_blk)
     g.c16_blocked, g.a_blocked = int(c16_blocked), int(a_blocked)
     g.bias, g.act = _p(bias), ACT[act]
-    if bias_seg_rows:   # bias is a per-segment table [ceil(M / bias_seg_rows), ld]
-        g.bias_seg_rows, g.bias_ld = int(bias_seg_rows), bias.stride(0)
     g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     dev = a_hi.device
     c32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out32 else None
@@ -115,15 +113,15 @@ def w_block_pack(w16):
     return out
 
 
-def seg_mean16(a16, seg_rows, stride=1, valid_rows=None, M=None):
-    """Per-segment mean rows of a 16-bit plane [M, K] -> [ceil(M / seg_rows), K] (mer_seg_mean16)."""
-    assert a16.is_cuda and a16.dim() == 2 and a16.stride(1) == 1
+def bias_corr(a16, w_lo, bias=None, valid_rows=None, seg_rows=0, M=None):
+    """out[n] = bias[n] + mean_rows(a16)[k] * w_lo[n, k] (mer_bias_corr): the batch-mean weight-residual correction of a one-pass GEMM."""
+    assert a16.is_cuda and a16.dim() == 2 and a16.stride(1) == 1 and w_lo.dim() == 2 and w_lo.stride(1) == 1
     M = M if M is not None else a16.shape[0]
-    K = a16.shape[1]
-    nseg = (M + seg_rows - 1) // seg_rows
-    out = torch.empty((nseg, K), dtype=a16.dtype, device=a16.device)
-    _lib.check(_lib.lib().mer_seg_mean16(a16.data_ptr(), dt_code(a16.dtype), a16.stride(0), 0, 0, M, K, int(seg_rows), int(stride), _p(valid_rows),
-                                         out.data_ptr(), K, stream()), "mer_seg_mean16")
+    K, N = a16.shape[1], w_lo.shape[0]
+    scratch = torch.empty(_lib.lib().mer_bias_corr_scratch_bytes(K), dtype=torch.uint8, device=a16.device)
+    out = torch.empty(N, dtype=torch.float32, device=a16.device)
+    _lib.check(_lib.lib().mer_bias_corr(a16.data_ptr(), dt_code(a16.dtype), a16.stride(0), 0, 0, M, K, int(seg_rows), _p(valid_rows),
+                                        w_lo.data_ptr(), w_lo.stride(0), _p(bias), N, scratch.data_ptr(), out.data_ptr(), stream()), "mer_bias_corr")
     return out
 
 

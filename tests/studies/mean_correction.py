@@ -12,6 +12,7 @@ from mertools_amd import synthetic as W
 from oracle import encoders_ref as R
 
 MODE = {"corr": "none"}
+CAL = {"rec": None, "i": 0}   # "cal" mode: per-call-site mean tokens recorded on a calibration batch, replayed on the test batch
 _lin, _conv = F.linear, F.conv1d
 
 
@@ -22,6 +23,14 @@ def lin(x, w, b=None):
         out = out + _lin(a16, wl)
     elif MODE["corr"] == "mean":
         m = a16.mean(dim=-2, keepdim=True) if a16.dim() >= 3 else a16      # [B, 1, K]: the clip's (frame's) mean token
+        out = out + _lin(m, wl)
+    elif MODE["corr"] == "gmean":                                           # ONE mean token for the whole batch (all clips, all tokens)
+        m = a16.reshape(-1, a16.shape[-1]).mean(dim=0, keepdim=True)
+        out = out + _lin(m, wl)
+    elif MODE["corr"] == "calrec":
+        CAL["rec"].append(a16.reshape(-1, a16.shape[-1]).mean(dim=0, keepdim=True))
+    elif MODE["corr"] == "cal":
+        m = CAL["rec"][CAL["i"]]; CAL["i"] += 1
         out = out + _lin(m, wl)
     elif MODE["corr"].startswith("sub"):                                    # mean over every s-th token only
         st = int(MODE["corr"][3:])
@@ -40,6 +49,14 @@ def conv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     out = _conv(a16, wh, None, stride, padding, dilation, groups)
     if MODE["corr"] == "exact":
         out = out + _conv(a16, wl, None, stride, padding, dilation, groups)
+    elif MODE["corr"] == "gmean":
+        full = _conv(a16, wl, None, stride, padding, dilation, groups)
+        out = out + full.mean(dim=(0, 2), keepdim=True)
+    elif MODE["corr"] == "calrec":
+        CAL["rec"].append(_conv(a16, wl, None, stride, padding, dilation, groups).mean(dim=(0, 2), keepdim=True))
+    elif MODE["corr"] == "cal":
+        m = CAL["rec"][CAL["i"]]; CAL["i"] += 1
+        out = out + m
     elif MODE["corr"] == "mean" or MODE["corr"].startswith("sub"):
         # mean over the output positions of the im2col rows == conv of the correction evaluated on the mean window
         full = _conv(a16, wl, None, stride, padding, dilation, groups)       # [B, Co, T]
@@ -69,8 +86,20 @@ def main():
     with torch.no_grad():
         h0, c0, t0 = run()
         R.F.linear, R.F.conv1d = lin, conv
+        calkind = next((a[6:] for a in sys.argv[1:] if a.startswith("--cal=")), None)
+        if calkind:   # record the per-call-site means on a calibration batch
+            if calkind == "seed":      # same distribution, other samples
+                cw, cp, ci = W.synth_audio(2, 48000, seed=99), W.synth_frames(8, seed=98), W.synth_tokens(4, seed=97)
+            elif calkind == "odd":     # a deliberately different distribution: a 440 Hz tone, flat grey frames, one repeated token
+                tt = torch.arange(48000) / 16000.0
+                cw = torch.sin(2 * 3.14159265 * 440 * tt)[None].repeat(2, 1); cw = (cw - cw.mean(1, keepdim=True)) / cw.std(1, keepdim=True)
+                cp = torch.zeros(8, 3, 224, 224); ci = torch.full((4, 64), 1000, dtype=torch.long); ci[:, 0] = 0; ci[:, -1] = 2
+            CAL["rec"] = []; MODE["corr"] = "calrec"
+            torch.stack(R.hubert_hidden_states(hsd, vars(hc), cw)); R.clip_image_features(csd, ccfg, cp)
+            R.bert_hidden_states(bsd, dict(vars(bc), roberta=True), ci, torch.ones_like(ci))
         for mode in (sys.argv[1:] and [a for a in sys.argv[1:] if not a.startswith("--")] or ["none", "exact", "mean"]):
             MODE["corr"] = mode
+            CAL["i"] = 0
             h, c, t = run()
             print(f"{'heavy ' if heavy else ''}corr={mode:6s}: HuBERT utt {rel(h.mean(1), h0.mean(1)):.2e} frame {rel(h, h0):.2e} | "
                   f"CLIP utt {rel(c.mean(0), c0.mean(0)):.2e} frames {rel(c, c0):.2e} | RoBERTa utt {rel(t.mean(1), t0.mean(1)):.2e} frame {rel(t, t0):.2e}", flush=True)

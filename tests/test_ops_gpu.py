@@ -615,44 +615,53 @@ def test_image_resize_crop_u8_matches_pillow(dev, h, w, size):
         assert np.array_equal(out[n], ref), n
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3])
-@pytest.mark.parametrize("M,N,K,seg", [(2304, 768, 256, 197), (1000, 520, 96, 64), (4096, 1536, 128, 249)])
-def test_gemm16_per_segment_bias_table(dev, M, N, K, seg, tile):
-    """bias_seg_rows: row m adds table[m // seg, n] — in all three epilogues (16-bit-only / fp32-only with residual / both outputs),
-    with an activation on top (the bias is added before it)."""
-    ops = _ops()
-    a = _rand((M, K), 81)
-    w = _rand((N, K), 82) * 0.05
-    nseg = (M + seg - 1) // seg
-    table = _rand((nseg, N), 83)
-    res = _rand((M, N), 84)
-    ah, _ = ops.split16(a.to(dev), "f16", lo=False)
-    wh = ops.split16_host(w, "f16")[0].to(dev)
-    z = ah.double().cpu() @ wh.double().cpu().T + table.double()[torch.arange(M) // seg]
-    for act in (None, "gelu"):
-        true = _act_ref(z, act or "none")
-        _, c16, _ = ops.gemm16(ah, wh, bias=table.to(dev), bias_seg_rows=seg, act=act, out16=True, passes=1, tile=tile)
-        c32, _, _ = ops.gemm16(ah, wh, bias=table.to(dev), bias_seg_rows=seg, act=act, residual=res.to(dev), out32=True, passes=1, tile=tile)
-        b32, b16, _ = ops.gemm16(ah, wh, bias=table.to(dev), bias_seg_rows=seg, act=act, out32=True, out16=True, passes=1, tile=tile)
-        torch.cuda.synchronize()
-        assert_close(c16.float().cpu(), true.float(), 1.5e-3, f"segment bias, 16-bit epilogue (act={act})")
-        assert_close(c32.cpu(), (true + res.double()).float(), 2e-5, f"segment bias, fp32 epilogue (act={act})")
-        assert_close(b32.cpu(), true.float(), 2e-5, f"segment bias, generic epilogue fp32 (act={act})")
-        # (two differently compiled code paths: the fp32 value may differ in its last bit before the 16-bit rounding)
-        assert_close(b16.float().cpu(), c16.float().cpu(), 1e-3, "generic vs packed 16-bit epilogue under a segment bias")
-
-
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_seg_mean16(dev, dtype):
+@pytest.mark.parametrize("M,N,K", [(1000, 776, 776), (4096, 200, 96), (20000, 2304, 768), (9000, 768, 3072)])
+def test_bias_corr(dev, dtype, M, N, K):
+    """mer_bias_corr: out[n] = bias[n] + mean(sampled rows of A)[k] * w_lo[n, k] — against the same sample in fp64."""
     ops = _ops()
-    M, K, seg = 1000, 776, 197
-    x = _rand((M, K), 85).to(ops.torch16(dtype))
+    t16 = ops.torch16(dtype)
+    a = (_rand((M, K), 85) + 0.3).to(t16)
+    wl = (_rand((N, K), 86) * 1e-3).to(t16)
+    bias = _rand((N,), 87)
+    stride = M // 2048 if M > 2048 else 1
+    out = ops.bias_corr(a.to(dev), wl.to(dev), bias.to(dev))
+    out0 = ops.bias_corr(a.to(dev), wl.to(dev))
+    torch.cuda.synchronize()
+    mean = a[::stride].double().mean(0)
+    ref = wl.double() @ mean
+    assert_close(out0.cpu(), ref.float(), 2e-5, "bias_corr without bias")
+    assert (out.cpu() - out0.cpu() - bias).abs().max().item() < 1e-6 * (1 + bias.abs().max().item())
+    # the sample mean is the full mean to within its sampling noise
+    assert (mean - a.double().mean(0)).abs().max().item() < 0.15
+
+
+def test_bias_corr_skips_padded_rows(dev):
+    ops = _ops()
+    M, K, N, seg = 1000, 128, 64, 197
+    a = _rand((M, K), 88).half()
+    wl = (_rand((N, K), 89) * 1e-3).half()
     valid = torch.tensor([197, 50, 1, 197, 100, 15], dtype=torch.int32)
-    for stride in (1, 8):
-        out = ops.seg_mean16(x.to(dev), seg, stride=stride, valid_rows=valid.to(dev))
-        torch.cuda.synchronize()
-        assert out.shape == (6, K)
-        for s_ in range(6):
-            n = min(int(valid[s_]), M - s_ * seg)
-            ref = x[s_ * seg: s_ * seg + n: stride].double().mean(0)
-            assert_close(out[s_].float().cpu(), ref.float(), 5e-3 if dtype == "bf16" else 6e-4, f"segment {s_} mean (stride {stride})")
+    out = ops.bias_corr(a.to(dev), wl.to(dev), valid_rows=valid.to(dev), seg_rows=seg)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(s_ * seg, s_ * seg + min(int(valid[s_]), M - s_ * seg)) for s_ in range(6)])
+    ref = wl.double() @ a[rows].double().mean(0)
+    assert_close(out.cpu(), ref.float(), 2e-5, "bias_corr over the valid rows of a ragged batch")
+
+
+def test_gemm_with_bias_corr_matches_two_pass_on_the_mean(dev):
+    """One pass + the batch-mean correction reproduces the exact weight-residual term wherever the activations share a mean."""
+    ops = _ops()
+    M, N, K = 4096, 768, 768
+    a = _rand((M, K), 90) * 0.2 + _rand((1, K), 91)          # a strong common component, as LayerNorm outputs have
+    w = _rand((N, K), 92) * 0.05
+    ah, _ = ops.split16(a.to(dev), "f16", lo=False)
+    wh, wl = ops.split16_host(w, "f16", True)
+    c = ops.bias_corr(ah, wl.to(dev))
+    o1, _, _ = ops.gemm16(ah, wh.to(dev), bias=c, out32=True, passes=1)
+    o0, _, _ = ops.gemm16(ah, wh.to(dev), out32=True, passes=1)
+    torch.cuda.synchronize()
+    true = ah.double().cpu() @ w.double().T
+    e1 = (o1.double().cpu() - true).abs().max() / true.abs().max()
+    e0 = (o0.double().cpu() - true).abs().max() / true.abs().max()
+    assert e1 < 0.5 * e0, (e0.item(), e1.item())
