@@ -48,7 +48,10 @@ const char* mer_target_arch(void);
  * [{"name","calls","ms","flops","bytes"}] aggregated per kernel and clears the records. */
 /* sizeof() of a struct of this header by name ("mer_gemm16_args", ...) so bindings can verify layouts. */
 int mer_abi_sizeof(const char* name);
-/* Tuning knobs (A/B testing): "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged. */
+/* Debug switches — process-global, NOT thread-safe (set them while no forward is in flight); nothing on the product path needs them:
+ * "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged; "gemm_generic_epi" 1 = every GEMM takes the generic
+ * epilogue (bit-equality tests of the specialised ones); "gemm_dbg_skip" 1 / 2 = skip the epilogue's stores / the whole epilogue
+ * (timing decomposition); "gemm_stamp" 1 = s_memtime-instrumented kernels writing into mer_set_debug_buffer's buffer. */
 int mer_set_option(const char* name, int value);
 /* Kernel-phase timing for tuning: when non-NULL, every mer_gemm16 workgroup writes 4 s_memtime stamps (start, first
  * slab ready, K loop done, end) at buffer[4*workgroup ..], per-phase counters at [4*W + 16*workgroup ..] (gemm_stamp builds)
@@ -101,11 +104,6 @@ typedef struct {
    * 256x256 LDS-DMA kernels (a DMA piece becomes 1 KiB contiguous); NULL = not available.  w_lo_blk is only
    * needed for passes 2 / 3. */
   const void* w_hi_blk; const void* w_lo_blk;
-  /* blocked activation planes between two GEMMs (fc1 -> fc2): c16_blocked != 0 writes the 16-bit output as
-   * [ceil(M/256)][N/32] blocks of 16 KB (the LDS image of a 256-row x 32-k stage plane; c16_hi must hold
-   * ceil(M/256)*256 * N elements; N % 32 == 0); a_blocked != 0 reads a_hi in that form (K = the producer's N; only the
-   * 256x256 one-/two-pass kernels: M >= 1024, N >= 192, K % 32 == 0, no batching — anything else is MER_ESHAPE). */
-  int c16_blocked; int a_blocked;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
@@ -117,7 +115,9 @@ int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
  * is the same perturbation for every token, so what it does to the features goes almost entirely through the MEAN activation
  * (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass) — i.e. it
  * is a bias, and the GEMM that follows runs passes = 1 with `out` as its bias.  scratch: device, mer_bias_corr_scratch_bytes(K)
- * bytes, 16-byte aligned; out: device fp32 [N].  Two small launches on `stream`. */
+ * bytes, 16-byte aligned, ZERO on entry (64-bit fixed-point column-sum accumulators + a row counter: integer atomics, so the
+ * result is independent of workgroup order; the call leaves them non-zero — clear them before the next use); out: device fp32 [N].
+ * Two small launches on `stream`. */
 long long mer_bias_corr_scratch_bytes(int K);
 int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
                   int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
@@ -167,6 +167,12 @@ int mer_attention(const void* q, const void* k, const void* v, long long ld,
  * output), so every head's K/V tile is one contiguous 128*T-byte stream.  out stays row-major [B*T, ldo]. */
 int mer_attention_hm(const void* q, const void* k, const void* v, void* out_hi, void* out_lo, long long ldo,
                      int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
+
+/* Attention for ONE query per sequence (the [CLS] row of a ViT's last block, which is all get_image_features reads):
+ * q: 16-bit [B, ldq] (head h at columns [64h, 64h+64)), k / v: 16-bit [B*T, ld] as in mer_attention, out: 16-bit planes [B, ldo];
+ * fp32 softmax and accumulation; T <= 584. */
+int mer_attention_cls(const void* q, long long ldq, const void* k, const void* v, long long ld, void* out_hi, void* out_lo,
+                      long long ldo, int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
 
 /* fp32 -> 16-bit planes (lo may be NULL). n elements. */
 int mer_split16(const float* x, void* hi, void* lo, long long n, int dtype, mer_stream_t stream);

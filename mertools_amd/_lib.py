@@ -37,7 +37,6 @@ class GemmArgs(C.Structure):
         ("passes", c_int), ("tile", c_int), ("headmajor_T", c_int), ("headmajor_H", c_int),
         ("w_mx", c_void_p),
         ("w_hi_blk", c_void_p), ("w_lo_blk", c_void_p),
-        ("c16_blocked", c_int), ("a_blocked", c_int),
     ]
 
 
@@ -169,6 +168,7 @@ _PROTOS = {
                                    c_void_p, c_int, c_void_p, c_void_p]),
     "mer_hubert_forward_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
+    "mer_attention_cls": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "mer_bias_corr_scratch_bytes": (c_ll, [c_int]),
     "mer_bias_corr": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int,
                               c_void_p, c_void_p, c_void_p]),
@@ -232,7 +232,7 @@ def lib():
                 continue  # checked by tests/test_abi.py against the header
             fn.restype = res
             fn.argtypes = args
-        # tuning switches: MER_OPTIONS="gemm_store=0,attn_waves=4" -> mer_set_option() at load time
+        # debug switches (include/mer_hip.h: mer_set_option): MER_OPTIONS="gemm_generic_epi=1,gemm_dbg_skip=1" at load time
         for kv in filter(None, os.environ.get("MER_OPTIONS", "").split(",")):
             k, _, v = kv.partition("=")
             if h.mer_set_option(k.strip().encode(), int(v or "1")) != MER_OK:

@@ -21,11 +21,7 @@
 namespace mer {
 
 extern unsigned long long* g_gemm_dbg;
-int g_attn_waves = 8;      // mer_set_option("attn_waves", 4): 4-wave workgroups for every T (A/B testing)
-int g_attn_stream_qs = 2;  // mer_set_option("attn_stream_qs", 1): the streaming kernel with one 16-query sub-tile per wave (A/B testing)
-int g_attn_stream_pf = 0;  // mer_set_option("attn_stream_pf", 1): register prefetch of the next key block (measured slower at QS = 2: 487 vs 507 TF — the 28 extra VGPRs cost a resident wave per SIMD)
-int g_attn_nt = 0;         // mer_set_option("attn_nt", 1): K / V staging with non-temporal loads
-int g_attn_force_nkt = 0;  // tuning: force a larger single-pass instantiation (LDS footprint experiment)  // shared debug-stamp buffer (mer_set_debug_buffer)
+// shared debug-stamp buffer (mer_set_debug_buffer)
 
 // BIAS: scores get an additive term gate[b,h,q] * bias[h,q,k] before the softmax — WavLM's gated relative position bias
 // (HF:wavlm/modeling_wavlm.py WavLMAttention.forward: one [H,T,T] table shared by the batch and by all layers, a per-query
@@ -49,7 +45,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 
                                                       const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                       long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm, unsigned long long* dbg,
                                                       const float* __restrict__ bias = nullptr, long long ldb = 0,
-                                                      const float* __restrict__ gate = nullptr, int nt = 0) {
+                                                      const float* __restrict__ gate = nullptr) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
   constexpr int TP = NKT * 16;
@@ -87,14 +83,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 
       kreg[it] = u32x4{0u, 0u, 0u, 0u};
       vreg[it] = u32x4{0u, 0u, 0u, 0u};
       if (g0 + it < SIT && row < klen) {
-        // nt: a head's K / V are read once per (batch, head)
-        if (nt) {
-          kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8));
-          vreg[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8));
-        } else {
-          kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
-          vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
-        }
+        kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)row * ld + ch * 8);
+        vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)row * ld + ch * 8);
       }
     }
 #pragma unroll
@@ -450,17 +440,16 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
                        const float* bias = nullptr, long long ldb = 0, const float* gate = nullptr) {
   const float sl2 = scale * 1.4426950408889634f;
   dim3 grid(1, H, B), block(256), block8(512);  // one workgroup per (batch, head): K/V staged once
-  const bool w8 = g_attn_waves != 4;   // mer_set_option("attn_waves", 4): 4-wave workgroups everywhere (A/B)
   ProfScope prof(bias ? "attention_bias" : "attention", 4.0 * B * H * (double)Tn * Tn * 64, 2.0 * 4 * (double)B * Tn * H * 64, st);
   if (bias) {
 #define MER_ATTN_BCASE(N)                                                                                            \
   do {                                                                                                               \
-    if (w8 && N >= 8 && N <= 16)                                                                                     \
+    if (N >= 8 && N <= 16)                                                                                     \
       hipLaunchKernelGGL((attn_sp_kernel<T, N, true, (N >= 8 && N <= 16) ? 8 : 4>), grid, (N >= 8 && N <= 16) ? block8 : block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate, g_attn_nt);                     \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate);                     \
     else                                                                                                             \
       hipLaunchKernelGGL((attn_sp_kernel<T, N, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate, g_attn_nt);                     \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, bias, ldb, gate);                     \
   } while (0)
     if (Tn <= 64) MER_ATTN_BCASE(4);
     else if (Tn <= 128) MER_ATTN_BCASE(8);
@@ -477,18 +466,14 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   }
 #define MER_ATTN_CASE(N)                                                                                       \
   do {                                                                                                         \
-    if (w8 && N >= 8 && N <= 16)                                                                               \
+    if (N >= 8 && N <= 16)                                                                               \
       hipLaunchKernelGGL((attn_sp_kernel<T, N, false, (N >= 8 && N <= 16) ? 8 : 4>), grid, (N >= 8 && N <= 16) ? block8 : block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, nullptr, 0, nullptr, g_attn_nt);                                \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, nullptr, 0, nullptr);                                \
     else                                                                                                       \
       hipLaunchKernelGGL((attn_sp_kernel<T, N>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
-                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, nullptr, 0, nullptr, g_attn_nt);                                \
+                         (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm, g_gemm_dbg, nullptr, 0, nullptr);                                \
   } while (0)
-  const int f = g_attn_force_nkt;
-  if (f == 14 && Tn <= 224) MER_ATTN_CASE(14);
-  else if (f == 18 && Tn <= 288) MER_ATTN_CASE(18);
-  else if (f == 32 && Tn <= 512) MER_ATTN_CASE(32);
-  else if (Tn <= 64) MER_ATTN_CASE(4);
+  if (Tn <= 64) MER_ATTN_CASE(4);
   else if (Tn <= 128) MER_ATTN_CASE(8);
   else if (Tn <= 224) MER_ATTN_CASE(14);
   else if (Tn <= 256) MER_ATTN_CASE(16);
@@ -502,14 +487,107 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
     hipLaunchKernelGGL((attn_stream_kernel<T, QS_, PF_>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
                        (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm);                                                          \
   } while (0)
-    if (g_attn_stream_qs >= 2 && g_attn_stream_pf) MER_ATTN_STREAM(2, true);
-    else if (g_attn_stream_qs >= 2) MER_ATTN_STREAM(2, false);
-    else if (g_attn_stream_pf) MER_ATTN_STREAM(1, true);
-    else MER_ATTN_STREAM(1, false);
+    MER_ATTN_STREAM(2, false);   // (QS = 1 and the register-prefetch form measured slower: profiles/r02_attention_variants.jsonl)
 #undef MER_ATTN_STREAM
   }
 #undef MER_ATTN_CASE
   return check_launch("attention");
+}
+
+
+// One query per sequence (the [CLS] row of a ViT's last block: get_image_features only reads h[:, 0], HF:clip/modeling_clip.py:719-748):
+// out[b, h*64 ..] = softmax(q[b, h] . K[b, :, h]^T * scale) V[b, :, h].  One wave per (sequence, head); a wave-load covers 8 keys x
+// 128 B (whole lines): lane (sub, cg) owns dims 8 cg .. 8 cg + 7 of key 8 it + sub, so a key's score lands in the 8 lanes that
+// later scale the same key's V row — no LDS, no second pass over K; all fp32.  NIT = ceil(T / 8) bounds the register array.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, long long ldq, const T* __restrict__ k, const T* __restrict__ v,
+                                                       long long ld, T* __restrict__ oh, T* __restrict__ ol, long long ldo, int Tn, int H,
+                                                       int nbh, float scale, const int* __restrict__ kv_len) {
+  typedef typename T16<T>::v8 v8;
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= nbh) return;
+  const int b = bh / H, h = bh % H;
+  const int sub = lane >> 3, cg = lane & 7;
+  const int klen = kv_len ? (kv_len[b] < Tn ? kv_len[b] : Tn) : Tn;
+  const v8 qv = *reinterpret_cast<const v8*>(q + (long long)b * ldq + h * 64 + cg * 8);
+  float qf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qf[j] = T16<T>::to_f32(qv[j]) * scale;
+  const T* kb = k + (long long)b * Tn * ld + h * 64 + cg * 8;
+  const T* vb = v + (long long)b * Tn * ld + h * 64 + cg * 8;
+  float s[NIT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int t = it * 8 + sub;
+    float d = 0.f;
+    if (t < klen) {
+      const v8 kv = *reinterpret_cast<const v8*>(kb + (long long)t * ld);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += qf[j] * T16<T>::to_f32(kv[j]);
+    }
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    d += __shfl_xor(d, 4);
+    s[it] = t < klen ? d : -INFINITY;
+    mx = fmaxf(mx, s[it]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f, acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int t = it * 8 + sub;
+    if (t < klen) {
+      const float p = __expf(s[it] - mx);
+      sum += p;
+      const v8 vv = *reinterpret_cast<const v8*>(vb + (long long)t * ld);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += p * T16<T>::to_f32(vv[j]);
+    }
+  }
+  // every key's p sits in 8 lanes (cg): the wave sum counts it 8 times
+  sum = wave_sum(sum) * 0.125f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 8);
+    acc[j] += __shfl_xor(acc[j], 16);
+    acc[j] += __shfl_xor(acc[j], 32);
+  }
+  if (sub == 0) {
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    v8 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      T a, c;
+      split16<T>(acc[j] * inv, a, c);
+      hh[j] = a;
+      ll[j] = c;
+    }
+    *reinterpret_cast<v8*>(oh + (long long)b * ldo + h * 64 + cg * 8) = hh;
+    if (ol) *reinterpret_cast<v8*>(ol + (long long)b * ldo + h * 64 + cg * 8) = ll;
+  }
+}
+
+template <typename T>
+static int launch_attn_cls(const void* q, long long ldq, const void* k, const void* v, long long ld, void* oh, void* ol, long long ldo,
+                           int B, int Tn, int H, float scale, const int* kv_len, hipStream_t st) {
+  const int nbh = B * H;
+  dim3 grid((unsigned)cdiv(nbh, 4)), block(256);
+  ProfScope prof("attention_cls", 4.0 * nbh * (double)Tn * 64, 2.0 * 2 * (double)B * Tn * H * 64, st);
+#define MER_CLS_CASE(N) hipLaunchKernelGGL((attn_cls_kernel<T, N>), grid, block, 0, st, (const T*)q, ldq, (const T*)k, (const T*)v, ld, (T*)oh, (T*)ol, ldo, Tn, H, nbh, scale, kv_len)
+  if (Tn <= 64) MER_CLS_CASE(8);
+  else if (Tn <= 208) MER_CLS_CASE(26);
+  else if (Tn <= 264) MER_CLS_CASE(33);
+  else if (Tn <= 584) MER_CLS_CASE(73);
+  else {
+    set_error("mer_attention_cls: T=%d > 584 unsupported", Tn);
+    return MER_EUNSUPPORTED;
+  }
+#undef MER_CLS_CASE
+  return check_launch("attention_cls");
 }
 
 }  // namespace mer
@@ -556,5 +634,20 @@ extern "C" int mer_attention_bias(const void* q, const void* k, const void* v, l
   if (dtype == MER_DT_F16) return launch_attn<f16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 0, st, bias, ldb, gate);
   if (dtype == MER_DT_BF16) return launch_attn<bf16>(q, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, 0, st, bias, ldb, gate);
   set_error("mer_attention_bias: bad dtype %d", dtype);
+  return MER_EINVAL;
+}
+
+extern "C" int mer_attention_cls(const void* q, long long ldq, const void* k, const void* v, long long ld, void* out_hi, void* out_lo,
+                                 long long ldo, int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(q && k && v && out_hi, MER_EINVAL, "mer_attention_cls: null pointer");
+  MER_REQUIRE(B > 0 && T > 0 && H > 0, MER_ESHAPE, "mer_attention_cls: bad shape B=%d T=%d H=%d", B, T, H);
+  MER_REQUIRE(ld % 8 == 0 && ldq % 8 == 0 && ldo % 8 == 0, MER_ESHAPE, "mer_attention_cls: ld / ldq / ldo must be multiples of 8");
+  MER_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0, MER_EINVAL,
+              "mer_attention_cls: operands must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MER_DT_F16) return launch_attn_cls<f16>(q, ldq, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, st);
+  if (dtype == MER_DT_BF16) return launch_attn_cls<bf16>(q, ldq, k, v, ld, out_hi, out_lo, ldo, B, T, H, scale, kv_len, st);
+  set_error("mer_attention_cls: bad dtype %d", dtype);
   return MER_EINVAL;
 }

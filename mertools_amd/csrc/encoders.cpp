@@ -45,34 +45,51 @@ struct HsMap {
   float* at(int l) const { return base + (long long)(ring ? (l % ring) : l) * stride; }
 };
 
-// mer_set_option("tf_ablk", 1): the FFN's intermediate plane travels fc1 -> fc2 in blocked form (whole-line LDS-DMA pieces for
-// the K = ffn GEMM, whose A traffic dominates: ceiling probe -15 % on CLIP's fc2).  Off by default until measured end to end.
-int g_tf_ablk = 0;
-
 // passes == 5: ONE f16 MFMA pass + the weight-rounding residual applied through the batch's MEAN activation:
 //   c[n] = bias[n] + mean_rows(A)[k] * (W - f16(W))[n, k]     (mer_bias_corr: sampled column means + a GEMV on the `lo` plane)
 //   C = epi(A * f16(W)^T + c)
 // `cw` carries the scratch of the two helper kernels; without it (or without a `lo` plane) 5 degrades to 4 / 2.
-struct CorrWs {
-  void* scratch;         // mer_bias_corr_scratch_bytes(Kmax); NULL = not available
+struct CorrArena {       // one forward's mer_bias_corr scratch: a zeroed accumulator set ("site") per corrected GEMM
+  char* base;            // nsites * stride bytes, cleared by ONE memset at the start of the forward; NULL = not available
+  long long stride;      // mer_bias_corr_scratch_bytes(Kmax)
+  int nsites, next;
   float* cvec;           // [Nmax] fp32: the corrected bias of the GEMM that is about to run
+};
+struct CorrWs {
+  CorrArena* arena;
   int seg_rows;          // ragged batches: rows per sequence ...
   const int* valid;      // ... and device int32 [nseq] valid rows of each (NULL: every row counts)
 };
+static void corr_plan(Arena& ar, CorrArena& ca, bool on, int kmax, long long nmax, int nsites) {
+  ca.stride = mer_bias_corr_scratch_bytes(kmax);
+  ca.nsites = nsites;
+  ca.next = 0;
+  ca.base = on ? (char*)ar.take(ca.stride * nsites) : nullptr;
+  ca.cvec = on ? (float*)ar.take(nmax * 4) : nullptr;
+}
+static int corr_begin(hipStream_t st, CorrArena& ca) {   // dry-run arenas have base == NULL
+  ca.next = 0;
+  if (!ca.base) return MER_OK;
+  MER_REQUIRE(hipMemsetAsync(ca.base, 0, (size_t)(ca.stride * ca.nsites), st) == hipSuccess, MER_ELAUNCH, "bias-correction scratch: memset failed");
+  return MER_OK;
+}
 
 // mer_gemm16 with the passes == 5 preamble; `g` is complete except for the pass code handling
 static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
   if (g.passes == 5) {
-    const bool ok = cw && cw->scratch && g.w_lo && !g.a_blocked && g.N % 8 == 0 && g.K % 8 == 0 && g.nbatch <= 1;
+    CorrArena* ca = cw ? cw->arena : nullptr;
+    const bool ok = ca && ca->base && ca->next < ca->nsites && mer_bias_corr_scratch_bytes(g.K) <= ca->stride && g.w_lo &&
+                    g.N % 8 == 0 && g.K % 8 == 0 && g.nbatch <= 1;
     if (!ok) {
       g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
     } else {
       int rc = mer_bias_corr(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->valid ? cw->seg_rows : 0, cw->valid,
-                             g.w_lo, g.ldw, g.bias, g.N, cw->scratch, cw->cvec, (mer_stream_t)st);
+                             g.w_lo, g.ldw, g.bias, g.N, ca->base + ca->stride * ca->next, ca->cvec, (mer_stream_t)st);
+      ++ca->next;
       if (rc != MER_OK) return rc;
       g.passes = 1;
       g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
-      g.bias = cw->cvec;
+      g.bias = ca->cvec;
     }
   }
   return mer_gemm16(&g, (mer_stream_t)st);
@@ -80,7 +97,7 @@ static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
 
 static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 a, long long lda, const mer_w16& w,
                 const float* bias, int act, const float* residual, long long ldr, float* c32, long long ldc32, P16 c16,
-                long long ldc16, int c16_blocked = 0, int a_blocked = 0, const CorrWs* cw = nullptr) {
+                long long ldc16, const CorrWs* cw = nullptr) {
   mer_gemm16_args g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
@@ -90,7 +107,6 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
-  g.c16_blocked = c16_blocked; g.a_blocked = a_blocked;
   return run_gemm(st, g, cw);
 }
 
@@ -107,11 +123,29 @@ struct TfBufs {
   float* ffn32;    // SwiGLU: fp32 [M, 2F] output of weights_in awaiting the gate
   float* gate;     // WavLM: [B, H, T] gate of the current layer
   float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
-  void* corr;      // passes == 5: scratch of mer_bias_corr for K <= max(D, F)
-  float* cvec;     // passes == 5: [max(3D, 2F)] corrected bias of the GEMM about to run
+  CorrArena corr;  // passes == 5: mer_bias_corr scratch (the encoder's other GEMMs share it)
 };
 
-static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
+// ViT whose caller only reads the [CLS] row of the last block (CLIP get_image_features): that block computes K and V for every
+// token but Q, attention, output projection and the FFN for the CLS rows alone (nseq rows instead of nseq * T).
+struct ClsBufs {
+  P16 q16, ctx16, h16, f16;
+  float* t32;      // CLS residual stream after the attention half
+  float* y32;      // ... after the FFN: what post_layernorm reads
+};
+static void cls_plan(Arena& ar, const mer_tf_config& c, long long nseq, ClsBufs& b) {
+  const bool lo = c.passes == 3;
+  const long long D = c.hidden, F = c.ffn;
+  b.q16 = take16(ar, nseq * D, false);
+  b.ctx16 = take16(ar, nseq * D, lo);
+  b.h16 = take16(ar, nseq * D, lo);
+  b.f16 = take16(ar, nseq * F, lo);
+  b.t32 = (float*)ar.take(nseq * D * 4);
+  b.y32 = (float*)ar.take(nseq * D * 4);
+}
+
+// extra_sites / extra_k / extra_n: corrected GEMMs outside the blocks that share the arena (conv stack, patch embedding)
+static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b, int extra_sites = 0, int extra_k = 0, long long extra_n = 0) {
   const bool lo = c.passes == 3;
   const long long D = c.hidden, F = c.ffn;
   b.t32 = (float*)ar.take(M * D * 4);
@@ -120,37 +154,58 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b) {
   b.qkv16 = take16(ar, M * 3 * D, false);
   b.ctx16 = take16(ar, M * D, lo);
   b.h1_16 = take16(ar, M * D, lo);
-  b.f16 = take16(ar, cdiv(M, 256) * 256 * F, lo);   // rows padded to the 256-row blocks of the blocked fc1 -> fc2 plane
+  b.f16 = take16(ar, M * F, lo);
   b.ffn32 = c.ffn_swiglu ? (float*)ar.take(M * 2 * F * 4) : nullptr;
   b.gate = c.gated_rel_pos ? (float*)ar.take(M * c.heads * 4) : nullptr;
   b.gin32 = (c.gated_rel_pos && c.pre_ln) ? (float*)ar.take(M * D * 4) : nullptr;
-  const long long wide = 2 * F > 3 * D ? 2 * F : 3 * D;
-  b.corr = c.passes == 5 ? ar.take(mer_bias_corr_scratch_bytes((int)(F > D ? F : D))) : nullptr;
-  b.cvec = c.passes == 5 ? (float*)ar.take(wide * 4) : nullptr;
+  long long wide = 2 * F > 3 * D ? 2 * F : 3 * D;
+  wide = extra_n > wide ? extra_n : wide;
+  int kmax = (int)(F > D ? F : D);
+  kmax = extra_k > kmax ? extra_k : kmax;
+  corr_plan(ar, b.corr, c.passes == 5 || extra_sites > 0, kmax, wide, 4 * c.layers + 4 + extra_sites);
 }
 
 // Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
 // input; pre-LN: hs.at(0) holds the raw residual stream.  Writes hs.at(l+1) for every layer.
 static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer* L, int Bseq, int T, const HsMap& hs,
-                      TfBufs& b, const int* kv_len, const float* pos_bias = nullptr, long long ldb = 0) {
+                      TfBufs& b, const int* kv_len, const float* pos_bias = nullptr, long long ldb = 0, const ClsBufs* cls = nullptr) {
   const int M = Bseq * T, D = c.hidden, F = c.ffn, H = c.heads;
   const int dt = c.dtype, ps = c.passes;
   const bool sel = ps == 4 || ps == 5;                      // presets with a selective weight-residual correction (mx_skip)
   const int ps1 = (sel && (c.mx_skip & 2)) ? 1 : ps;       // fc1 without the correction
   const int ps2 = (sel && (c.mx_skip & 4)) ? 1 : ps;       // fc2 without the correction
   // passes == 5: the correction goes through the batch's mean token (run_gemm() above); a sequence = T rows, kv_len = its valid rows
-  const CorrWs cwv = {b.corr, b.cvec, T, kv_len};
-  const CorrWs* mc = (ps == 5 && b.corr) ? &cwv : nullptr;
+  const CorrWs cwv = {&b.corr, T, kv_len};
+  const CorrWs* mc = (ps == 5 && b.corr.base) ? &cwv : nullptr;
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
-  // blocked fc1 -> fc2 plane: only where fc2 runs the 256x256 one-/two-pass kernel (same test as mer_gemm16's tile choice)
-  const int ablk = (g_tf_ablk && !c.ffn_swiglu && ps != 3 && (ps2 == 1 || ps2 == 2) && M >= 1024 && D >= 192 && F % 32 == 0) ? 1 : 0;   // (not with passes 5)
   for (int l = 0; l < c.layers; ++l) {
     const mer_tf_layer& w = L[l];
     float* x = hs.at(l);
     float* y = hs.at(l + 1);
     if (c.pre_ln)
       MER_TRY(mer_layernorm(x, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.gin32, D, b.cur16.hi, b.cur16.lo, D, dt, st));
+    if (cls && l == c.layers - 1) {
+      // last block, CLS rows only (the caller checked: pre-LN, plain FFN, no score bias).  K | V for every token ...
+      const long long woff = (long long)D * D * 2;   // bytes into the 16-bit planes: row D of the fused [3D, D] weight
+      const bool tiles = D % 256 == 0;               // the pre-blocked / MX planes are stored per 256-row tile
+      const mer_w16 wkv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
+                           (w.wqkv.mx && tiles) ? (const char*)w.wqkv.mx + (long long)(D / 256) * (D / 32) * 5120 : nullptr,
+                           (w.wqkv.hi_blk && tiles) ? (const char*)w.wqkv.hi_blk + woff : nullptr,
+                           (w.wqkv.lo_blk && tiles) ? (const char*)w.wqkv.lo_blk + woff : nullptr};
+      const P16 ckv = {(char*)b.qkv16.hi + (long long)D * 2, nullptr};
+      MER_TRY(gemm(st, dt, ps, M, 2 * D, D, b.cur16, D, wkv, w.bqkv + D, MER_ACT_NONE, nullptr, 0, nullptr, 0, ckv, 3 * D, mc));
+      // ... Q for the CLS rows (row n of the A operand = token 0 of sequence n: lda = T * D)
+      const mer_w16 wq = {w.wqkv.hi, w.wqkv.lo, nullptr, nullptr, nullptr};
+      MER_TRY(gemm(st, dt, ps, Bseq, D, D, b.cur16, (long long)T * D, wq, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, cls->q16, D, mc));
+      MER_TRY(mer_attention_cls(cls->q16.hi, D, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
+                                cls->ctx16.hi, cls->ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, (mer_stream_t)st));
+      MER_TRY(gemm(st, dt, ps, Bseq, D, D, cls->ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, (long long)T * D, cls->t32, D, none, 0, mc));
+      MER_TRY(mer_layernorm(cls->t32, D, w.ln2_g, w.ln2_b, c.ln_eps, Bseq, D, MER_ACT_NONE, nullptr, 0, cls->h16.hi, cls->h16.lo, D, dt, st));
+      MER_TRY(gemm(st, dt, ps1, Bseq, F, D, cls->h16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, cls->f16, F, mc));
+      MER_TRY(gemm(st, dt, ps2, Bseq, D, F, cls->f16, F, w.w2, w.b2, MER_ACT_NONE, cls->t32, D, cls->y32, D, none, 0, mc));
+      continue;
+    }
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
     if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx != nullptr) {
@@ -165,9 +220,9 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                           w.wqkv.hi_blk ? (const char*)w.wqkv.hi_blk + woff : nullptr,
                           w.wqkv.lo_blk ? (const char*)w.wqkv.lo_blk + woff : nullptr};
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
-      MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, 0, 0, mc));
+      MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, mc));
     } else
-    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D, 0, 0, mc));
+    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D, mc));
     const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
     if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
       const float* gate = nullptr;
@@ -180,19 +235,19 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     } else
     MER_TRY(mer_attention(b.qkv16.hi, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
                           b.ctx16.hi, b.ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, st));
-    MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0, 0, 0, mc));
+    MER_TRY(gemm(st, dt, ps, M, D, D, b.ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, D, b.t32, D, none, 0, mc));
     if (c.pre_ln) {
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, nullptr, 0, b.h1_16.hi, b.h1_16.lo, D, dt, st));
       if (c.ffn_swiglu) {  // weights_in -> fp32 [M, 2F]; silu(first half) * second half -> 16-bit planes [M, F]
-        MER_TRY(gemm(st, dt, ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0, 0, 0, mc));
+        MER_TRY(gemm(st, dt, ps1, M, 2 * F, D, b.h1_16, D, w.w1, w.b1, MER_ACT_NONE, nullptr, 0, b.ffn32, 2 * F, none, 0, mc));
         MER_TRY(mer_swiglu(b.ffn32, 2 * F, M, F, b.f16.hi, b.f16.lo, dt, (mer_stream_t)st));
       } else
-      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0, mc));
-      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0, 0, ablk, mc));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, mc));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.t32, D, y, D, none, 0, mc));
     } else {
       MER_TRY(mer_layernorm(b.t32, D, w.ln1_g, w.ln1_b, c.ln_eps, M, D, MER_ACT_NONE, b.h1_32, D, b.h1_16.hi, b.h1_16.lo, D, dt, st));
-      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, ablk, 0, mc));
-      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0, 0, ablk, mc));
+      MER_TRY(gemm(st, dt, ps1, M, F, D, b.h1_16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, b.f16, F, mc));
+      MER_TRY(gemm(st, dt, ps2, M, D, F, b.f16, F, w.w2, w.b2, MER_ACT_NONE, b.h1_32, D, b.t32, D, none, 0, mc));
       MER_TRY(mer_layernorm(b.t32, D, w.ln2_g, w.ln2_b, c.ln_eps, M, D, MER_ACT_NONE, y, D, b.cur16.hi, b.cur16.lo, D, dt, st));
     }
   }
@@ -287,8 +342,6 @@ struct HubertPlan {
   float* posbuf;       // data2vec-audio: output of a positional conv layer (input of the next)
   float* ring;
   int* vlen;           // ragged batches: t0_len[B] | tn_len[B] (device int32)
-  void* ccorr;         // conv_passes == 5: mer_bias_corr scratch for the conv GEMMs / the projection
-  float* ccvec;        //                   and their corrected bias [max(C, D)]
   TfBufs tf;
   int T[MER_MAX_CONV];
 };
@@ -313,9 +366,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
   int kmax = (int)C;
   for (int i = 1; i < c.n_conv; ++i) kmax = c.conv_kernel[i] * (int)C > kmax ? c.conv_kernel[i] * (int)C : kmax;
-  p.ccorr = c.conv_passes == 5 ? ar.take(mer_bias_corr_scratch_bytes(kmax)) : nullptr;
-  p.ccvec = c.conv_passes == 5 ? (float*)ar.take((C > D ? C : D) * 4) : nullptr;
-  tf_plan(ar, c.tf, M, p.tf);
+  tf_plan(ar, c.tf, M, p.tf, c.conv_passes == 5 ? c.n_conv + 1 : 0, kmax, C > D ? C : D);
   return ar.off;
 }
 
@@ -364,8 +415,9 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   const P16 none = {nullptr, nullptr};
   // conv_passes == 5: batch-mean correction of the conv GEMMs (padded rows of a ragged batch are not excluded here: the conv
   // stack's frames of the zero tail are a small share of the sampled windows)
-  const CorrWs ccw = {p.ccorr, p.ccvec, 0, nullptr};
-  const CorrWs* cw = p.ccorr ? &ccw : nullptr;
+  MER_TRY(corr_begin(st, p.tf.corr));
+  const CorrWs ccw = {&p.tf.corr, 0, nullptr};
+  const CorrWs* cw = (cps == 5 && p.tf.corr.base) ? &ccw : nullptr;
 
   // ragged batch: per-row valid frame counts after conv 0 (GroupNorm statistics) and after the stack (positional conv zeros,
   // attention key mask), derived on the device from the rows' sample counts
@@ -421,7 +473,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   // feature projection: LayerNorm(C) -> Linear(C -> D)   (HF:hubert/modeling_hubert.py:216-231)
   if (c.feat_proj_layer_norm)
     MER_TRY(mer_layernorm(p.conv_last32, C, w.fp_ln_g, w.fp_ln_b, c.tf.ln_eps, M, C, MER_ACT_NONE, nullptr, 0, p.fp16.hi, p.fp16.lo, C, dt, st));
-  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, 0, 0, cw));
+  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, cw));
 
   // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
   HsMap hs;
@@ -511,7 +563,11 @@ struct VitPlan {
   P16 cls16;
   float* feats;
   TfBufs tf;
+  ClsBufs cls;
 };
+
+// CLIP features come from the CLS row alone: the last block runs for those rows only unless the caller wants every token
+static bool vit_cls_only(const mer_vit_config& c) { return c.variant == 0 && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1; }
 
 static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   const mer_vit_config& c = h->cfg;
@@ -523,7 +579,8 @@ static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   p.x = (float*)ar.take(N * (P + 1) * D * 4);
   p.cls16 = take16(ar, (long long)N * D, lo);
   p.feats = (float*)ar.take((long long)N * c.proj_dim * 4);
-  tf_plan(ar, c.tf, N * (P + 1), p.tf);
+  tf_plan(ar, c.tf, N * (P + 1), p.tf, c.tf.passes == 5 ? 4 : 0, (int)cols);
+  if (vit_cls_only(c)) cls_plan(ar, c.tf, N, p.cls);
   return ar.off;
 }
 
@@ -557,15 +614,18 @@ extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int
   const P16 none = {nullptr, nullptr};
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
-  const CorrWs pcw = {p.tf.corr, p.tf.cvec, 0, nullptr};   // (scratch sized for K <= max(D, F): the patch rows qualify when cols <= that)
+  MER_TRY(corr_begin(st, p.tf.corr));
+  const CorrWs pcw = {&p.tf.corr, 0, nullptr};
   MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, c.variant == 1 ? w.patch_b : nullptr, MER_ACT_NONE, nullptr, 0,
-               p.patch32, D, none, 0, 0, 0, (p.tf.corr && cols <= (c.tf.ffn > D ? c.tf.ffn : D)) ? &pcw : nullptr));
+               p.patch32, D, none, 0, &pcw));
   // [CLS] + position embeddings (+ pre_layrnorm for CLIP; DINOv2 has no embedding LayerNorm: gamma == NULL stores the plain sum)
   MER_TRY(mer_vit_assemble(p.patch32, w.cls, w.pos, c.variant == 0 ? w.pre_ln_g : nullptr, c.variant == 0 ? w.pre_ln_b : nullptr,
                            c.tf.ln_eps, N, P, D, p.x, nullptr, nullptr, dt, st));
   HsMap hs;
   hs.base = p.x; hs.stride = 0; hs.ring = 1;  // pre-LN blocks update the residual stream in place
-  MER_TRY(tf_forward(st, c.tf, h->layers.data(), N, P + 1, hs, p.tf, nullptr));
+  bool cls_only = vit_cls_only(c) && !tokens_out;
+  for (int l = 0; l < c.tf.layers; ++l) cls_only = cls_only && !h->layers[l].attn_bias;
+  MER_TRY(tf_forward(st, c.tf, h->layers.data(), N, P + 1, hs, p.tf, nullptr, nullptr, 0, cls_only ? &p.cls : nullptr));
   if (tokens_out)
     MER_REQUIRE(hipMemcpyAsync(tokens_out, p.x, (size_t)N * (P + 1) * D * 4, hipMemcpyDeviceToDevice, st) == hipSuccess, MER_ELAUNCH,
                 "mer_vit_forward: copy of the token states failed");
@@ -576,8 +636,8 @@ extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int
     return MER_OK;
   }
   // pooled = post_layernorm(x[:, 0]); features = visual_projection(pooled)   (HF:clip/modeling_clip.py:719-748)
-  MER_TRY(mer_layernorm(p.x, (long long)(P + 1) * D, w.post_ln_g, w.post_ln_b, c.tf.ln_eps, N, D, MER_ACT_NONE, nullptr, 0,
-                        p.cls16.hi, p.cls16.lo, D, dt, st));
+  MER_TRY(mer_layernorm(cls_only ? p.cls.y32 : p.x, cls_only ? (long long)D : (long long)(P + 1) * D, w.post_ln_g, w.post_ln_b, c.tf.ln_eps, N, D,
+                        MER_ACT_NONE, nullptr, 0, p.cls16.hi, p.cls16.lo, D, dt, st));
   float* feats = image_features ? image_features : p.feats;
   MER_TRY(gemm(st, dt, ps, N, c.proj_dim, D, p.cls16, D, w.proj_w, nullptr, MER_ACT_NONE, nullptr, 0, feats, c.proj_dim, none, 0));
   if (pooled) MER_TRY(mer_sum_pool(feats, nullptr, nullptr, nullptr, N, c.proj_dim, nullptr, seg_start, seg_len, nseg, pooled, st));
@@ -621,7 +681,7 @@ static long long vmae_plan(const mer_videomae* h, Arena& ar, int B, VmaePlan& p)
   const long long cols = (long long)c.channels * c.tubelet_size * c.patch_size * c.patch_size;
   p.patches = take16(ar, B * NP * cols, c.tf.passes == 3);
   p.x = (float*)ar.take(B * NP * D * 4);
-  tf_plan(ar, c.tf, B * NP, p.tf);
+  tf_plan(ar, c.tf, B * NP, p.tf, c.tf.passes == 5 ? 2 : 0, (int)cols);
   return ar.off;
 }
 extern "C" long long mer_videomae_workspace_bytes(const mer_videomae* h, int B) {
@@ -650,9 +710,9 @@ extern "C" int mer_videomae_forward(const mer_videomae* h, const float* pixels, 
   // tubelet embedding: Conv3d(stride == kernel, bias) == GEMM over tubelet rows; + fixed sin-cos positions
   MER_TRY(mer_video_patchify(pixels, B, c.num_frames, c.channels, c.image_size, c.image_size, c.patch_size, c.tubelet_size,
                              p.patches.hi, p.patches.lo, dt, st));
-  const CorrWs pcw = {p.tf.corr, p.tf.cvec, 0, nullptr};
-  MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0, 0, 0,
-               (p.tf.corr && cols <= (c.tf.ffn > D ? c.tf.ffn : D)) ? &pcw : nullptr));
+  MER_TRY(corr_begin(st, p.tf.corr));
+  const CorrWs pcw = {&p.tf.corr, 0, nullptr};
+  MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0, &pcw));
   MER_TRY(mer_add_pos(x, w.pos, (long long)B * NP, NP, D, st));
   HsMap hs;
   hs.base = x; hs.stride = 0; hs.ring = 1;
@@ -730,6 +790,7 @@ extern "C" int mer_bert_forward(const mer_bert* h, const int64_t* ids, const int
   HsMap hs;
   hs.stride = M * D;
   if (hidden_states) { hs.base = hidden_states; hs.ring = 0; } else { hs.base = p.ring; hs.ring = 5; }
+  MER_TRY(corr_begin(st, p.tf.corr));
   if (c.emb_dim > 0 && c.emb_dim != D) {   // factorised embeddings: E-wide tables + LayerNorm, then Linear(E -> D) = hidden_states[0]
     MER_TRY(mer_bert_embed(ids, token_type, B, T, c.emb_dim, w.word, w.pos, w.type, c.pos_mode, c.pad_id, w.emb_ln_g, w.emb_ln_b,
                            c.emb_ln_eps, nullptr, p.emb16.hi, p.emb16.lo, dt, st));

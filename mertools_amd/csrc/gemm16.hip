@@ -3,16 +3,12 @@
 #include "gemm16_impl.h"
 
 namespace mer {
-int g_gemm_skip = 0;
-int g_gemm_stamp = 0;
-int g_gemm_glds = 1;
-int g_gemm_pkepi = 1;     // mer_set_option("gemm_pkepi", 0): 16-bit-only outputs take the generic fp32-staged epilogue (A/B testing)
-int g_gemm_store = 2;     // mer_set_option("gemm_store", m): store flavour of the 16-bit-only epilogue (0 plain, 1 sc1, 2 nt, 3 sc0 sc1)
-int g_gemm_store32 = 0;   // mer_set_option("gemm_store32", m): the same for the fp32-only epilogue
-int g_gemm_res_nt = 0;    // mer_set_option("gemm_res_nt", 1): the fp32-only epilogue streams its residual rows with non-temporal loads
-int g_gemm_epi32 = 1;     // mer_set_option("gemm_epi32", 0): fp32-only outputs take the generic 8-columns-per-lane epilogue (A/B testing)
-int g_gemm_wblk = 1;      // mer_set_option("gemm_wblk", 0): ignore pre-blocked weight planes (A/B testing)
-unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel  // mer_set_option("gemm_glds", 0) forces the register-staged loader (A/B testing)
+// debug / tuning switches (mer_set_option; process-global and NOT thread-safe: set them before any forward is in flight)
+int g_gemm_skip = 0;          // "gemm_dbg_skip": 1 = skip the epilogue's global stores, 2 = skip the whole epilogue (timing decomposition)
+int g_gemm_stamp = 0;         // "gemm_stamp": the instrumented (s_memtime) build of the 8-wave kernels, with mer_set_debug_buffer
+int g_gemm_glds = 1;          // "gemm_glds": 0 = register-staged loader instead of LDS-DMA (A/B and the K % 32 != 0 fallback's twin)
+int g_gemm_generic_epi = 0;   // "gemm_generic_epi": 1 = every launch takes the generic epilogue (the specialised ones must equal it)
+unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel
 
 template <typename T>
 static int dispatch(const Gemm16Params& p, int nbatch, int passes, int tile, hipStream_t st) {
@@ -27,25 +23,11 @@ extern "C" int mer_set_debug_buffer(void* device_u64_buffer) {
   return MER_OK;
 }
 
-namespace mer { extern int g_attn_force_nkt; extern int g_attn_waves; extern int g_attn_nt; extern int g_attn_stream_qs; extern int g_attn_stream_pf; extern int g_ln_nt; extern int g_ln_rows; extern int g_tf_ablk; }
 extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_wblk") == 0) { mer::g_gemm_wblk = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_pkepi") == 0) { mer::g_gemm_pkepi = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_store") == 0) { mer::g_gemm_store = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_store32") == 0) { mer::g_gemm_store32 = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_epi32") == 0) { mer::g_gemm_epi32 = value; return MER_OK; }
-  if (name && strcmp(name, "tf_ablk") == 0) { mer::g_tf_ablk = value; return MER_OK; }
-  if (name && strcmp(name, "attn_force_nkt") == 0) { mer::g_attn_force_nkt = value; return MER_OK; }
-  if (name && strcmp(name, "attn_waves") == 0) { mer::g_attn_waves = value; return MER_OK; }
-  if (name && strcmp(name, "attn_nt") == 0) { mer::g_attn_nt = value; return MER_OK; }
-  if (name && strcmp(name, "attn_stream_qs") == 0) { mer::g_attn_stream_qs = value; return MER_OK; }
-  if (name && strcmp(name, "attn_stream_pf") == 0) { mer::g_attn_stream_pf = value; return MER_OK; }
-  if (name && strcmp(name, "ln_nt") == 0) { mer::g_ln_nt = value; return MER_OK; }
-  if (name && strcmp(name, "ln_rows") == 0) { mer::g_ln_rows = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_res_nt") == 0) { mer::g_gemm_res_nt = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_generic_epi") == 0) { mer::g_gemm_generic_epi = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
 }
@@ -174,7 +156,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   Gemm16Params p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
-  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0; p.a_blk = 0; p.c16_blk = 0;
+  p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0;
   p.bias = a->bias; p.act = a->act;
   p.residual = a->residual; p.ldr = a->ldr;
   p.c32 = a->c32; p.ldc32 = a->ldc32;
@@ -192,14 +174,11 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   if (a->c16_hi) vec = vec && (a->ldc16 % 8 == 0) && (((uintptr_t)a->c16_hi & 15) == 0);
   if (a->c16_lo) vec = vec && (((uintptr_t)a->c16_lo & 15) == 0);
   p.vec_ok = vec ? 1 : 0;
-  p.st_mode = g_gemm_store;
-  p.st_mode32 = g_gemm_store32;
-  p.res_nt = g_gemm_res_nt;
   // fp32-only epilogue: whole-line residual loads / stores (4 columns per lane); N % 8 == 0 and 16-byte alignment are `vec`
-  p.epi32 = (g_gemm_epi32 && vec && a->c32 && !a->c16_hi && !a->c16_lo && a->headmajor_T == 0 && (a->act == MER_ACT_NONE || a->act == MER_ACT_GELU) &&
+  p.epi32 = (!g_gemm_generic_epi && vec && a->c32 && !a->c16_hi && !a->c16_lo && a->headmajor_T == 0 && (a->act == MER_ACT_NONE || a->act == MER_ACT_GELU) &&
              (!a->bias || ((((uintptr_t)a->bias) & 15) == 0 && a->bias_si % 4 == 0))) ? 1 : 0;   // its static bias is one 16-byte load per lane
   // packed-pair epilogue: 16-bit output only (no fp32 copy, residual or lo plane), row-major, every column group of 8 in range
-  p.pk_epi = (g_gemm_pkepi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 && !a->c16_blocked &&
+  p.pk_epi = (!g_gemm_generic_epi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 &&
               a->act != MER_ACT_RELU) ? 1 : 0;
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
@@ -223,22 +202,11 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
     }
   }
   // pre-blocked weight planes feed the 256-wide LDS-DMA kernels only (their block is one 256 x 32 stage plane)
-  if (a->w_hi_blk && g_gemm_wblk && tile == 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && (passes == 1 || passes == 4 || a->w_lo_blk)) {
+  if (a->w_hi_blk && tile == 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && (passes == 1 || passes == 4 || a->w_lo_blk)) {
     MER_REQUIRE((((uintptr_t)a->w_hi_blk | (uintptr_t)a->w_lo_blk) & 15) == 0, MER_EINVAL, "mer_gemm16: pre-blocked planes must be 16-byte aligned");
     p.w_hi = a->w_hi_blk;
     p.w_lo = a->w_lo_blk;
     p.w_blk = 1;
-  }
-  if (a->c16_blocked) {
-    MER_REQUIRE(a->c16_hi && !a->c16_lo && vec && a->N % 32 == 0 && a->headmajor_T == 0 && nbatch == 1, MER_ESHAPE,
-                "mer_gemm16: a blocked 16-bit output needs c16_hi only, N %% 32 == 0, aligned outputs, no batching (N=%d)", a->N);
-    p.c16_blk = a->N / 32;
-  }
-  if (a->a_blocked) {
-    // the plane has no row-major form to fall back to: the caller must only ask for what the 256x256 LDS-DMA kernels cover
-    MER_REQUIRE(tile == 3 && passes != 4 && passes != 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && a->a_rows_per_batch == 0, MER_ESHAPE,
-                "mer_gemm16: a blocked A plane needs the 256x256 one-/two-pass kernel (tile %d, passes %d, K=%d)", tile, passes, a->K);
-    p.a_blk = 1;
   }
   if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, passes, tile, st);
   return dispatch<bf16>(p, nbatch, passes, tile, st);

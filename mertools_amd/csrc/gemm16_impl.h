@@ -39,8 +39,6 @@ struct Gemm16Params {
   const void* w_hi; const void* w_lo; long long ldw;
   const void* w_mx;   // MX kernel: packed fp4 + E8M0 correction plane (mer_mx_pack)
   int w_blk;          // w_hi / w_lo are pre-blocked planes (mer_w_block_pack): [n-tile of 256][32-deep k-slab][the 16 KB LDS image]
-  int a_blk;          // a_hi is a blocked activation plane written by a producer GEMM with c16_blk (same block geometry, rows = M)
-  int c16_blk;        // > 0: the 16-bit output is written blocked for a consumer with K = N: value = N / 32 (k-slabs per row tile)
   const float* bias; int act;
   const float* residual; long long ldr;
   float* c32; long long ldc32;
@@ -48,9 +46,6 @@ struct Gemm16Params {
   int nb_inner; long long a_so, a_si, w_si, bias_si, c_so, c_si;
   int tiles_m, tiles_n;
   int vec_ok;  // N % 8 == 0 and all output/residual strides+offsets aligned for 16-byte accesses
-  int st_mode;    // store flavour of the 16-bit-only (packed-pair) epilogue: 0 plain, 1 sc1, 2 nt (default: streaming stores leave L2 / MALL to the operands), 3 sc0 sc1
-  int st_mode32;  // the same for the fp32-only epilogue
-  int res_nt;     // fp32-only epilogue: residual rows loaded non-temporally
   int epi32;      // fp32-only outputs (+ residual): 4 columns per lane, so that one store instruction covers whole 256-byte row runs
   int pk_epi;     // 16-bit-only outputs: activation on the accumulators, row pairs packed before the LDS transposition (half the LDS traffic)
   int dbg_skip;   // tuning experiments: 1 = skip the epilogue global stores, 2 = skip the whole epilogue
@@ -71,12 +66,11 @@ __device__ __forceinline__ int swz_of(int row) {
   return C == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3);
 }
 
-// 16-byte global store with a cache-policy flavour (see Gemm16Params::st_mode)
-__device__ __forceinline__ void gstore16(void* ptr, u32x4 v, int mode) {
-  if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(v) : "memory");
-  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(ptr), "v"(v) : "memory");
-  else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ptr), "v"(v) : "memory");
-  else *reinterpret_cast<u32x4*>(ptr) = v;
+// 16-byte streaming (non-temporal) global store: 16-bit GEMM outputs are not re-read by this launch, and allocating their lines in
+// L2 / the Infinity Cache evicts the A / W lines the other CUs' K loops are re-reading (+19-20 % on the QKV / fc1 launches, DESIGN.md §3;
+// sc1 / sc0 sc1 flavours measured slower).  fp32 outputs keep plain stores: their lines are re-read by the LayerNorm that follows.
+__device__ __forceinline__ void gstore16_nt(void* ptr, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(ptr), "v"(v) : "memory");
 }
 
 template <int N>
@@ -123,10 +117,7 @@ __device__ __forceinline__ f32x4 mx_mfma(i32x8 a, i32x8 b, f32x4 c, int sb) {
 // STAMP (tuning builds of the 8-wave kernels, mer_set_option("gemm_stamp", 1)): waves 0 and NW/2 accumulate, per K-loop
 // iteration, the cycles spent in LOAD work / waiting at the mid barrier / MATH work / waiting at the end barrier, split
 // into the MX-burst slabs and the others, into p.dbg[4 * nblk + (blk * 2 + group) * 8 ..].
-// PERSIST (8-wave non-MX kernels; NOT instantiated since round 2 — it gained 1-3 % in round 1 and its register set no longer fits
-// beside the specialised epilogues): one workgroup per CU walks tiles L = blockIdx.x + i*gridDim.x; the first PF slabs of the next tile
-// are DMA'd into stages 0..PF-1 while the epilogue of the current tile runs out of a staging area placed behind them.
-template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false, bool STAMP = false, bool PERSIST = false>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, bool GLDS, int NS, bool MX = false, bool STAMP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
   constexpr int NT = WM * WN * 64;
@@ -147,11 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   constexpr int EROWS = SN > 64 ? 16 : (SM > 64 ? 32 : SM);   // rows of the wave tile staged per epilogue chunk
   constexpr int CSTAGE = WM * WN * EROWS * CLD * 4;
   constexpr int RING = NS * STAGE + (MX ? MX_LDS : 0);
-  constexpr int PF_FIT = (163840 - CSTAGE) / STAGE;                           // stages that fit below the C staging area
-  constexpr int PF = PERSIST ? ((NS - 1) < PF_FIT ? (NS - 1) : PF_FIT) : 0;   // slabs of the next tile prefetched during the epilogue
-  constexpr int CT_OFF = PF * STAGE;                                           // byte offset of the C staging area
-  static_assert(!PERSIST || (PF >= 1 && !MX && GLDS && STAGGER), "persistent tiles: 8-wave LDS-DMA kernels only");
-  constexpr int SMEM = (RING > CT_OFF + CSTAGE) ? RING : CT_OFF + CSTAGE;
+  constexpr int SMEM = RING > CSTAGE ? RING : CSTAGE;   // the C staging area of the epilogue aliases the (dead) ring
   static_assert(NS >= 2 && (GLDS || NS == 2), "register-staged loader is double-buffered only");
   static_assert(NT % C == 0 && (BM * C) % NT == 0 && (BN * C) % NT == 0, "bad tile/thread split");
 
@@ -180,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   };
   int tile_m, tile_n;
   tile_of(blockIdx.x, tile_m, tile_n);
-  int m0 = tile_m * BM, n0 = tile_n * BN;   // the tile being computed / written (PERSIST: advanced per tile)
+  const int m0 = tile_m * BM, n0 = tile_n * BN;   // the tile being computed / written
 
   // ---- batch offsets ----
   const int z = blockIdx.y;
@@ -205,9 +192,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       a_off[i] = (p.a_rpb > 0) ? (long long)(m / p.a_rpb) * p.a_bstride + (long long)(m % p.a_rpb) * p.lda
                                : (long long)m * p.lda;
       a_src[i] = a_off[i] + ((ld_ch ^ swz_of<C>(ld_row0 + i * ROWS_PER_IT)) << 3);
-      if constexpr (!MX) {   // blocked activation plane: same [tile][k-slab][LDS image] geometry as the pre-blocked weights
-        if (p.a_blk) a_src[i] = ((long long)(m0_ / BM) * (p.K / BK)) * (BM * BK) + (long long)(ld_row0 + i * ROWS_PER_IT) * BK + ld_ch * 8;
-      }
     }
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
@@ -276,7 +260,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     mx_o32 = (unsigned)((tid < 320 ? tid : 256 + (tid & 63)) * 16);
   }
   const long long w_kmul = p.w_blk ? BN : 1;   // element distance of consecutive k (row-major) or of consecutive k-slabs / BK (pre-blocked)
-  const long long a_kmul = (!MX && p.a_blk) ? BM : 1;
   const char* mx_base = MX ? (const char*)p.w_mx + ((long long)tile_n * ((p.K + BK - 1) / BK)) * MX_BLOCK : nullptr;
   auto glds_issue = [&](int k0, int stage) __attribute__((always_inline)) {
     char* base = smem + stage * STAGE;
@@ -298,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       for (int pl = 0; pl < AP; ++pl)
 #pragma unroll
         for (int i = 0; i < CA; ++i)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0 * a_kmul),
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(a_pl[pl] + a_src[i] + k0),
                                            (lds_void_t*)(base + pl * A_PLANE + (wave_row0 + i * ROWS_PER_IT) * RB), 16, 0, 0);
 #pragma unroll
       for (int pl = 0; pl < WP; ++pl)
@@ -370,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   // that 16-bit outputs leave as one 16-byte store per lane (the store tail is issue-bound: half the instructions,
   // half the time) and fp32 outputs / residuals as two.  The stage buffers are dead here (the K loop ended on a
   // barrier); each wave owns a private EROWS x CLD slice.
-  float* ct = reinterpret_cast<float*>(smem + CT_OFF) + wave * EROWS * CLD;
+  float* ct = reinterpret_cast<float*>(smem) + wave * EROWS * CLD;
   constexpr int CPL = 8;                       // columns per lane
   constexpr int LANES_PER_ROW = SN / CPL;
   constexpr int ROWS_IT = 64 / LANES_PER_ROW;
@@ -465,10 +448,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
               const int bb = row / p.hm_T, tt = row % p.hm_T;
               o16 = ((((long long)which * (p.M / p.hm_T) + bb) * p.hm_H + hh2) * p.hm_T + tt) * 64 + d0;
             }
-            if (p.c16_blk > 0) {  // blocked plane for the consumer GEMM: block (row / 256, col / 32), row image of 64 B, chunks XOR-swizzled
-              const int rr = row & 255, lc = (col & 31) >> 3;
-              o16 = ((((long long)(row >> 8) * p.c16_blk + (col >> 5)) * 256 + rr) << 5) + ((lc ^ swz_of<4>(rr)) << 3);
-            }
             *reinterpret_cast<v8*>(c16h + o16) = h;
             if (c16l) {  // lo plane only when a 3-pass consumer needs it (3 extra VALU per element otherwise wasted)
               v8 l;
@@ -551,8 +530,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         ev[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); od[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u);
         ev[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u); od[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
         if (c16h) {
-          gstore16(c16h + (long long)row * p.ldc16 + col, ev, p.st_mode);
-          if (row + 1 < p.M) gstore16(c16h + (long long)(row + 1) * p.ldc16 + col, od, p.st_mode);
+          gstore16_nt(c16h + (long long)row * p.ldc16 + col, ev);
+          if (row + 1 < p.M) gstore16_nt(c16h + (long long)(row + 1) * p.ldc16 + col, od);
         }
       }
     }
@@ -589,8 +568,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           const int row = row0 + it * RIT;
           rr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (row < p.M && ok4)
-            rr[it] = p.res_nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4))
-                              : *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4);
+            rr[it] = *reinterpret_cast<const f32x4*>(res + (long long)row * p.ldr + col4);
         }
       }
 #pragma unroll
@@ -603,7 +581,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + bb[j], ACT);
         if (res) v += rr[it];
-        if (c32) gstore16(c32 + (long long)row * p.ldc32 + col4, __builtin_bit_cast(u32x4, v), p.st_mode32);
+        if (c32) *reinterpret_cast<f32x4*>(c32 + (long long)row * p.ldc32 + col4) = v;
         }
       }
     }
@@ -755,56 +733,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
       cur = cur + 1 == NS ? 0 : cur + 1;
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
     };
-    int L = blockIdx.x;   // PERSIST: linear index of the tile being computed
-    for (;;) {
-      for (int kt = 0; kt < nk; ++kt) iter(kt);   // MX: K % 128 == 0 (checked by the launcher)
-      if (STAMP && p.dbg && lane == 0 && (wave == 0 || wave == WM * WN / 2)) {
-        unsigned long long* d = p.dbg + 4ll * gridDim.x * gridDim.y + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 8;
+    for (int kt = 0; kt < nk; ++kt) iter(kt);   // MX: K % 128 == 0 (checked by the launcher)
+    if (STAMP && p.dbg && lane == 0 && (wave == 0 || wave == WM * WN / 2)) {
+      unsigned long long* d = p.dbg + 4ll * gridDim.x * gridDim.y + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = acc_t[i];
-      }
-      if (!g1) __builtin_amdgcn_s_barrier();
-      __syncthreads();
-      if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
-      if constexpr (!PERSIST) {
-        break;
-      } else {
-        // Next tile of this workgroup: its first PF slabs go to stages 0..PF-1 now (every wave is past its last LDS read of
-        // the ring), the epilogue of the current tile stages through [CT_OFF, CT_OFF + CSTAGE) behind them, and the
-        // remaining prologue slabs follow once all waves have left the staging area.  The counted vmcnt waits stay valid:
-        // the epilogue's stores / residual loads sit between the DMAs in issue order, which only makes the waits stricter.
-        const int Ln = L + (int)gridDim.x;
-        const bool has_next = Ln < nblk;
-        int tmn = 0, tnn = 0;
-        if (has_next) {
-          tile_of(Ln, tmn, tnn);
-          setup_loads(tmn * BM, tnn * BN);
-#pragma unroll
-          for (int s = 0; s < PF; ++s)
-            if (s < nk) glds_issue(s * BK, s);
-        }
-        run_epilogue();
-        if (!has_next) return;
-        m0 = tmn * BM;
-        n0 = tnn * BN;
-        L = Ln;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // every wave has left the C staging area: stages PF.. may be refilled
-#pragma unroll
-        for (int s = PF; s < D; ++s)
-          if (s < nk) glds_issue(s * BK, s);
-        if (nk >= D) wait_vmcnt<LPS*(D - 1)>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (g1) __builtin_amdgcn_s_barrier();
-        cur = 0;
-        nxt = D;
-      }
+      for (int i = 0; i < 8; ++i) d[i] = acc_t[i];
     }
+    if (!g1) __builtin_amdgcn_s_barrier();
+    __syncthreads();
+    if (p.dbg && tid == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memtime();
   } else
   if (GLDS) {
     // NS-stage LDS ring, LDS-DMA prefetch distance D = NS-1 slabs, counted vmcnt: at the end of iteration
@@ -850,7 +787,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_glds, g_gemm_wblk, g_gemm_pkepi, g_gemm_store, g_gemm_store32, g_gemm_epi32, g_gemm_res_nt;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_glds, g_gemm_generic_epi;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>

@@ -7,9 +7,6 @@
 #include "common.h"
 
 namespace mer {
-int g_ln_nt = 0;   // mer_set_option("ln_nt", 1): LayerNorm streams its fp32 input with non-temporal loads
-int g_ln_rows = 1; // mer_set_option("ln_rows", 0): one row per wave for every M (A/B testing of the multi-row kernel)
-
 
 template <typename T, int NV>
 struct RowLN {
@@ -94,7 +91,7 @@ struct RowLN {
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long long ldx, const float* gamma,
                                                         const float* beta, float eps, int M, int D, int act,
-                                                        float* out32, long long ld32, T* ohi, T* olo, long long ld16, int nt) {
+                                                        float* out32, long long ld32, T* ohi, T* olo, long long ld16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63, nv4 = D >> 2;
@@ -103,9 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long lon
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int idx = lane + 64 * j;
-    // nt: the fp32 row is streamed (it is not read again before ~1 GB of other traffic has passed), so it should not push
-    // the 16-bit plane written here — the next GEMM's A operand — out of L2 / the Infinity Cache
-    if (idx < nv4) v[j] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + idx * 4)) : *reinterpret_cast<const f32x4*>(xr + idx * 4);
+    if (idx < nv4) v[j] = *reinterpret_cast<const f32x4*>(xr + idx * 4);
     else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   RowLN<T, NV>::run(v, lane, nv4, D, gamma, beta, eps, act, out32 ? out32 + (long long)row * ld32 : nullptr,
@@ -118,7 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long lon
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, long long ldx, const float* gamma, const float* beta, float eps,
                                                              int M, int D, int act, float* out32, long long ld32, T* ohi, T* olo,
-                                                             long long ld16, int nt) {
+                                                             long long ld16) {
   const int lane = threadIdx.x & 63, nv4 = D >> 2;
   const int nwaves = gridDim.x * 4;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -136,7 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, lon
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int idx = lane + 64 * j;
-      if (idx < nv4) v[j] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + idx * 4)) : *reinterpret_cast<const f32x4*>(xr + idx * 4);
+      if (idx < nv4) v[j] = *reinterpret_cast<const f32x4*>(xr + idx * 4);
       else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -155,31 +150,36 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, lon
 // Batch-mean weight-residual correction (precision "mean", passes == 5).  The rounding error of a weight matrix
 // is the same perturbation a (W - f16(W))^T for every token, and nearly all of it acts through the MEAN activation of the batch
 // (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass), i.e. it is a
-// bias:  c[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k].  Two tiny kernels in front of the one-pass GEMM, both latency-bound, so
-// both are shaped for loads in flight rather than for bytes:
-//   colmean16_kernel   workgroup = a 64-column slice of the 16-bit A plane, 16 waves; one wave-load = 8 sampled rows x 128 B (whole
-//                      lines), every lane's loads independent (CM_ROWS / 128 of them in flight); rows addressed like mer_gemm16's A
-//                      operand, padded rows of ragged batches skipped; the slice's column means leave as fp32, no cross-workgroup step
-//   bias_corr_kernel   the mean vector into LDS, then one wave per 4 output columns takes the dot products with the residual
-//                      plane rows (a GEMV over [N, K])
-constexpr int CM_ROWS = 2048;   // sampled rows (every row when M is smaller)
+// bias:  c[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k].  Two tiny kernels in front of the one-pass GEMM.  Both are latency-bound
+// and a CU pulls only ~25-50 GB/s on its own, so both are spread over a few hundred workgroups:
+//   colsum16_kernel    workgroup = (64-column slice of the 16-bit A plane, one of CM_PARTS row groups); a wave-load = 8 sampled rows
+//                      x 128 B (whole lines), every lane's loads independent; rows addressed like mer_gemm16's A operand, padded
+//                      rows of ragged batches skipped.  The workgroup's column sums (fp32, fixed order) are added to the call's
+//                      accumulators as 64-bit FIXED-POINT integers: integer atomics commute, so the result does not depend on
+//                      the order the workgroups arrive in (a float atomic would make the bias — and with it every output of the
+//                      GEMM — vary from run to run in the last bit)
+//   bias_corr_kernel   the mean vector into LDS, then one wave per 2 output columns takes the dot products with the residual
+//                      plane rows (a GEMV over [N, K]); 8 columns per workgroup
+constexpr int CM_ROWS = 2048;    // sampled rows (every row when M is smaller)
+constexpr int CM_PARTS = 16;     // row groups (workgroups per column slice)
+constexpr float CM_FIX = 1048576.0f;   // 2^20: |x| <= 65504 (f16) -> |x * 2^20| < 2^36, 2048 rows < 2^47
 template <typename T>
-__global__ __launch_bounds__(1024) void colmean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int stride,
-                                                         int seg_rows, const int* valid_rows, float* mean) {
+__global__ __launch_bounds__(256) void colsum16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int stride,
+                                                       int seg_rows, const int* valid_rows, long long* acc, int* cnt) {
   typedef typename T16<T>::v8 v8;
-  __shared__ float red[16][64];
-  __shared__ int rcnt[16];
+  __shared__ float red[4][64];
+  __shared__ int rcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane >> 3, cg = lane & 7;
   const int col = blockIdx.x * 64 + cg * 8;
   const bool cin = col < K;
   const int R = (M + stride - 1) / stride;   // sampled rows
-  float acc[8];
+  float s[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
   int n = 0;
 #pragma unroll 4
-  for (int i = wave * 8 + sub; i < R; i += 128) {
+  for (int i = (blockIdx.y * 4 + wave) * 8 + sub; i < R; i += CM_PARTS * 32) {
     const int r = i * stride;
     if (valid_rows && (r % seg_rows) >= valid_rows[r / seg_rows]) continue;
     ++n;
@@ -187,45 +187,45 @@ __global__ __launch_bounds__(1024) void colmean16_kernel(const T* a, long long l
       const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
       const v8 x = *reinterpret_cast<const v8*>(a + off + col);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += T16<T>::to_f32(x[j]);
+      for (int j = 0; j < 8; ++j) s[j] += T16<T>::to_f32(x[j]);
     }
   }
-  // the 8 row groups of a wave (lanes cg, cg + 8, ...), then the 16 waves through LDS — fixed order: deterministic
+  // the 8 row groups of a wave (lanes cg, cg + 8, ...), then the 4 waves through LDS — fixed order
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    acc[j] += __shfl_xor(acc[j], 8);
-    acc[j] += __shfl_xor(acc[j], 16);
-    acc[j] += __shfl_xor(acc[j], 32);
+    s[j] += __shfl_xor(s[j], 8);
+    s[j] += __shfl_xor(s[j], 16);
+    s[j] += __shfl_xor(s[j], 32);
   }
   int nn = cg == 0 ? n : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o);
   if (sub == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[wave][cg * 8 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) red[wave][cg * 8 + j] = s[j];
   }
   if (lane == 0) rcnt[wave] = nn;
   __syncthreads();
   if (threadIdx.x < 64) {
-    float s = 0.f;
-    int total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      s += red[w][threadIdx.x];
-      total += rcnt[w];
-    }
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < K) mean[c] = total > 0 ? s / (float)total : 0.f;
+    // saturating: a bf16 plane may hold values beyond the fixed-point range (2^40 after the row sums: far outside any activation)
+    const float lim = 1.0995116e12f;
+    const float tc = fminf(fmaxf(t, -lim), lim);
+    if (c < K) atomicAdd(reinterpret_cast<unsigned long long*>(acc + c), (unsigned long long)(long long)__float2ll_rn(tc * CM_FIX));
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cnt, (rcnt[0] + rcnt[1]) + (rcnt[2] + rcnt[3]));
   }
 }
 
-constexpr int BC_COLS = 16;   // output columns per workgroup (4 per wave)
+constexpr int BC_COLS = 8;   // output columns per workgroup (2 per wave)
 template <typename T>
-__global__ __launch_bounds__(256) void bias_corr_kernel(const float* mean_g, int K, const T* w_lo, long long ldw,
+__global__ __launch_bounds__(256) void bias_corr_kernel(const long long* acc, const int* cnt, int K, const T* w_lo, long long ldw,
                                                         const float* bias, int N, float* out) {
   typedef typename T16<T>::v8 v8;
   extern __shared__ __attribute__((aligned(16))) float mean[];   // [K]
-  for (int k = threadIdx.x * 4; k < K; k += 1024) *reinterpret_cast<f32x4*>(mean + k) = *reinterpret_cast<const f32x4*>(mean_g + k);
+  const int total = *cnt;
+  const float inv = total > 0 ? 1.0f / ((float)total * CM_FIX) : 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) mean[k] = (float)acc[k] * inv;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s[BC_COLS / 4];
@@ -385,31 +385,31 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof("layernorm", 0.0, (double)M * D * (4 + (out32 ? 4 : 0) + (out16_hi ? 2 : 0) + (out16_lo ? 2 : 0)), st);
   // many rows of <= 1024 columns (the encoders' block LayerNorms): the multi-row kernel on exactly the grid that is resident at once
-  const int rows_grid = (g_ln_rows && nv <= 4) ? (dtype == MER_DT_F16 ? ln_rows_grid<f16>(nv) : ln_rows_grid<bf16>(nv)) : 0;
+  const int rows_grid = nv <= 4 ? (dtype == MER_DT_F16 ? ln_rows_grid<f16>(nv) : ln_rows_grid<bf16>(nv)) : 0;
   if (rows_grid > 0 && M >= 8 * rows_grid) {   // at least two rows per wave
     dim3 rgrid(rows_grid);
     if (dtype == MER_DT_F16) {
       MER_NV_SWITCH(nv, layernorm_rows_kernel<f16, NV><<<rgrid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
-                                            act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16, g_ln_nt));
+                                            act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16));
     } else {
       MER_NV_SWITCH(nv, layernorm_rows_kernel<bf16, NV><<<rgrid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
-                                            act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16, g_ln_nt));
+                                            act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16));
     }
     return check_launch("layernorm");
   }
   if (dtype == MER_DT_F16) {
     MER_NV_SWITCH(nv, layernorm_kernel<f16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
-                                          act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16, g_ln_nt));
+                                          act, out32, ld32, (f16*)out16_hi, (f16*)out16_lo, ld16));
   } else {
     MER_NV_SWITCH(nv, layernorm_kernel<bf16, NV><<<grid, block, 0, st>>>(x, ldx, gamma, beta, eps, M, D,
-                                          act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16, g_ln_nt));
+                                          act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16));
   }
   return check_launch("layernorm");
 }
 
 extern "C" long long mer_bias_corr_scratch_bytes(int K) {
   if (K <= 0) return 0;
-  return ((long long)K * 4 + 255) / 256 * 256;   // the mean vector [K] fp32
+  return ((long long)K * 8 + 16 + 255) / 256 * 256;   // column-sum accumulators [K] int64 | row count int32
 }
 
 extern "C" int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
@@ -423,18 +423,19 @@ extern "C" int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows
   MER_REQUIRE(!valid_rows || seg_rows > 0, MER_EINVAL, "mer_bias_corr: valid_rows needs seg_rows");
   MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_bias_corr: bad dtype");
   hipStream_t st = (hipStream_t)stream;
-  float* mean = (float*)scratch;
+  long long* acc = (long long*)scratch;
+  int* cnt = (int*)(acc + K);
   // about CM_ROWS evenly spaced rows (every row below that): the mean of >= 2048 tokens is far inside what the correction needs
   const int stride = M > CM_ROWS ? M / CM_ROWS : 1;
-  dim3 g1((unsigned)cdiv(K, 64)), g2((unsigned)cdiv(N, BC_COLS));
+  dim3 g1((unsigned)cdiv(K, 64), CM_PARTS), g2((unsigned)cdiv(N, BC_COLS));
   {
     ProfScope prof("bias_corr", 2.0 * N * K, (double)cdiv(M, stride) * K * 2 + (double)N * K * 2, st);
     if (dtype == MER_DT_F16) {
-      hipLaunchKernelGGL((colmean16_kernel<f16>), g1, dim3(1024), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, mean);
-      hipLaunchKernelGGL((bias_corr_kernel<f16>), g2, dim3(256), (size_t)K * 4, st, mean, K, (const f16*)w_lo, ldw, bias, N, out);
+      hipLaunchKernelGGL((colsum16_kernel<f16>), g1, dim3(256), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, acc, cnt);
+      hipLaunchKernelGGL((bias_corr_kernel<f16>), g2, dim3(256), (size_t)K * 4, st, acc, cnt, K, (const f16*)w_lo, ldw, bias, N, out);
     } else {
-      hipLaunchKernelGGL((colmean16_kernel<bf16>), g1, dim3(1024), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, mean);
-      hipLaunchKernelGGL((bias_corr_kernel<bf16>), g2, dim3(256), (size_t)K * 4, st, mean, K, (const bf16*)w_lo, ldw, bias, N, out);
+      hipLaunchKernelGGL((colsum16_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, acc, cnt);
+      hipLaunchKernelGGL((bias_corr_kernel<bf16>), g2, dim3(256), (size_t)K * 4, st, acc, cnt, K, (const bf16*)w_lo, ldw, bias, N, out);
     }
   }
   return check_launch("bias_corr");

@@ -57,7 +57,7 @@ def split16_host(x, dtype="f16", lo=True):
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
            out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
-           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, c16_blocked=False, a_blocked=False):
+           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -71,12 +71,11 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.w_hi, g.w_lo, g.ldw = _p(w_hi), _p(w_lo), w_hi.stride(0)
     g.w_mx = _p(w_mx)
     g.w_hi_blk, g.w_lo_blk = _p(w_hi_blk), _p(w_lo_blk)
-    g.c16_blocked, g.a_blocked = int(c16_blocked), int(a_blocked)
     g.bias, g.act = _p(bias), ACT[act]
     g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     dev = a_hi.device
     c32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out32 else None
-    c16h = torch.empty(((M + 255) // 256 * 256 if c16_blocked else M, N), dtype=torch16(dtype), device=dev) if out16 else None
+    c16h = torch.empty((M, N), dtype=torch16(dtype), device=dev) if out16 else None
     c16l = torch.empty((M, N), dtype=torch16(dtype), device=dev) if (out16 and out16_lo) else None
     g.c32, g.ldc32 = _p(c32), N
     g.c16_hi, g.c16_lo, g.ldc16 = _p(c16h), _p(c16l), N
@@ -118,7 +117,7 @@ def bias_corr(a16, w_lo, bias=None, valid_rows=None, seg_rows=0, M=None):
     assert a16.is_cuda and a16.dim() == 2 and a16.stride(1) == 1 and w_lo.dim() == 2 and w_lo.stride(1) == 1
     M = M if M is not None else a16.shape[0]
     K, N = a16.shape[1], w_lo.shape[0]
-    scratch = torch.empty(_lib.lib().mer_bias_corr_scratch_bytes(K), dtype=torch.uint8, device=a16.device)
+    scratch = torch.zeros(_lib.lib().mer_bias_corr_scratch_bytes(K), dtype=torch.uint8, device=a16.device)
     out = torch.empty(N, dtype=torch.float32, device=a16.device)
     _lib.check(_lib.lib().mer_bias_corr(a16.data_ptr(), dt_code(a16.dtype), a16.stride(0), 0, 0, M, K, int(seg_rows), _p(valid_rows),
                                         w_lo.data_ptr(), w_lo.stride(0), _p(bias), N, scratch.data_ptr(), out.data_ptr(), stream()), "mer_bias_corr")
@@ -153,6 +152,17 @@ def attention(qkv, B, T, H, scale, *, kv_len=None, out_lo=False):
                                         _p(oh), _p(ol), D, B, T, H, float(scale), _p(kv_len), dt_code(qkv.dtype), stream()),
                "mer_attention")
     return oh, ol
+
+
+def attention_cls(q, qkv, B, T, H, scale, *, kv_len=None):
+    """One query per sequence: q 16-bit [B, H*64], keys / values from qkv [B*T, 3*H*64] -> ctx 16-bit [B, H*64] (mer_attention_cls)."""
+    D = H * 64
+    assert qkv.shape == (B * T, 3 * D) and qkv.is_contiguous() and q.shape == (B, D) and q.is_contiguous()
+    oh = torch.empty((B, D), dtype=qkv.dtype, device=qkv.device)
+    es = qkv.element_size()
+    _lib.check(_lib.lib().mer_attention_cls(q.data_ptr(), D, qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, 3 * D, _p(oh), None, D,
+                                            B, T, H, float(scale), _p(kv_len), dt_code(qkv.dtype), stream()), "mer_attention_cls")
+    return oh
 
 
 def wave_normalize(x, do_normalize=True):

@@ -409,6 +409,23 @@ def heavy_tailed(sd, sigma=0.7, seed=99):
     return out
 
 
+def ln_outliers(sd, channels=3, lo=30.0, hi=100.0, seed=77):
+    """Copy of a synthetic checkpoint in which `channels` channels of every LayerNorm weight are scaled by 30-100x: what pretrained
+    HuBERT / RoBERTa checkpoints do (a few massive LayerNorm-gamma / residual channels), and what stresses the 16-bit activation
+    planes, the bf8 A operand of the MX correction and the batch-mean correction — weight perturbations (heavy_tailed) do not."""
+    g = _g(seed)
+    out, chosen = {}, {}
+    for k, v in sd.items():
+        if v.dim() == 1 and k.endswith("weight") and ("layer_norm" in k.lower() or "layernorm" in k.lower() or k.endswith("LayerNorm.weight")):
+            v = v.clone()
+            if v.numel() not in chosen:   # the same channels in every LayerNorm of a width, as in pretrained checkpoints
+                chosen[v.numel()] = (torch.randperm(v.numel(), generator=g)[:channels], lo + (hi - lo) * torch.rand(channels, generator=g))
+            idx, f = chosen[v.numel()]
+            v[idx] = v[idx] * f
+        out[k] = v
+    return out
+
+
 # ---- the seeded synthetic inputs of SURVEY.md §8(d) ----
 def synth_audio(B, L=80000, seed=1234):
     wav = 0.1 * torch.randn(B, L, generator=_g(seed))

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Aggregates a rocprofv3 SQ counter pass (scripts/pmc_mfma.sh) per kernel: mean per launch of every counter, and
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs of the chip)
+i.e. the fraction of the launch's SIMD-cycles in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, summed
+over the chip: 16 per v_mfma_f32_16x16x32_f16; GRBM_GUI_ACTIVE = shader-clock cycles the launch took).  The analytic cross-check
+(MFMA instructions the launch must issue x 16 cycles) is printed next to it for the GEMM kernels."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+SIMDS = 256 * 4
+agg = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Kernel_Name"]
+            if "gemm16_kernel" in name:
+                targs = name.split("gemm16_kernelI")[1].split("EEvNS")[0]
+                short = "gemm16<" + ",".join([("f16" if targs.startswith("DF16_") else "bf16")] + re.findall(r"L[ib](\d+)E", targs)) + ">"
+            else:
+                short = re.sub(r"^_ZN3mer\d+", "", name.split("(")[0])[:60]
+            agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
+print(f"{'kernel':64s} {'launches':>8s} {'mfma_busy':>9s} {'MFMA insts/launch':>18s} {'GUI_ACTIVE':>12s}")
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
+    mean = {c: sum(x) / len(x) for c, x in v.items()}
+    n = len(next(iter(v.values())))
+    act = mean.get("GRBM_GUI_ACTIVE", 0.0)
+    busy = mean.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    out[k] = dict(launches=n, counters_per_launch={c: round(x, 1) for c, x in mean.items()},
+                  mfma_busy=round(busy / (act * SIMDS), 4) if act else None)
+    print(f"{k[:64]:64s} {n:8d} {out[k]['mfma_busy'] if out[k]['mfma_busy'] is not None else float('nan'):9.4f} {mean.get('SQ_INSTS_MFMA', 0):18.0f} {act:12.0f}")
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mertools_amd", "csrc")
+out["_source_sha"] = hashlib.sha256(open(os.path.join(csrc, "gemm16_impl.h"), "rb").read()).hexdigest()[:16]
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)

@@ -1,12 +1,13 @@
 // gemm16_bench.cpp — times the REAL mer_gemm16 kernels through the C ABI of libmer_hip.so, without Python or torch, so that one
 // GPU-box call costs ~15 s instead of ~45 s (no interpreter / torch import): the tool for A/B-ing kernel changes next round.
 //
-//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | all
+//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | roberta | all;   MER_TILE=3|4 forces a tile class
 //
-// For every (shape, passes, epilogue) of the bench's dominant GEMMs it runs: row-major W, pre-blocked W (mer_w_block_pack), and —
-// for the K = ffn shapes — a blocked A plane produced by a c16_blocked producer.  One JSON line per configuration:
+// For every (shape, epilogue) of the bench's block GEMMs it runs pre-blocked W (mer_w_block_pack) with hot operands (one set of planes,
+// re-launched) and with cold ones (four rotating A / output plane sets).  Operands are pseudo-random f16 values: constant-filled planes
+// toggle so few bits that the chip clocks 15-20 % higher than on real activations.  One JSON line per configuration:
 // microseconds per launch (hipEvents around `reps` back-to-back launches after `warm` warm-up launches: sustained clocks) and
-// algorithmic TFLOP/s.  Options can be switched for a run with MER_SET="gemm_pkepi=0,gemm_wblk=0" (mer_set_option).
+// algorithmic TFLOP/s.  Debug switches can be set for a run with MER_SET="gemm_dbg_skip=1" (mer_set_option).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,6 +26,22 @@ static void* dev_alloc(size_t bytes, int fill) {
   void* p;
   CK(hipMalloc(&p, bytes));
   CK(hipMemset(p, fill, bytes));
+  return p;
+}
+
+// pseudo-random f16 values in (-scale, scale): data-dependent power makes constant planes unrepresentative
+__global__ void fill_rand16(_Float16* p, size_t n, float scale, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = (_Float16)(((int)(h & 0xffff) - 32768) * (scale / 32768.0f));
+  }
+}
+static void* dev_rand16(size_t elems, float scale, unsigned seed) {
+  void* p;
+  CK(hipMalloc(&p, elems * 2));
+  hipLaunchKernelGGL(fill_rand16, dim3(2048), dim3(256), 0, 0, (_Float16*)p, elems, scale, seed);
+  CK(hipGetLastError());
   return p;
 }
 
@@ -60,10 +77,8 @@ static float time_gemm_rot(const mer_gemm16_args* g, int n, int warm, int reps) 
 
 static void run_shape(const Shape& s, int warm, int reps) {
   const int Mp = (s.M + 255) / 256 * 256;
-  // operands: 0x3c bytes = f16 1.0-ish patterns are irrelevant for timing; zero planes would let the hardware clock higher
-  // (data-dependent power), so fill with a non-trivial byte pattern
-  void* a = dev_alloc((size_t)Mp * s.K * 2, 0x2e);
-  void* w = dev_alloc((size_t)s.N * s.K * 2, 0x2b);
+  void* a = dev_rand16((size_t)Mp * s.K, 2.0f, 1u);
+  void* w = dev_rand16((size_t)s.N * s.K, 0.05f, 2u);
   void* wlo = s.passes >= 2 && s.passes != 4 ? dev_alloc((size_t)s.N * s.K * 2, 0x11) : nullptr;
   void* wblk = dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0);
   void* wlo_blk = wlo ? dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0) : nullptr;
@@ -91,13 +106,13 @@ static void run_shape(const Shape& s, int warm, int reps) {
   g.bias = bias; g.act = s.act; g.residual = resid; g.ldr = s.N;
   g.c32 = c32; g.ldc32 = s.N; g.c16_hi = c16; g.ldc16 = s.N;
   g.nbatch = 1; g.nb_inner = 1; g.passes = s.passes;
+  if (const char* t = getenv("MER_TILE")) g.tile = atoi(t);   // 0 auto, 3 = 256x256, 4 = 128x256 (two workgroups per CU)
   const double flops = 2.0 * s.M * (double)s.N * s.K;
   auto report = [&](const char* variant, float us) {
     printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"passes\": %d, \"variant\": \"%s\", \"us\": %.1f, \"TFLOPs\": %.0f}\n",
            s.name, s.M, s.N, s.K, s.passes, variant, us, flops / us * 1e-6);
     fflush(stdout);
   };
-  report("row-major W", time_gemm(g, warm, reps));
   g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk;
   report("pre-blocked W", time_gemm(g, warm, reps));
   {   // cold operands: 4 rotating sets of A / residual / output planes (weights stay: they are small and shared by all row tiles)
@@ -107,22 +122,13 @@ static void run_shape(const Shape& s, int warm, int reps) {
     for (int r = 0; r < R; ++r) {
       gr[r] = g;
       if (r == 0) continue;
-      void* a2 = dev_alloc((size_t)Mp * s.K * 2, 0x2e); extra.push_back(a2); gr[r].a_hi = a2;
+      void* a2 = dev_rand16((size_t)Mp * s.K, 2.0f, 10u + r); extra.push_back(a2); gr[r].a_hi = a2;
       if (s.residual) { void* p = dev_alloc((size_t)s.M * s.N * 4, 0); extra.push_back(p); gr[r].residual = (float*)p; }
       if (s.out32) { void* p = dev_alloc((size_t)s.M * s.N * 4, 0); extra.push_back(p); gr[r].c32 = (float*)p; }
       if (s.out16) { void* p = dev_alloc((size_t)Mp * s.N * 2, 0); extra.push_back(p); gr[r].c16_hi = p; }
     }
     report("pre-blocked W, 4 rotating A / output planes (cold operands)", time_gemm_rot(gr, R, warm, reps));
     for (void* p : extra) CK(hipFree(p));
-  }
-  if (s.out16 && s.N % 32 == 0 && !s.out32) {   // producer side of a blocked activation plane (fc1)
-    g.c16_blocked = 1;
-    report("pre-blocked W, blocked 16-bit output", time_gemm(g, warm, reps));
-    g.c16_blocked = 0;
-  }
-  if (s.K >= 2048 && (s.passes == 1 || s.passes == 2)) {   // consumer side (fc2): the A plane's content is irrelevant for timing
-    g.a_blocked = 1;
-    report("pre-blocked W, blocked A", time_gemm(g, warm, reps));
   }
   for (void* p : {a, w, wlo, wblk, wlo_blk, wmx, (void*)bias, (void*)resid, (void*)c32, c16})
     if (p) CK(hipFree(p));
@@ -143,26 +149,35 @@ int main(int argc, char** argv) {
     }
   }
   printf("{\"library\": \"%s\", \"warm\": %d, \"reps\": %d}\n", mer_version(), warm, reps);
-  // CLIP-ViT-B/16, 64 clips x 8 frames x 197 tokens (bench.py's visual leg, default mx preset with the selective correction)
+  // the block GEMMs of bench.py's step under the default "mean" preset (every GEMM one f16 pass; the correction is a bias)
+  // CLIP-ViT-B/16: 64 clips x 8 frames x 197 tokens
   const int Mc = 100864;
   const Shape clip[] = {
-      {"clip Q|K (one pass)", Mc, 1536, 768, 1, MER_ACT_NONE, false, false, true},
-      {"clip V (MX)", Mc, 768, 768, 4, MER_ACT_NONE, false, false, true},
-      {"clip out-proj (MX, residual, fp32 out)", Mc, 768, 768, 4, MER_ACT_NONE, true, true, false},
-      {"clip fc1 (one pass, quick_gelu)", Mc, 3072, 768, 1, MER_ACT_QUICK_GELU, false, false, true},
-      {"clip fc2 (one pass, residual, fp32 out)", Mc, 768, 3072, 1, MER_ACT_NONE, true, true, false},
+      {"clip QKV", Mc, 2304, 768, 1, MER_ACT_NONE, false, false, true},
+      {"clip out-proj (residual, fp32 out)", Mc, 768, 768, 1, MER_ACT_NONE, true, true, false},
+      {"clip fc1 (quick_gelu)", Mc, 3072, 768, 1, MER_ACT_QUICK_GELU, false, false, true},
+      {"clip fc2 (residual, fp32 out)", Mc, 768, 3072, 1, MER_ACT_NONE, true, true, false},
   };
-  // HuBERT-base, 64 clips x 249 frames: post-LN blocks keep the FFN corrected; conv1 of the feature extractor (M = 64 x 7999)
+  // HuBERT-base: 64 clips x 249 frames; conv1 of the feature extractor (M = 64 x 7999)
   const int Mh = 15936;
   const Shape hubert[] = {
-      {"hubert Q|K (one pass)", Mh, 1536, 768, 1, MER_ACT_NONE, false, false, true},
-      {"hubert V (MX)", Mh, 768, 768, 4, MER_ACT_NONE, false, false, true},
-      {"hubert fc1 (MX, gelu)", Mh, 3072, 768, 4, MER_ACT_GELU, false, false, true},
-      {"hubert fc2 (MX, residual, fp32 out)", Mh, 768, 3072, 4, MER_ACT_NONE, true, true, false},
-      {"hubert conv1-like (MX, gelu, M = 511936, K = 1536, dense rows)", 511936, 512, 1536, 4, MER_ACT_GELU, false, false, true},
+      {"hubert QKV", Mh, 2304, 768, 1, MER_ACT_NONE, false, false, true},
+      {"hubert out-proj (residual, fp32 out)", Mh, 768, 768, 1, MER_ACT_NONE, true, true, false},
+      {"hubert fc1 (gelu)", Mh, 3072, 768, 1, MER_ACT_GELU, false, false, true},
+      {"hubert fc2 (residual, fp32 out)", Mh, 768, 3072, 1, MER_ACT_NONE, true, true, false},
+      {"hubert conv1-like (gelu, M = 511936, K = 1536, dense rows)", 511936, 512, 1536, 1, MER_ACT_GELU, false, false, true},
+  };
+  // RoBERTa-base: 64 clips x 64 tokens
+  const int Mr = 4096;
+  const Shape roberta[] = {
+      {"roberta QKV", Mr, 2304, 768, 1, MER_ACT_NONE, false, false, true},
+      {"roberta out-proj (residual, fp32 out)", Mr, 768, 768, 1, MER_ACT_NONE, true, true, false},
+      {"roberta fc1 (gelu)", Mr, 3072, 768, 1, MER_ACT_GELU, false, false, true},
+      {"roberta fc2 (residual, fp32 out)", Mr, 768, 3072, 1, MER_ACT_NONE, true, true, false},
   };
   const bool all = !strcmp(set, "all");
   if (all || !strcmp(set, "clip")) for (const Shape& s : clip) run_shape(s, warm, reps);
   if (all || !strcmp(set, "hubert")) for (const Shape& s : hubert) run_shape(s, warm, reps);
+  if (all || !strcmp(set, "roberta")) for (const Shape& s : roberta) run_shape(s, warm, reps);
   return 0;
 }

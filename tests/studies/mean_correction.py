@@ -78,6 +78,8 @@ def main():
     heavy = "--heavy" in sys.argv
     if heavy:
         hsd, csd, bsd = W.heavy_tailed(hsd), W.heavy_tailed(csd), W.heavy_tailed(bsd)
+    if "--outliers" in sys.argv:   # 3 LayerNorm-gamma channels x 30-100 (activation outliers)
+        hsd, csd, bsd = W.ln_outliers(hsd), W.ln_outliers(csd), W.ln_outliers(bsd)
     def run():
         h = torch.stack(R.hubert_hidden_states(hsd, vars(hc), wav))[[-4, -3, -2, -1]].sum(0)
         c = R.clip_image_features(csd, ccfg, px)

@@ -220,7 +220,7 @@ def test_clip_base16_8frames(dev):
         _report(f"clip-B/16[{prec}]", res[prec])
         del m
     assert res["balanced"]["utt"] <= TOL, res
-    assert res["mx"]["utt"] <= TOL and res["mx"]["frames"] <= 2 * TOL, res   # 1576 rows: every block GEMM runs the MX kernel
+    assert res["mx"]["utt"] <= TOL and res["mx"]["frames"] <= TOL, res   # 1576 rows: every block GEMM runs the MX kernel
     assert res["mean"]["utt"] <= TOL and res["mean"]["frames"] <= TOL, res  # one pass + per-frame mean-token correction
     assert res["accurate"]["frames"] <= TOL and res["accurate"]["utt"] <= X3, res
 
@@ -259,8 +259,8 @@ def test_hubert_base_bench_tiles(dev, heavy):
     from util import rel_err
     cfg = W.hubert_config("base")
     sd = W.hubert_state_dict(cfg, 0)
-    if heavy:
-        sd = W.heavy_tailed(sd)
+    if heavy:   # "outliers": 3 LayerNorm-gamma channels x 30-100 (activation outliers); True: log-normal outlier weights
+        sd = W.ln_outliers(sd) if heavy == "outliers" else W.heavy_tailed(sd)
     B = 8                                   # M = 8 * 249 = 1992 rows
     wav = W.synth_audio(B, 80000, seed=4321)
     hs = R.hubert_hidden_states(sd, vars(cfg), wav)
@@ -277,7 +277,7 @@ def test_hubert_base_bench_tiles(dev, heavy):
         del m
     for prec in res:
         assert res[prec]["utt"] <= TOL and res[prec]["utt_worst_clip"] <= TOL, res
-        assert res[prec]["frame"] <= 2 * TOL, res     # FRAME features: reported; the saved default (UTT) is held to 1e-3
+        assert res[prec]["frame"] <= TOL, res     # FRAME features (feature_level=FRAME saves them): the same 1e-3 bar
 
 
 @pytest.mark.parametrize("heavy", [False, True])
@@ -287,7 +287,7 @@ def test_roberta_base_bench_tiles(dev, heavy):
     cfg = W.bert_config("roberta-base")
     sd = W.bert_state_dict(cfg, 0)
     if heavy:
-        sd = W.heavy_tailed(sd)
+        sd = W.ln_outliers(sd) if heavy == "outliers" else W.heavy_tailed(sd)
     B = 16                                  # M = 16 * 64 = 1024 rows
     ids = W.synth_tokens(B, 64, seed=4322)
     ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids))
@@ -304,7 +304,7 @@ def test_roberta_base_bench_tiles(dev, heavy):
         del m
     for prec in res:
         assert res[prec]["utt"] <= TOL and res[prec]["utt_worst_clip"] <= TOL, res
-        assert res[prec]["frame"] <= 2 * TOL, res
+        assert res[prec]["frame"] <= TOL, res
 
 
 def test_clip_base16_heavy_tailed(dev):
@@ -322,7 +322,7 @@ def test_clip_base16_heavy_tailed(dev):
         torch.cuda.synchronize()
         e, eu = rel_err(out.cpu(), ref)[0], rel_err(pooled.cpu(), ref.mean(0, keepdim=True))[0]
         print(f"clip-B/16 heavy-tailed [{prec}]: frames={e:.2e} utt={eu:.2e}")
-        assert eu <= TOL and e <= 2 * TOL
+        assert eu <= TOL and e <= TOL
         del m
 
 
@@ -343,7 +343,7 @@ def test_clip_base32_frames(dev):
         e, eu = rel_err(out.cpu(), ref)[0], rel_err(pooled.cpu(), ref.view(4, 8, -1).mean(1))[0]
         print(f"clip-B/32[{prec}]: frames={e:.2e} utt={eu:.2e}")
         assert out.shape == (32, 512)
-        assert eu <= (TOL if prec == "mx" else X3) and e <= (2 * TOL if prec == "mx" else TOL)
+        assert eu <= (TOL if prec == "mx" else X3) and e <= TOL
         del m
 
 
@@ -390,7 +390,7 @@ def test_hubert_ragged_batch(dev, style):
         worst["frame"] = max(worst["frame"], rel_err(fr[b, :Tb], feat)[0])
     print(f"hubert ragged [{style}]: worst clip utt={worst['utt']:.2e} frame={worst['frame']:.2e}")
     assert worst["utt"] <= tol, worst
-    assert worst["frame"] <= (2 * TOL if style in ("base", "large") else tol), worst
+    assert worst["frame"] <= (TOL if style in ("base", "large") else tol), worst
     # padding must not leak: the same clips in a batch padded 1000 samples further give the same features
     batch2 = torch.zeros(B, L + 1000)
     batch2[:, :L] = batch
@@ -411,7 +411,7 @@ def test_large_trio(dev):
     wav = W.synth_audio(1, 80000)
     hs = R.hubert_hidden_states(sd, vars(cfg), wav)
     utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
-    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("accurate", "bf16")):
+    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("mean", "f16"), ("accurate", "bf16")):
         m = HipHubertModel(sd, cfg, device=dev, precision=prec, dtype=dtype)
         res[f"hubert-large[{prec},{dtype}]"] = rel_err(m.extract_utterance(wav.to(dev)).cpu(), utt)[0]
         del m
@@ -420,23 +420,41 @@ def test_large_trio(dev):
     sd = W.videomae_state_dict(cfg, 0)
     px = W.synth_video(1)
     exp = R.videomae_last_hidden_state(sd, vars(cfg), px).view(8, 196, -1).mean(1)
-    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("accurate", "bf16")):
+    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("mean", "f16"), ("accurate", "bf16")):
         m = HipVideoMAEModel(sd, cfg, device=dev, precision=prec, dtype=dtype)
         res[f"videomae-large[{prec},{dtype}]"] = rel_err(m.extract_segments(px.to(dev)).cpu(), exp)[0]
         del m
     del sd
     cfg = W.bert_config("roberta-large")
     sd = W.bert_state_dict(cfg, 0)
-    ids = W.synth_tokens(2, 64)
+    B = 16                                  # M = 1024 rows: the 256x256 kernels the bench times
+    ids = W.synth_tokens(B, 64)
     ref = torch.stack(R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
-    for prec, dtype in (("balanced", "f16"), ("accurate", "bf16")):
+    for prec, dtype in (("balanced", "f16"), ("mx", "f16"), ("mean", "f16")):
         m = HipBertModel(sd, cfg, device=dev, precision=prec, dtype=dtype)
-        res[f"roberta-large[{prec},{dtype}]"] = rel_err(m.extract_utterance(ids.to(dev), [64, 64], 1, -1).cpu(), ref)[0]
+        res[f"roberta-large[{prec},{dtype}]"] = rel_err(m.extract_utterance(ids.to(dev), [64] * B, 1, -1).cpu(), ref)[0]
         del m
     torch.cuda.synchronize()
     print("large trio: " + "  ".join(f"{k}={v:.2e}" for k, v in res.items()))
+    # configs[4] is served with f16 MFMA operands (same MFMA rate as bf16 on gfx950, three more mantissa bits).
+    # bf16 planes stay available: 3-pass bf16 meets the bar for the audio and video encoders; RoBERTa-large does not (1.2e-3: bf16's
+    # 8-bit mantissa in the attention operands) — test_roberta_large_bf16_is_outside_the_bar records that instead of a wider tolerance.
     for k, v in res.items():
-        assert v <= (TOL if ",f16]" in k else 5e-3), (k, v)   # bf16 (8-bit mantissa) even 3-pass is limited by bf16 attention / planes
+        assert v <= TOL, (k, v)
+
+
+@pytest.mark.xfail(reason="bf16 attention operands (8-bit mantissa) put RoBERTa-large at ~1.2e-3 even with 3-pass GEMMs; configs[4] is served in f16", strict=False)
+def test_roberta_large_bf16_is_outside_the_bar(dev):
+    from mertools_amd.encoders import HipBertModel
+    from util import rel_err
+    cfg = W.bert_config("roberta-large")
+    sd = W.bert_state_dict(cfg, 0)
+    ids = W.synth_tokens(2, 64)
+    ref = torch.stack(R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
+    m = HipBertModel(sd, cfg, device=dev, precision="accurate", dtype="bf16")
+    e = rel_err(m.extract_utterance(ids.to(dev), [64, 64], 1, -1).cpu(), ref)[0]
+    print(f"roberta-large[accurate,bf16]={e:.2e}")
+    assert e <= TOL
 
 
 # ---- data2vec-audio: 5-layer positional conv stack on the HuBERT engine ----

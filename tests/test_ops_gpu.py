@@ -150,29 +150,21 @@ def test_layernorm(dev, D):
 
 @pytest.mark.parametrize("D", [512, 768, 1024])
 def test_layernorm_many_rows(dev, D):
-    """M large enough for the multi-row kernel (a wave walks several rows, gamma / beta in LDS): agrees with the one-row kernel
-    (mer_set_option("ln_rows", 0)) to fp32 rounding, and both with the reference."""
-    from mertools_amd import _lib
-    ops, lib = _ops(), _lib.lib()
+    """M large enough for the multi-row kernel (a wave walks several rows, gamma / beta in LDS) against the fp64 reference, and
+    bit for bit against the one-row kernel the same rows take in a small launch (same arithmetic per row)."""
+    ops = _ops()
     M = 33003                                                     # > 8 rows per resident wave slot, not a multiple of anything
     x = (_rand((M, D), 12, 3.0) + 0.5).to(dev)
     g, b = (_rand((D,), 13) * 0.1 + 1.0).to(dev), (_rand((D,), 14) * 0.1).to(dev)
     ref = F.layer_norm(x.cpu().double(), (D,), g.cpu().double(), b.cpu().double(), 1e-5).float()
-    outs = {}
-    try:
-        for rows in (1, 0):
-            lib.mer_set_option(b"ln_rows", rows)
-            o32, oh, ol = ops.layernorm(x, g, b, 1e-5, out32=True, out16=True, out16_lo=True)
-            og, _, _ = ops.layernorm(x, g, b, 1e-5, act="gelu")
-            torch.cuda.synchronize()
-            outs[rows] = (o32.clone(), oh.clone(), ol.clone(), og.clone())
-    finally:
-        lib.mer_set_option(b"ln_rows", 1)
-    for a, c in zip(outs[1][:1] + outs[1][3:], outs[0][:1] + outs[0][3:]):   # fp32 outputs: the same arithmetic up to FMA contraction
-        assert_close(a.cpu(), c.cpu(), 1e-6, "multi-row vs one-row LayerNorm")
-    assert_close(outs[1][0].cpu(), ref, 2e-6, "layernorm fp32 (multi-row)")
-    assert_close((outs[1][1].float() + outs[1][2].float()).cpu(), ref, 2e-6, "layernorm planes (multi-row)")
-    assert_close(outs[1][3].cpu(), F.gelu(ref.double()).float(), 2e-6, "layernorm+gelu (multi-row)")
+    o32, oh, ol = ops.layernorm(x, g, b, 1e-5, out32=True, out16=True, out16_lo=True)
+    og, _, _ = ops.layernorm(x, g, b, 1e-5, act="gelu")
+    s32, _, _ = ops.layernorm(x[:1000].contiguous(), g, b, 1e-5, out32=True)     # small M: the one-row kernel
+    torch.cuda.synchronize()
+    assert_close(o32[:1000].cpu(), s32.cpu(), 1e-6, "multi-row vs one-row LayerNorm")
+    assert_close(o32.cpu(), ref, 2e-6, "layernorm fp32 (multi-row)")
+    assert_close((oh.float() + ol.float()).cpu(), ref, 2e-6, "layernorm planes (multi-row)")
+    assert_close(og.cpu(), F.gelu(ref.double()).float(), 2e-6, "layernorm+gelu (multi-row)")
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -460,8 +452,8 @@ def test_image_normalize_u8_matches_clip_preprocess(dev):
 @pytest.mark.parametrize("tile", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(2304, 1536, 256), (1000, 776, 96), (70000, 768, 64), (515, 72, 32)])
 def test_gemm16_specialised_epilogues_equal_generic(dev, M, N, K, tile):
-    """The two specialised epilogues — packed row pairs + streaming stores for 16-bit-only outputs (gemm_pkepi), whole-line
-    4-columns-per-lane for fp32-only outputs with residual (gemm_epi32) — against the generic fp32-staged epilogue, bit for bit,
+    """The two specialised epilogues — packed row pairs + streaming stores for 16-bit-only outputs, whole-line 4-columns-per-lane
+    for fp32-only outputs with residual — against the generic fp32-staged epilogue (debug switch gemm_generic_epi), bit for bit,
     on every tile class, ragged M / N included; and the generic one against fp64."""
     from mertools_amd import _lib
     ops = _ops()
@@ -476,13 +468,11 @@ def test_gemm16_specialised_epilogues_equal_generic(dev, M, N, K, tile):
         kw16 = dict(bias=bias, act=act, out16=True, passes=1, tile=tile)
         kw32 = dict(bias=bias, act=act, residual=res, out32=True, passes=1, tile=tile)
         try:
-            lib.mer_set_option(b"gemm_pkepi", 0)
-            lib.mer_set_option(b"gemm_epi32", 0)
+            lib.mer_set_option(b"gemm_generic_epi", 1)
             _, ref16, _ = ops.gemm16(ah, wh, **kw16)
             ref32, _, _ = ops.gemm16(ah, wh, **kw32)
         finally:
-            lib.mer_set_option(b"gemm_pkepi", 1)
-            lib.mer_set_option(b"gemm_epi32", 1)
+            lib.mer_set_option(b"gemm_generic_epi", 0)
         _, c16, _ = ops.gemm16(ah, wh, **kw16)
         c32, _, _ = ops.gemm16(ah, wh, **kw32)
         inplace = res.clone()                                   # residual updated in place (the ABI allows residual == c32)
@@ -553,51 +543,6 @@ def _unblock(plane, Mp, N):
     return logical.permute(0, 2, 1, 3, 4).reshape(Mp, N)
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 3072, 768), (1500, 512, 256), (4100, 1024, 96)])
-def test_gemm16_blocked_activation_plane(dev, M, N, K):
-    """fc1 -> fc2 in blocked form: (i) c16_blocked writes exactly the row-major 16-bit output, re-laid as [M/256][N/32] LDS images;
-    (ii) a consumer reading that plane with a_blocked gives bit-identical results to reading the row-major plane."""
-    ops = _ops()
-    a = _rand((M, K), 91)
-    w1 = _rand((N, K), 92) * 0.05
-    w2 = _rand((768, N), 93) * 0.05
-    ah, _ = ops.split16(a.to(dev), "f16")
-    w1h = ops.split16_host(w1, "f16")[0].to(dev)
-    w2h, w2l = ops.split16_host(w2, "f16")
-    w2h, w2l = w2h.to(dev), w2l.to(dev)
-    bias = _rand((N,), 94).to(dev)
-    _, ref16, _ = ops.gemm16(ah, w1h, bias=bias, act="gelu", out16=True, passes=1)
-    _, blk16, _ = ops.gemm16(ah, w1h, bias=bias, act="gelu", out16=True, passes=1, c16_blocked=True)
-    torch.cuda.synchronize()
-    Mp = (M + 255) // 256 * 256
-    assert blk16.shape[0] == Mp
-    assert torch.equal(_unblock(blk16, Mp, N)[:M], ref16)
-    for passes in (1, 2):
-        kw = dict(w_lo=w2l if passes == 2 else None, out32=True, passes=passes, tile=3)
-        r32, _, _ = ops.gemm16(ref16, w2h, **kw)
-        c32, _, _ = ops.gemm16(blk16, w2h, M=M, lda=N, a_blocked=True, **kw)
-        torch.cuda.synchronize()
-        assert torch.equal(c32, r32), passes
-
-
-def test_tf_ablk_option_is_bit_exact(dev):
-    """mer_set_option("tf_ablk", 1): CLIP-B/16 frames with the FFN plane blocked == the default path, bit for bit."""
-    from mertools_amd import _lib
-    from mertools_amd.encoders import HipCLIPModel
-    from oracle import weights as W
-    cfg = W.clip_config("base16")
-    model = HipCLIPModel(W.clip_state_dict(cfg, 0), cfg, device=dev)
-    px = W.synth_frames(8, seed=7).to(dev)
-    ref = model.get_image_features(px).clone()
-    try:
-        _lib.lib().mer_set_option(b"tf_ablk", 1)
-        out = model.get_image_features(px).clone()
-        torch.cuda.synchronize()
-    finally:
-        _lib.lib().mer_set_option(b"tf_ablk", 0)
-    assert torch.equal(out, ref)
-
-
 @pytest.mark.parametrize("h,w,size", [(256, 320, 224), (300, 200, 224), (100, 100, 224), (480, 640, 224), (231, 517, 224), (224, 224, 224), (40, 52, 32)])
 def test_image_resize_crop_u8_matches_pillow(dev, h, w, size):
     """mer_image_resize_crop_u8 (two integer passes on the GPU, cropped region only) == PIL Image.resize(BICUBIC) + centre crop,
@@ -665,3 +610,25 @@ def test_gemm_with_bias_corr_matches_two_pass_on_the_mean(dev):
     e1 = (o1.double().cpu() - true).abs().max() / true.abs().max()
     e0 = (o0.double().cpu() - true).abs().max() / true.abs().max()
     assert e1 < 0.5 * e0, (e0.item(), e1.item())
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("B,T,H,lens", [(5, 197, 12, None), (3, 50, 2, None), (2, 257, 4, None), (3, 64, 2, [64, 17, 1]), (1, 577, 2, None)])
+def test_attention_cls(dev, dtype, B, T, H, lens):
+    """mer_attention_cls: the CLS query of every sequence against all keys — softmax(q K^T * scale) V in fp64."""
+    ops = _ops()
+    t16 = ops.torch16(dtype)
+    D = H * 64
+    qkv = _rand((B * T, 3 * D), 93).to(t16)
+    q = _rand((B, D), 94).to(t16)
+    kv = torch.tensor(lens, dtype=torch.int32).to(dev) if lens else None
+    out = ops.attention_cls(q.to(dev), qkv.to(dev), B, T, H, 0.125, kv_len=kv)
+    torch.cuda.synchronize()
+    k = qkv[:, D:2 * D].double().view(B, T, H, 64)
+    v = qkv[:, 2 * D:].double().view(B, T, H, 64)
+    sc = torch.einsum("bhd,bthd->bht", q.double().view(B, H, 64), k) * 0.125
+    if lens:
+        for b, n in enumerate(lens):
+            sc[b, :, n:] = float("-inf")
+    ref = torch.einsum("bht,bthd->bhd", torch.softmax(sc, -1), v).reshape(B, D)
+    assert_close(out.float().cpu(), ref.float(), 6e-3 if dtype == "bf16" else 8e-4, f"attention_cls B={B} T={T} H={H}")
