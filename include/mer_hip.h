@@ -195,6 +195,9 @@ int mer_hubert_conv0_gn_ragged(const float* wav, int B, int L, const float* w /*
  * int32 [B] each; kernels / strides: HOST int [n_conv]. */
 int mer_hubert_valid_frames(const int* valid_samples, int B, int L, int n_conv, const int* kernels, const int* strides,
                             int* t0_len, int* tn_len, mer_stream_t stream);
+/* The same after EVERY conv layer: lens = device int32 [n_conv, B] (row 0 == t0_len, row n_conv - 1 == tn_len). */
+int mer_hubert_valid_frames_all(const int* valid_samples, int B, int L, int n_conv, const int* kernels, const int* strides,
+                                int* lens, mer_stream_t stream);
 
 /* Layer-0 conv for feat_extract_norm == "layer" (HuBERT-large / wav2vec2-large, HF:hubert/modeling_hubert.py:127-151):
  * out[b,t,c] = bias[c] + conv, fp32 channels-last [B,T0,C]; the per-frame LayerNorm + GELU is mer_layernorm(act=GELU). */

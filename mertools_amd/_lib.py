@@ -177,6 +177,7 @@ _PROTOS = {
     "mer_hubert_conv0_gn_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mer_hubert_valid_frames": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int), c_void_p, c_void_p, c_void_p]),
+    "mer_hubert_valid_frames_all": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int), c_void_p, c_void_p]),
     "mer_posconv_pack_ragged": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mer_vit_create": (c_int, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(c_void_p)]),
     "mer_vit_destroy": (None, [c_void_p]),

@@ -44,7 +44,7 @@ def _load(model, model_dir, hip_cls, device, precision):
 
 @registry.register_visual_encoder("HIP_CLIP_VIT_LARGE")
 class HIP_CLIP_VIT_LARGE:
-    def __init__(self, model=None, model_dir=None, device="cuda:0", precision="mx", image_size=224):
+    def __init__(self, model=None, model_dir=None, device="cuda:0", precision="mean", image_size=224):
         self.model = _load(model, model_dir, HipCLIPModel, device, precision)
         self.device = torch.device(device)
         self.image_size = image_size
@@ -67,7 +67,7 @@ class HIP_CLIP_VIT_LARGE:
 
 @registry.register_acoustic_encoder("HIP_HUBERT_LARGE")
 class HIP_HUBERT_LARGE:
-    def __init__(self, model=None, model_dir=None, device="cuda:0", precision="mx", do_normalize=True):
+    def __init__(self, model=None, model_dir=None, device="cuda:0", precision="mean", do_normalize=True):
         self.model = _load(model, model_dir, HipHubertModel, device, precision)
         self.device = torch.device(device)
         self.do_normalize = do_normalize     # Wav2Vec2FeatureExtractor.do_normalize of the checkpoint

@@ -341,7 +341,7 @@ struct HubertPlan {
   P16 pospack;
   float* posbuf;       // data2vec-audio: output of a positional conv layer (input of the next)
   float* ring;
-  int* vlen;           // ragged batches: t0_len[B] | tn_len[B] (device int32)
+  int* vlen;           // ragged batches: valid frames of every clip after each conv layer, [n_conv][B] (device int32)
   TfBufs tf;
   int T[MER_MAX_CONV];
 };
@@ -354,7 +354,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   const long long M = (long long)B * Tn;
   const bool clo = c.conv_passes == 3;
   p.stats = (double*)ar.take((long long)B * C * 2 * 8);
-  p.vlen = (int*)ar.take(2 * (long long)B * 4);
+  p.vlen = (int*)ar.take((long long)c.n_conv * B * 4);
   p.convA = take16(ar, (long long)B * p.T[0] * C, clo);
   p.convB = take16(ar, (long long)B * p.T[1] * C, clo);
   p.conv32 = c.feat_norm_group ? nullptr : (float*)ar.take((long long)B * p.T[0] * C * 4);
@@ -413,22 +413,19 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   MER_REQUIRE(Tn >= 1, MER_ESHAPE, "mer_hubert_forward: input too short");
   const int M = B * Tn;
   const P16 none = {nullptr, nullptr};
-  // conv_passes == 5: batch-mean correction of the conv GEMMs (padded rows of a ragged batch are not excluded here: the conv
-  // stack's frames of the zero tail are a small share of the sampled windows)
+  // conv_passes == 5: batch-mean correction of the conv GEMMs / the projection; in a ragged batch only the output frames that come
+  // from a clip's own samples count (the zero tail's frames look nothing like speech and would drag the mean with the padding)
   MER_TRY(corr_begin(st, p.tf.corr));
-  const CorrWs ccw = {&p.tf.corr, 0, nullptr};
-  const CorrWs* cw = (cps == 5 && p.tf.corr.base) ? &ccw : nullptr;
+  const bool corr_on = cps == 5 && p.tf.corr.base;
 
   // ragged batch: per-row valid frame counts after conv 0 (GroupNorm statistics) and after the stack (positional conv zeros,
   // attention key mask), derived on the device from the rows' sample counts
   const int* t0_len = nullptr;
   const int* tn_len = nullptr;
   if (valid_samples) {
-    int* t0 = p.vlen;
-    int* tn = t0 + B;
-    MER_TRY(mer_hubert_valid_frames(valid_samples, B, L, c.n_conv, c.conv_kernel, c.conv_stride, t0, tn, stream));
-    t0_len = t0;
-    tn_len = tn;
+    MER_TRY(mer_hubert_valid_frames_all(valid_samples, B, L, c.n_conv, c.conv_kernel, c.conv_stride, p.vlen, stream));
+    t0_len = p.vlen;
+    tn_len = p.vlen + (long long)(c.n_conv - 1) * B;
   }
   P16 src = p.convA, dst = p.convB;
   if (c.feat_norm_group) {
@@ -454,6 +451,8 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
     g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk;
     g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
+    const CorrWs ccw = {&p.tf.corr, p.T[i], valid_samples ? p.vlen + (long long)i * B : nullptr};
+    const CorrWs* cw = corr_on ? &ccw : nullptr;
     if (c.feat_norm_group) {
       g.act = MER_ACT_GELU;
       if (last) { g.c32 = p.conv_last32; g.ldc32 = C; }
@@ -473,7 +472,8 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   // feature projection: LayerNorm(C) -> Linear(C -> D)   (HF:hubert/modeling_hubert.py:216-231)
   if (c.feat_proj_layer_norm)
     MER_TRY(mer_layernorm(p.conv_last32, C, w.fp_ln_g, w.fp_ln_b, c.tf.ln_eps, M, C, MER_ACT_NONE, nullptr, 0, p.fp16.hi, p.fp16.lo, C, dt, st));
-  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, cw));
+  const CorrWs pcw = {&p.tf.corr, Tn, tn_len};
+  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, corr_on ? &pcw : nullptr));
 
   // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
   HsMap hs;

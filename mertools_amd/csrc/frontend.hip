@@ -536,7 +536,8 @@ __global__ void swiglu_kernel(const float* y, long long ldy, int M, int F, T* oh
 
 // frames left of `valid_samples[b]` input samples after the first conv / after the whole stack (valid convs: floor((n - k) / s) + 1)
 struct ConvGeom { int k[MER_MAX_CONV], s[MER_MAX_CONV]; };   // passed by value: no device copy of the table
-__global__ void hubert_valid_frames_kernel(const int* valid_samples, int B, int L, int n_conv, ConvGeom cg, int* t0_len, int* tn_len) {
+// all_len (or NULL): the counts after EVERY conv layer, [n_conv][B] (row i = frames of each clip after conv i)
+__global__ void hubert_valid_frames_kernel(const int* valid_samples, int B, int L, int n_conv, ConvGeom cg, int* t0_len, int* tn_len, int* all_len) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int n = valid_samples[b];
@@ -544,9 +545,10 @@ __global__ void hubert_valid_frames_kernel(const int* valid_samples, int B, int 
   for (int i = 0; i < n_conv; ++i) {
     const int k = cg.k[i], s = cg.s[i];
     n = n >= k ? (n - k) / s + 1 : 0;
-    if (i == 0) t0_len[b] = n > 0 ? n : 1;   // (a clip shorter than the receptive field is rejected by the caller; stay finite)
+    if (i == 0 && t0_len) t0_len[b] = n > 0 ? n : 1;   // (a clip shorter than the receptive field is rejected by the caller; stay finite)
+    if (all_len) all_len[(long long)i * B + b] = (i == 0 && n <= 0) ? 1 : n;
   }
-  tn_len[b] = n;
+  if (tn_len) tn_len[b] = n;
 }
 
 static inline unsigned grid_for(long long n, int block) {
@@ -570,7 +572,19 @@ extern "C" int mer_hubert_valid_frames(const int* valid_samples, int B, int L, i
   ConvGeom cg;
   for (int i = 0; i < MER_MAX_CONV; ++i) { cg.k[i] = i < n_conv ? kernels[i] : 1; cg.s[i] = i < n_conv ? strides[i] : 1; }
   hipLaunchKernelGGL(hubert_valid_frames_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, valid_samples, B, L, n_conv,
-                     cg, t0_len, tn_len);
+                     cg, t0_len, tn_len, (int*)nullptr);
+  return check_launch("hubert_valid_frames");
+}
+
+extern "C" int mer_hubert_valid_frames_all(const int* valid_samples, int B, int L, int n_conv, const int* kernels, const int* strides,
+                                           int* lens, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(valid_samples && kernels && strides && lens && B > 0 && n_conv >= 1 && n_conv <= MER_MAX_CONV, MER_EINVAL,
+              "mer_hubert_valid_frames_all: bad argument");
+  ConvGeom cg;
+  for (int i = 0; i < MER_MAX_CONV; ++i) { cg.k[i] = i < n_conv ? kernels[i] : 1; cg.s[i] = i < n_conv ? strides[i] : 1; }
+  hipLaunchKernelGGL(hubert_valid_frames_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, valid_samples, B, L, n_conv,
+                     cg, (int*)nullptr, (int*)nullptr, lens);
   return check_launch("hubert_valid_frames");
 }
 

@@ -257,7 +257,7 @@ class _HipModule:
 class HipHubertModel(_HipModule):
     _destroy = "mer_hubert_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mean"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -461,7 +461,7 @@ HipWavLMModel = HipHubertModel
 class HipCLIPModel(_HipModule):
     _destroy = "mer_vit_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mean"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -545,7 +545,7 @@ class HipDinov2Model(_HipModule):
     vectors are folded into the attention-output / fc2 weights and biases (y = x + lambda * (h W^T + b) == x + h (lambda*W)^T
     + lambda*b), so the blocks are the plain pre-LN blocks of the ViT engine.  dinov2-giant's SwiGLU feed-forward is supported (`use_swiglu_ffn`)."""
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx", input_size=224):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mean", input_size=224):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -655,7 +655,7 @@ class HipData2VecVisionModel(HipDinov2Model):
     table and/or the shared one, expanded to [H, T, ceil4(T)] and baked into each layer (`mer_tf_layer.attn_bias`), added to
     the scores by mer_attention_bias.  Native resolution only (config.image_size)."""
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mean"):
         _HipModule.__init__(self)
         sd = _sd_of(state_dict)
         self.config = config
@@ -750,7 +750,7 @@ class HipVideoMAEModel(_HipModule):
     """`model(inputs).last_hidden_state` of extract_vision_huggingface.py:155 (VideoMAE branch)."""
     _destroy = "mer_videomae_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mean"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config
@@ -842,7 +842,7 @@ class HipBertModel(_HipModule):
     Not covered: DeBERTa (disentangled attention), XLNet / T5 / MPNet (relative attention), the decoder-only LLMs."""
     _destroy = "mer_bert_destroy"
 
-    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mx"):
+    def __init__(self, state_dict, config, device="cuda:0", dtype="f16", precision="mean"):
         super().__init__()
         sd = _sd_of(state_dict)
         self.config = config

@@ -63,7 +63,7 @@ def save_feature(csv_file, feature, feature_level):
     np.save(csv_file, feature)
 
 
-def load_model(model_name, gpu, precision="mx"):
+def load_model(model_name, gpu, precision="mean"):
     """AutoModel checkpoint under config.PATH_TO_PRETRAINED_MODELS/transformers/<model_name> -> HIP encoder."""
     from transformers import AutoModel, Wav2Vec2FeatureExtractor
     from .. import config
@@ -184,14 +184,16 @@ def plan_batches(pending, batch_rows, ragged, final, max_stretch=1.5, keep_at_mo
 
 
 def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
-            reader=read_audio, device_preprocess=False, workers=0, rank=None, world=None, window=256, ragged=True):
+            reader=read_audio, device_preprocess=False, workers=0, rank=None, world=None, window=256, ragged=True, async_save=True):
     """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy.
     workers: threads that read and normalise the clips ahead of the batching loop (extract.prefetch; 0 = in line).
     rank / world: this process's share of `audio_files` (distributed.shard: sorted(files)[rank::world]; default = the
     torch.distributed rank / world size, 0 / 1 when not initialised) — clips are independent, no collective.
     window: clips held on the host at most before batches are cut (host memory is O(window), not O(corpus)).
     ragged: batch clips of DIFFERENT lengths together (rows zero-padded to the longest, mer_hubert_forward_ragged makes each
-    clip equal to its batch-of-one forward); False = only clips of identical length share a batch."""
+    clip equal to its batch-of-one forward); False = only clips of identical length share a batch.
+    async_save: features leave the GPU through pinned buffers without blocking this thread and are written by worker threads
+    (extract.pipeline.AsyncWriter; the same bytes reach the same files); False = the reference's blocking copy + in-line np.save."""
     from .prefetch import prefetch_map
     from .. import distributed
     if rank is None:
@@ -226,29 +228,37 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
         chunks = [it['rows'] for it in items]
         valid = None if same else [it['len'] for it in items for _ in range(it['rows'])]
         T = model.out_frames(L)
+        vids = [it['vid'] for it in items]
         if feature_level == 'UTTERANCE':
-            pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid).cpu().numpy()
-            for it, feat in zip(items, pooled):
-                save_feature(os.path.join(save_dir, f"{it['vid']}.npy"), feat, feature_level)
+            pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid)
+
+            def save_utt(arr, vids=vids):
+                for vid, feat in zip(vids, arr):
+                    save_feature(os.path.join(save_dir, f"{vid}.npy"), feat, feature_level)
+            out.submit(pooled, save_utt)
         else:
             starts, lens = model.clip_segments(L, chunks, valid)
             _, frames, _ = model.forward_raw(rows, frames=True, valid_samples=valid)
-            frames = frames.cpu().numpy()
-            for it, s0, n in zip(items, starts, lens):
-                save_feature(os.path.join(save_dir, f"{it['vid']}.npy"), frames[s0:s0 + n], feature_level)
 
+            def save_frames(arr, vids=vids, starts=starts, lens=lens):
+                for vid, s0, n in zip(vids, starts, lens):
+                    save_feature(os.path.join(save_dir, f"{vid}.npy"), arr[s0:s0 + n], feature_level)
+            out.submit(frames, save_frames)
+
+    from .pipeline import writer
     pending = []
-    for audio_file, iv in prefetch_map(host_stage, audio_files, workers):
-        if device_preprocess:   # GPU work stays on the calling thread
-            iv = split_into_batch_any(device_normalize(iv, do_normalize, model.device))
-        pending.append(dict(vid=os.path.basename(audio_file)[:-4], iv=iv, rows=iv.shape[0], len=iv.shape[1]))
-        if len(pending) >= window:
-            batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=window // 2)
-            for b in batches:
-                flush(b)
-    batches, pending = plan_batches(pending, batch_rows, ragged, final=True)
-    for b in batches:
-        flush(b)
+    with writer(model.device, async_save) as out:
+        for audio_file, iv in prefetch_map(host_stage, audio_files, workers):
+            if device_preprocess:   # GPU work stays on the calling thread
+                iv = split_into_batch_any(device_normalize(iv, do_normalize, model.device))
+            pending.append(dict(vid=os.path.basename(audio_file)[:-4], iv=iv, rows=iv.shape[0], len=iv.shape[1]))
+            if len(pending) >= window:
+                batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=window // 2)
+                for b in batches:
+                    flush(b)
+        batches, pending = plan_batches(pending, batch_rows, ragged, final=True)
+        for b in batches:
+            flush(b)
     print(f'Total time used: {time.time() - start_time:.1f}s.')
 
 

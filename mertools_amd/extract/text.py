@@ -58,7 +58,7 @@ def save_embeddings(csv_file, embeddings, feature_level, feature_dim):
 
 
 def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, punc_case=None, language='chinese',
-                      model_dir=None, model=None, tokenizer=None, batch_size=64, rank=None, world=None):
+                      model_dir=None, model=None, tokenizer=None, batch_size=64, rank=None, world=None, async_save=True):
     import pandas as pd
     print('=' * 30 + f' Extracting "{model_name}" ' + '=' * 30)
     start_time = time.time()
@@ -99,25 +99,34 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
         else:
             save_embeddings(os.path.join(save_dir, f"{row['name']}.npy"), [], feature_level, feature_dim)
     todo.sort(key=lambda it: len(it[1]))
-    for i in range(0, len(todo), batch_size):
-        chunk = todo[i:i + batch_size]
-        T = max(len(ids) for _, ids in chunk)
-        batch = torch.full((len(chunk), T), pad_id, dtype=torch.int64)
-        lens = []
-        for r, (_, ids) in enumerate(chunk):
-            batch[r, :len(ids)] = ids
-            lens.append(len(ids))
-        if feature_level == 'FRAME':
-            _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
-            frames = frames.cpu().numpy().reshape(len(chunk), T, -1)
-            for r, (name, _) in enumerate(chunk):
-                e = lens[r] + end if end is not None else lens[r]
-                save_embeddings(os.path.join(save_dir, f'{name}.npy'), frames[r, start:e], feature_level, feature_dim)
-        else:
-            pooled = model.extract_utterance(batch, lens, start, end).cpu().numpy()
-            for r, (name, _) in enumerate(chunk):
-                n_tok = (lens[r] + (end if end is not None else 0)) - start
-                save_embeddings(os.path.join(save_dir, f'{name}.npy'), pooled[r] if n_tok > 0 else [], feature_level, feature_dim)
+    from .pipeline import writer
+    with writer(model.device, async_save) as out:   # pinned non-blocking D2H + np.save on worker threads (extract.pipeline)
+        for i in range(0, len(todo), batch_size):
+            chunk = todo[i:i + batch_size]
+            T = max(len(ids) for _, ids in chunk)
+            batch = torch.full((len(chunk), T), pad_id, dtype=torch.int64)
+            lens = []
+            for r, (_, ids) in enumerate(chunk):
+                batch[r, :len(ids)] = ids
+                lens.append(len(ids))
+            names = [name for name, _ in chunk]
+            if feature_level == 'FRAME':
+                _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
+
+                def save_frames(arr, names=names, lens=lens, T=T):
+                    arr = arr.reshape(len(names), T, -1)
+                    for r, name in enumerate(names):
+                        e = lens[r] + end if end is not None else lens[r]
+                        save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r, start:e], feature_level, feature_dim)
+                out.submit(frames, save_frames)
+            else:
+                pooled = model.extract_utterance(batch, lens, start, end)
+
+                def save_utt(arr, names=names, lens=lens):
+                    for r, name in enumerate(names):
+                        n_tok = (lens[r] + (end if end is not None else 0)) - start
+                        save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r] if n_tok > 0 else [], feature_level, feature_dim)
+                out.submit(pooled, save_utt)
     print(f'Total {len(df)} files done! Time used ({model_name}): {time.time() - start_time:.1f}s.')
 
 

@@ -72,7 +72,7 @@ def save_embeddings(save_file, embeddings, feature_level, embedding_dim):
 
 
 def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
-            device_preprocess=False, workers=0, rank=None, world=None):
+            device_preprocess=False, workers=0, rank=None, world=None, async_save=True):
     """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video.
     device_preprocess: frames that already have the model's resolution go to the GPU as uint8 (a quarter of the fp32 bytes)
     and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path —
@@ -96,12 +96,15 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             return
         px = torch.cat([p.to(model.device) for _, p in pending], 0)
         counts = [p.shape[0] for _, p in pending]
-        feats = model.get_image_features(px).cpu().numpy()  # [sum(frames), P]
+        feats = model.get_image_features(px)  # [sum(frames), P], on the device
         embedding_dim = max(embedding_dim, feats.shape[-1])
-        r = 0
-        for (vid, _), n in zip(pending, counts):
-            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), feats[r:r + n], feature_level, embedding_dim)
-            r += n
+
+        def save(arr, vids=[vid for vid, _ in pending], counts=counts, dim=embedding_dim):
+            r = 0
+            for vid, n in zip(vids, counts):
+                save_embeddings(os.path.join(save_dir, f'{vid}.npy'), arr[r:r + n], feature_level, dim)
+                r += n
+        out.submit(feats, save)   # async_save: pinned non-blocking D2H + np.save on worker threads (extract.pipeline)
         pending, nframes = [], 0
 
     def host_stage(vid):   # everything that needs no GPU: file read + (PIL) pre-processing
@@ -112,23 +115,25 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             return vid, 'u8', torch.from_numpy(np.ascontiguousarray(frames))
         return vid, 'f32', clip_preprocess(frames, size)
 
-    for vid, kind, px in prefetch_map(host_stage, vids, workers):
-        if kind is None:
-            flush()
-            save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
-            continue
-        if kind == 'u8':
-            from .. import ops
-            px = px.to(model.device)
-            if tuple(px.shape[1:3]) != (size, size):
-                from .resize import resize_crop_u8
-                px = resize_crop_u8(px, size)
-            px = ops.image_normalize_u8(px, CLIP_MEAN, CLIP_STD, bgr=True)
-        if nframes + len(px) > frames_per_batch:
-            flush()
-        pending.append((vid, px))
-        nframes += len(px)
-    flush()
+    from .pipeline import writer
+    with writer(model.device, async_save) as out:
+        for vid, kind, px in prefetch_map(host_stage, vids, workers):
+            if kind is None:
+                flush()
+                save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
+                continue
+            if kind == 'u8':
+                from .. import ops
+                px = px.to(model.device)
+                if tuple(px.shape[1:3]) != (size, size):
+                    from .resize import resize_crop_u8
+                    px = resize_crop_u8(px, size)
+                px = ops.image_normalize_u8(px, CLIP_MEAN, CLIP_STD, bgr=True)
+            if nframes + len(px) > frames_per_batch:
+                flush()
+            pending.append((vid, px))
+            nframes += len(px)
+        flush()
 
 
 

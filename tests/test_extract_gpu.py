@@ -224,3 +224,36 @@ def test_model_on_second_gpu_while_first_is_current():
     assert out.device == torch.device("cuda:1") and torch.cuda.current_device() == 0
     torch.cuda.synchronize(1)
     assert rel_err(out.cpu(), ref)[0] < 3e-4
+
+
+def test_async_save_writes_the_same_bytes(dev, tmp_path):
+    """extract.pipeline.AsyncWriter (pinned non-blocking D2H + np.save on worker threads) against the blocking in-line path:
+    the same files with the same bytes, UTTERANCE and FRAME, audio and visual drivers, many small batches in flight."""
+    from mertools_amd.encoders import HipCLIPModel, HipHubertModel
+    from mertools_amd.extract import audio, visual
+    cfg = W.hubert_config("tiny")
+    ma = HipHubertModel(W.hubert_state_dict(cfg, 1), cfg, device=dev)
+    rng = np.random.RandomState(3)
+    files = []
+    for i in range(23):
+        p = str(tmp_path / f"clip{i}.wav")
+        _write_wav(p, rng.randn(4000 + 137 * i) * 0.1)
+        files.append(p)
+    ccfg = W.clip_config("tiny")
+    mv = HipCLIPModel(W.clip_state_dict(ccfg, 3), ccfg, device=dev)
+    face = tmp_path / "face"
+    vids = []
+    for i in range(11):
+        (face / f"v{i}").mkdir(parents=True)
+        np.save(face / f"v{i}" / f"v{i}.npy", rng.randint(0, 256, (1 + i % 5, 64, 64, 3)).astype(np.uint8))
+        vids.append(f"v{i}")
+    for level in ("UTTERANCE", "FRAME"):
+        for asyn in (False, True):
+            audio.extract("hubert-tiny", files, str(tmp_path / f"a-{level}-{asyn}"), level, 0, model=ma, batch_rows=4, async_save=asyn, workers=2 if asyn else 0)
+            visual.extract(mv, str(face), str(tmp_path / f"v-{level}-{asyn}"), level, vids=vids, frames_per_batch=6, async_save=asyn, device_preprocess=True)
+        for kind in "av":
+            d0, d1 = tmp_path / f"{kind}-{level}-False", tmp_path / f"{kind}-{level}-True"
+            names = sorted(os.listdir(d0))
+            assert names == sorted(os.listdir(d1)) and len(names) == (23 if kind == "a" else 11)
+            for n in names:
+                assert (d0 / n).read_bytes() == (d1 / n).read_bytes(), (kind, level, n)
