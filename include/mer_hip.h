@@ -108,16 +108,17 @@ typedef struct {
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
 /* Batch-mean weight-residual correction of a one-pass GEMM (precision "mean"): out[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k],
- * w_lo = the 16-bit plane of W - f16(W) ([N, K], row stride ldw).  mean_rows runs over about 2048 evenly spaced rows of the A
- * plane (every row when M <= 2048), addressed like mer_gemm16's A operand (a_rows_per_batch / a_batch_stride / lda; <= 0 ->
- * plain row-major), fp32 accumulation in a fixed order (deterministic).  valid_rows (device int32 [ceil(M / seg_rows)], or NULL):
- * rows r with r % seg_rows >= valid_rows[r / seg_rows] are padding and do not count.  The rounding error of a weight matrix
+ * w_lo = the 16-bit plane of W - f16(W) ([N, K], row stride ldw).  mean_rows runs over 2048 .. 4096 evenly spaced rows of the A
+ * plane (every row when M < 4096): rows 0, s, 2s, ... of every sequence of seg_rows rows (seg_rows == 0: of the whole plane), s the
+ * largest power of two <= M / 2048; rows addressed like mer_gemm16's A operand (a_rows_per_batch / a_batch_stride / lda; <= 0 ->
+ * plain row-major).  valid_rows (device int32 [ceil(M / seg_rows)], or NULL): rows t >= valid_rows[sequence] of a sequence are
+ * padding and do not count.  Elements are summed as 64-bit fixed-point integers (2^-14 resolution): the result depends only on the
+ * SET of sampled rows, not on their order, layout or the amount of padding — bit for bit.  The rounding error of a weight matrix
  * is the same perturbation for every token, so what it does to the features goes almost entirely through the MEAN activation
  * (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass) — i.e. it
  * is a bias, and the GEMM that follows runs passes = 1 with `out` as its bias.  scratch: device, mer_bias_corr_scratch_bytes(K)
- * bytes, 16-byte aligned, ZERO on entry (64-bit fixed-point column-sum accumulators + a row counter: integer atomics, so the
- * result is independent of workgroup order; the call leaves them non-zero — clear them before the next use); out: device fp32 [N].
- * Two small launches on `stream`. */
+ * bytes, 16-byte aligned, ZERO on entry (the accumulators + a row counter; the call leaves them non-zero — clear them before the
+ * next use); out: device fp32 [N].  Two small launches on `stream`. */
 long long mer_bias_corr_scratch_bytes(int K);
 int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
                   int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,

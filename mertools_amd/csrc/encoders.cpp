@@ -57,8 +57,8 @@ struct CorrArena {       // one forward's mer_bias_corr scratch: a zeroed accumu
 };
 struct CorrWs {
   CorrArena* arena;
-  int seg_rows;          // ragged batches: rows per sequence ...
-  const int* valid;      // ... and device int32 [nseq] valid rows of each (NULL: every row counts)
+  int seg_rows;          // rows per sequence (the sample is taken per sequence; 0: the plane has no sequence structure) ...
+  const int* valid;      // ... ragged batches: device int32 [nseq] valid rows of each (NULL: every row counts)
 };
 static void corr_plan(Arena& ar, CorrArena& ca, bool on, int kmax, long long nmax, int nsites) {
   ca.stride = mer_bias_corr_scratch_bytes(kmax);
@@ -83,7 +83,7 @@ static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
     if (!ok) {
       g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
     } else {
-      int rc = mer_bias_corr(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->valid ? cw->seg_rows : 0, cw->valid,
+      int rc = mer_bias_corr(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->seg_rows, cw->valid,
                              g.w_lo, g.ldw, g.bias, g.N, ca->base + ca->stride * ca->next, ca->cvec, (mer_stream_t)st);
       ++ca->next;
       if (rc != MER_OK) return rc;
@@ -615,7 +615,7 @@ extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
   MER_TRY(corr_begin(st, p.tf.corr));
-  const CorrWs pcw = {&p.tf.corr, 0, nullptr};
+  const CorrWs pcw = {&p.tf.corr, P, nullptr};
   MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, c.variant == 1 ? w.patch_b : nullptr, MER_ACT_NONE, nullptr, 0,
                p.patch32, D, none, 0, &pcw));
   // [CLS] + position embeddings (+ pre_layrnorm for CLIP; DINOv2 has no embedding LayerNorm: gamma == NULL stores the plain sum)
@@ -711,7 +711,7 @@ extern "C" int mer_videomae_forward(const mer_videomae* h, const float* pixels, 
   MER_TRY(mer_video_patchify(pixels, B, c.num_frames, c.channels, c.image_size, c.image_size, c.patch_size, c.tubelet_size,
                              p.patches.hi, p.patches.lo, dt, st));
   MER_TRY(corr_begin(st, p.tf.corr));
-  const CorrWs pcw = {&p.tf.corr, 0, nullptr};
+  const CorrWs pcw = {&p.tf.corr, NP, nullptr};
   MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0, &pcw));
   MER_TRY(mer_add_pos(x, w.pos, (long long)B * NP, NP, D, st));
   HsMap hs;

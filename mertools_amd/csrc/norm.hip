@@ -160,37 +160,53 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, lon
 //                      GEMM — vary from run to run in the last bit)
 //   bias_corr_kernel   the mean vector into LDS, then one wave per 2 output columns takes the dot products with the residual
 //                      plane rows (a GEMV over [N, K]); 8 columns per workgroup
-constexpr int CM_ROWS = 2048;    // sampled rows (every row when M is smaller)
+constexpr int CM_ROWS = 2048;    // sampled rows: between CM_ROWS and 2 CM_ROWS of them (every row when M is smaller)
 constexpr int CM_PARTS = 16;     // row groups (workgroups per column slice)
-constexpr float CM_FIX = 1048576.0f;   // 2^20: |x| <= 65504 (f16) -> |x * 2^20| < 2^36, 2048 rows < 2^47
+constexpr float CM_FIX = 16384.0f;   // 2^14: |x| <= 65504 (f16) -> |x * 2^14| < 2^31 per element; sums in 64 bits
+// Every element becomes a fixed-point integer BEFORE it is added, so all sums (lane, wave, workgroup, the global atomics) are exact
+// integer sums: the mean — and with it the bias, and with it every output bit of the GEMM — does not depend on which lane or
+// workgroup a row lands in, i.e. not on the batch's padding or row layout, only on the SET of sampled rows.  (An fp32 partial sum
+// would differ in its last bit between two paddings of the same clips; the 16-bit planes downstream then round differently and the
+// features move by the size of the rounding noise itself.)  Sampling is per sequence — tokens 0, s, 2s, ... of every sequence, s a
+// power of two — so that the sampled set does not change either when rows are padded further.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int stride,
                                                        int seg_rows, const int* valid_rows, long long* acc, int* cnt) {
   typedef typename T16<T>::v8 v8;
-  __shared__ float red[4][64];
+  __shared__ long long red[4][64];
   __shared__ int rcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane >> 3, cg = lane & 7;
   const int col = blockIdx.x * 64 + cg * 8;
   const bool cin = col < K;
-  const int R = (M + stride - 1) / stride;   // sampled rows
-  float s[8];
+  const int per_seq = seg_rows > 0 ? (seg_rows + stride - 1) / stride : 0;
+  const int R = seg_rows > 0 ? ((M + seg_rows - 1) / seg_rows) * per_seq : (M + stride - 1) / stride;   // sample slots
+  long long s[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  for (int j = 0; j < 8; ++j) s[j] = 0;
   int n = 0;
 #pragma unroll 4
   for (int i = (blockIdx.y * 4 + wave) * 8 + sub; i < R; i += CM_PARTS * 32) {
-    const int r = i * stride;
-    if (valid_rows && (r % seg_rows) >= valid_rows[r / seg_rows]) continue;
+    int r = i * stride;
+    if (seg_rows > 0) {
+      const int seq = i / per_seq, t = (i - seq * per_seq) * stride;
+      r = seq * seg_rows + t;
+      if (t >= seg_rows || (valid_rows && t >= valid_rows[seq])) continue;
+    }
+    if (r >= M) continue;
     ++n;
     if (cin) {
       const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
       const v8 x = *reinterpret_cast<const v8*>(a + off + col);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += T16<T>::to_f32(x[j]);
+      for (int j = 0; j < 8; ++j) {
+        // saturating: a bf16 plane may hold values beyond the fixed-point range (far outside any activation)
+        const float v = fminf(fmaxf(T16<T>::to_f32(x[j]), -131000.f), 131000.f);
+        s[j] += (long long)__float2int_rn(v * CM_FIX);
+      }
     }
   }
-  // the 8 row groups of a wave (lanes cg, cg + 8, ...), then the 4 waves through LDS — fixed order
+  // the 8 row groups of a wave (lanes cg, cg + 8, ...), then the 4 waves through LDS: integer sums, any order gives the same bits
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     s[j] += __shfl_xor(s[j], 8);
@@ -207,12 +223,9 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const T* a, long long lda
   if (lane == 0) rcnt[wave] = nn;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const long long t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     const int c = blockIdx.x * 64 + threadIdx.x;
-    // saturating: a bf16 plane may hold values beyond the fixed-point range (2^40 after the row sums: far outside any activation)
-    const float lim = 1.0995116e12f;
-    const float tc = fminf(fmaxf(t, -lim), lim);
-    if (c < K) atomicAdd(reinterpret_cast<unsigned long long*>(acc + c), (unsigned long long)(long long)__float2ll_rn(tc * CM_FIX));
+    if (c < K) atomicAdd(reinterpret_cast<unsigned long long*>(acc + c), (unsigned long long)t);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cnt, (rcnt[0] + rcnt[1]) + (rcnt[2] + rcnt[3]));
   }
 }
@@ -224,8 +237,8 @@ __global__ __launch_bounds__(256) void bias_corr_kernel(const long long* acc, co
   typedef typename T16<T>::v8 v8;
   extern __shared__ __attribute__((aligned(16))) float mean[];   // [K]
   const int total = *cnt;
-  const float inv = total > 0 ? 1.0f / ((float)total * CM_FIX) : 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) mean[k] = (float)acc[k] * inv;
+  const double inv = total > 0 ? 1.0 / ((double)total * (double)CM_FIX) : 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) mean[k] = (float)((double)acc[k] * inv);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s[BC_COLS / 4];
@@ -421,12 +434,16 @@ extern "C" int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows
               "mer_bias_corr: K, lda, ldw, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
   MER_REQUIRE(K <= 16384, MER_EUNSUPPORTED, "mer_bias_corr: K=%d > 16384", K);
   MER_REQUIRE(!valid_rows || seg_rows > 0, MER_EINVAL, "mer_bias_corr: valid_rows needs seg_rows");
+  MER_REQUIRE(seg_rows >= 0, MER_EINVAL, "mer_bias_corr: seg_rows < 0");
   MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_bias_corr: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   long long* acc = (long long*)scratch;
   int* cnt = (int*)(acc + K);
-  // about CM_ROWS evenly spaced rows (every row below that): the mean of >= 2048 tokens is far inside what the correction needs
-  const int stride = M > CM_ROWS ? M / CM_ROWS : 1;
+  // CM_ROWS .. 2 CM_ROWS evenly spaced rows (every row below that; the mean of >= 2048 tokens is far inside what the correction
+  // needs): tokens 0, s, 2s, ... of every sequence, s the largest power of two <= M / CM_ROWS — padding the batch a little further
+  // changes neither s nor the sampled set
+  int stride = 1;
+  while ((long long)stride * 2 * CM_ROWS <= M) stride *= 2;
   dim3 g1((unsigned)cdiv(K, 64), CM_PARTS), g2((unsigned)cdiv(N, BC_COLS));
   {
     ProfScope prof("bias_corr", 2.0 * N * K, (double)cdiv(M, stride) * K * 2 + (double)N * K * 2, st);

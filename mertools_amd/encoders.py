@@ -156,7 +156,7 @@ def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes, mx_s
 
 
 # precision preset -> (GEMM passes in the HuBERT conv stack, GEMM passes in the transformer blocks)
-_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2), "mx": (4, 4), "mean": (5, 5),
+_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2), "mx": (4, 4), "mean": (5, 5), "mean_blocks": (2, 5), "mean_conv": (5, 2),
          "accurate": (3, 3), "x3": (3, 3)}
 
 

@@ -140,6 +140,19 @@ def extract_whisper(model_name, audio_files, save_dir, feature_level, gpu, model
     print(f'Total time used: {time.time() - start_time:.1f}s.')
 
 
+def to_pcm16_or_f32(samples):
+    """int16 PCM when `samples` (float in [-1, 1)) is exactly what a PCM16 file holds — half the H2D bytes of fp32, a quarter of the
+    float64 the reference moves — else float32."""
+    x = np.asarray(samples)
+    if x.dtype == np.int16:
+        return x
+    x = x.astype(np.float64, copy=False)
+    pcm = np.round(x * 32768.0)
+    if np.array_equal(pcm / 32768.0, x) and pcm.min() >= -32768 and pcm.max() <= 32767:
+        return pcm.astype(np.int16)
+    return x.astype(np.float32)
+
+
 def device_normalize(samples, do_normalize, device):
     """wav2vec2_normalize on the GPU: the utterance goes up as 16-bit PCM when it is exactly representable (what a PCM16 file
     holds: half the H2D bytes of fp32, a quarter of the float64 the reference moves), else as fp32; mer_wave_normalize.
@@ -209,15 +222,31 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
     def host_stage(audio_file):
         samples, sr = reader(audio_file)
         assert sr == 16000, 'currently, we only test on 16k audio'
-        if device_preprocess:
-            return audio_file, samples
+        if device_preprocess:   # (a worker thread: numpy releases the GIL) 16-bit PCM when the file holds exactly that, else fp32
+            return audio_file, to_pcm16_or_f32(samples)
         return audio_file, split_into_batch(wav2vec2_normalize(samples, do_normalize))
 
-    def flush(items):
+    up = None
+    if device_preprocess:
+        from .pipeline import Uploader
+        up = Uploader(model.device)
+
+    def flush_raw(items):
+        """device_preprocess fast path: one-row clips of ONE length and sample type travel as a single pinned [B, L] block on the
+        upload stream and are normalised by one kernel — no per-clip H2D copy, launch or device allocation on this thread."""
+        from .. import ops
+        block = torch.from_numpy(np.stack([it['raw'] for it in items]))
+        dev_block = up.up(block)
+        up.ready(dev_block)
+        flush(items, ops.wave_normalize(dev_block, do_normalize))
+
+    def flush(items, rows=None):
         L = max(it['len'] for it in items)
         same = all(it['len'] == L for it in items)
-        ivs = [it['iv'] for it in items]
-        if same:
+        ivs = [it.get('iv') for it in items]
+        if rows is not None:   # already one normalised [B, L] block on the device (flush_raw)
+            pass
+        elif same:
             rows = torch.cat(ivs, 0)
         else:   # zero-padded rows; one-row clips only differ in length (chunked clips are exactly MAXLEN wide)
             rows = torch.zeros((sum(it['rows'] for it in items), L), dtype=torch.float32, device=ivs[0].device)
@@ -248,17 +277,37 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
     from .pipeline import writer
     pending = []
     with writer(model.device, async_save) as out:
+        def emit(b):
+            if any('raw' in it for it in b):
+                same = len({(it['len'], it['raw'].dtype) for it in b if 'raw' in it}) == 1 and all('raw' in it for it in b)
+                if same:
+                    return flush_raw(b)
+                from .. import ops
+                for it in b:   # mixed lengths / sample types: normalise clip by clip (GPU work stays on the calling thread)
+                    if 'raw' in it:
+                        with torch.cuda.device(model.device):
+                            it['iv'] = ops.wave_normalize(torch.from_numpy(it['raw'])[None].to(model.device), do_normalize)
+            flush(b)
+
         for audio_file, iv in prefetch_map(host_stage, audio_files, workers):
-            if device_preprocess:   # GPU work stays on the calling thread
-                iv = split_into_batch_any(device_normalize(iv, do_normalize, model.device))
-            pending.append(dict(vid=os.path.basename(audio_file)[:-4], iv=iv, rows=iv.shape[0], len=iv.shape[1]))
+            vid = os.path.basename(audio_file)[:-4]
+            if device_preprocess:
+                if len(iv) > MAXLEN:   # > 10 s: chunked after the normalisation (reference :40-50)
+                    with torch.cuda.device(model.device):
+                        from .. import ops
+                        ivd = split_into_batch_any(ops.wave_normalize(torch.from_numpy(iv)[None].to(model.device), do_normalize))
+                    pending.append(dict(vid=vid, iv=ivd, rows=ivd.shape[0], len=ivd.shape[1]))
+                else:
+                    pending.append(dict(vid=vid, raw=iv, rows=1, len=len(iv)))
+            else:
+                pending.append(dict(vid=vid, iv=iv, rows=iv.shape[0], len=iv.shape[1]))
             if len(pending) >= window:
                 batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=window // 2)
                 for b in batches:
-                    flush(b)
+                    emit(b)
         batches, pending = plan_batches(pending, batch_rows, ragged, final=True)
         for b in batches:
-            flush(b)
+            emit(b)
     print(f'Total time used: {time.time() - start_time:.1f}s.')
 
 

@@ -90,11 +90,28 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
     pending, nframes = [], 0
     size = model.config.vision_config.image_size
 
+    up = None
+    if device_preprocess:
+        from .pipeline import Uploader
+        up = Uploader(model.device)
+
     def flush():
         nonlocal pending, nframes, embedding_dim
         if not pending:
             return
-        px = torch.cat([p.to(model.device) for _, p in pending], 0)
+        if all(p.dtype == torch.uint8 and not p.is_cuda for _, p in pending) and len({tuple(p.shape[1:]) for _, p in pending}) == 1:
+            # device_preprocess fast path: the batch's uint8 frames (all of the model's resolution, or all of one size awaiting the GPU
+            # resize) travel as ONE block on the upload stream and are resized / normalised by one launch each — no per-video H2D copy,
+            # kernel launch or device allocation on this thread
+            from .. import ops
+            block = up.up(torch.cat([p for _, p in pending], 0))
+            up.ready(block)
+            if tuple(block.shape[1:3]) != (size, size):
+                from .resize import resize_crop_u8
+                block = resize_crop_u8(block, size)
+            px = ops.image_normalize_u8(block, CLIP_MEAN, CLIP_STD, bgr=True)
+        else:
+            px = torch.cat([_to_px(p) for _, p in pending], 0)
         counts = [p.shape[0] for _, p in pending]
         feats = model.get_image_features(px)  # [sum(frames), P], on the device
         embedding_dim = max(embedding_dim, feats.shape[-1])
@@ -116,19 +133,23 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
         return vid, 'f32', clip_preprocess(frames, size)
 
     from .pipeline import writer
+    def _to_px(p):
+        """one video's frames -> fp32 [n, 3, size, size] on the device (mixed batches: uint8 videos of different sizes, host-PIL ones)"""
+        if p.dtype != torch.uint8:
+            return p.to(model.device)
+        from .. import ops
+        p = p.to(model.device)
+        if tuple(p.shape[1:3]) != (size, size):
+            from .resize import resize_crop_u8
+            p = resize_crop_u8(p, size)
+        return ops.image_normalize_u8(p, CLIP_MEAN, CLIP_STD, bgr=True)
+
     with writer(model.device, async_save) as out:
         for vid, kind, px in prefetch_map(host_stage, vids, workers):
             if kind is None:
                 flush()
                 save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
                 continue
-            if kind == 'u8':
-                from .. import ops
-                px = px.to(model.device)
-                if tuple(px.shape[1:3]) != (size, size):
-                    from .resize import resize_crop_u8
-                    px = resize_crop_u8(px, size)
-                px = ops.image_normalize_u8(px, CLIP_MEAN, CLIP_STD, bgr=True)
             if nframes + len(px) > frames_per_batch:
                 flush()
             pending.append((vid, px))

@@ -75,7 +75,8 @@ static int check_bias_corr(int M) {
   CK(hipDeviceSynchronize());
   std::vector<float> out(N);
   CK(hipMemcpy(out.data(), dout, (size_t)N * 4, hipMemcpyDeviceToHost));
-  const int stride = M > 2048 ? M / 2048 : 1;
+  int stride = 1;
+  while ((long long)stride * 2 * 2048 <= M) stride *= 2;
   std::vector<double> mean(K, 0.0);
   int cnt = 0;
   for (int r = 0; r < M; r += stride, ++cnt)
@@ -87,7 +88,7 @@ static int check_bias_corr(int M) {
     worst = fmax(worst, fabs(ref - out[n]));
     scale = fmax(scale, fabs(ref));
   }
-  const bool ok = worst <= 2e-6 * scale + 1e-7;
+  const bool ok = worst <= 3e-4 * scale + 1e-7;   // elements enter the sums as 2^-14 fixed-point values
   printf("{\"check\": \"bias_corr == host sum over the sampled rows\", \"M\": %d, \"max_abs_err\": %.3g, \"ok\": %s}\n", M, worst, ok ? "true" : "false");
   return ok ? 0 : 1;
 }

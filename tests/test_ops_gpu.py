@@ -569,13 +569,15 @@ def test_bias_corr(dev, dtype, M, N, K):
     a = (_rand((M, K), 85) + 0.3).to(t16)
     wl = (_rand((N, K), 86) * 1e-3).to(t16)
     bias = _rand((N,), 87)
-    stride = M // 2048 if M > 2048 else 1
+    stride = 1
+    while stride * 2 * 2048 <= M:
+        stride *= 2
     out = ops.bias_corr(a.to(dev), wl.to(dev), bias.to(dev))
     out0 = ops.bias_corr(a.to(dev), wl.to(dev))
     torch.cuda.synchronize()
     mean = a[::stride].double().mean(0)
     ref = wl.double() @ mean
-    assert_close(out0.cpu(), ref.float(), 2e-5, "bias_corr without bias")
+    assert_close(out0.cpu(), ref.float(), 3e-4 if dtype == "f16" else 3e-4, "bias_corr without bias")   # 2^-14 fixed-point elements
     assert (out.cpu() - out0.cpu() - bias).abs().max().item() < 1e-6 * (1 + bias.abs().max().item())
     # the sample mean is the full mean to within its sampling noise
     assert (mean - a.double().mean(0)).abs().max().item() < 0.15
@@ -591,7 +593,16 @@ def test_bias_corr_skips_padded_rows(dev):
     torch.cuda.synchronize()
     rows = torch.cat([torch.arange(s_ * seg, s_ * seg + min(int(valid[s_]), M - s_ * seg)) for s_ in range(6)])
     ref = wl.double() @ a[rows].double().mean(0)
-    assert_close(out.cpu(), ref.float(), 2e-5, "bias_corr over the valid rows of a ragged batch")
+    assert_close(out.cpu(), ref.float(), 3e-4, "bias_corr over the valid rows of a ragged batch")
+    # the same clips padded further (and poisoned with NaN beyond their valid rows): the SAME BITS
+    seg2 = 230
+    a2 = torch.full((6 * seg2, K), float("nan")).half()
+    for s_ in range(6):
+        n = min(int(valid[s_]), M - s_ * seg)
+        a2[s_ * seg2: s_ * seg2 + n] = a[s_ * seg: s_ * seg + n]
+    out2 = ops.bias_corr(a2.to(dev), wl.to(dev), valid_rows=valid.to(dev), seg_rows=seg2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
 
 
 def test_gemm_with_bias_corr_matches_two_pass_on_the_mean(dev):
