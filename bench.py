@@ -543,6 +543,16 @@ def e2e(args, dev):
                 same = same and open(os.path.join(root, d0, f), "rb").read() == open(os.path.join(root, d1, f), "rb").read()
         torch.cuda.synchronize()
 
+        # each driver alone first (its own host + GPU time, nothing competing for the interpreter), then the three together
+        alone = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            for name, fn in (("a", lambda: run_a(wavs, os.path.join(root, "alone_a"))), ("v", lambda: run_v(vids, os.path.join(root, "alone_v"))),
+                             ("t", lambda: run_t(N, os.path.join(root, "alone_t")))):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                alone[name] = time.perf_counter() - t0
         secs = {}
 
         def timed(name, fn):
@@ -565,6 +575,7 @@ def e2e(args, dev):
         nfiles = sum(len(os.listdir(os.path.join(root, d))) for d in ("out_a", "out_v", "out_t/roberta-base-UTT"))
         assert nfiles == 3 * N, f"e2e: {nfiles} feature files for {N} clips x 3 modalities"
         return {"clips": N, "seconds": round(wall, 3), "clips_per_s": round(N / wall, 1), "per_modality_seconds": {k: round(v, 3) for k, v in secs.items()},
+                "per_modality_seconds_alone": {k: round(v, 3) for k, v in alone.items()},
                 "inputs": "PCM16 wav (5 s) + uint8 frame stacks [8,224,224,3] + transcription csv (64 tokens), on /dev/shm", "outputs": f"{nfiles} .npy files (UTT)",
                 "drivers": "extract.audio / visual / text on three host threads: device_preprocess, 8 read-ahead threads, pinned async D2H + worker-thread np.save",
                 "byte_identical_to_sync_path": bool(same)}

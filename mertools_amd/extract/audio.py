@@ -40,18 +40,39 @@ def wav2vec2_normalize(samples, do_normalize=True):
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None]
 
 
+_SF = []   # [soundfile module or None], resolved once (a failing import costs a sys.path scan per call)
+
+
+def read_pcm16(path):
+    """(int16 samples, sample_rate) of a PCM16 WAV without the float64 round trip, or None when the file is something else."""
+    try:
+        with wave.open(path, 'rb') as w:
+            if w.getsampwidth() != 2 or w.getcomptype() != 'NONE':
+                return None
+            raw = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2')
+            if w.getnchannels() > 1:
+                return None   # (the float path keeps the reference's channel handling)
+            return raw, w.getframerate()
+    except (wave.Error, EOFError):
+        return None
+
+
 def read_audio(path):
     """(samples float64 in [-1,1), sample_rate) — soundfile when importable, else stdlib PCM16 WAV."""
-    try:
-        import soundfile as sf
-        return sf.read(path)
-    except ImportError:
-        with wave.open(path, 'rb') as w:
-            assert w.getsampwidth() == 2, 'only PCM16 wav supported without soundfile'
-            raw = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float64) / 32768.0
-            if w.getnchannels() > 1:
-                raw = raw.reshape(-1, w.getnchannels())
-            return raw, w.getframerate()
+    if not _SF:
+        try:
+            import soundfile as sf
+            _SF.append(sf)
+        except ImportError:
+            _SF.append(None)
+    if _SF[0] is not None:
+        return _SF[0].read(path)
+    with wave.open(path, 'rb') as w:
+        assert w.getsampwidth() == 2, 'only PCM16 wav supported without soundfile'
+        raw = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float64) / 32768.0
+        if w.getnchannels() > 1:
+            raw = raw.reshape(-1, w.getnchannels())
+        return raw, w.getframerate()
 
 
 def save_feature(csv_file, feature, feature_level):
@@ -220,6 +241,11 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
     os.makedirs(save_dir, exist_ok=True)
 
     def host_stage(audio_file):
+        if device_preprocess and reader is read_audio:   # PCM16 files go up as the 16-bit samples they hold: no float64 round trip
+            got = read_pcm16(audio_file)
+            if got is not None:
+                assert got[1] == 16000, 'currently, we only test on 16k audio'
+                return audio_file, got[0]
         samples, sr = reader(audio_file)
         assert sr == 16000, 'currently, we only test on 16k audio'
         if device_preprocess:   # (a worker thread: numpy releases the GIL) 16-bit PCM when the file holds exactly that, else fp32

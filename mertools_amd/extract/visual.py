@@ -104,7 +104,13 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             # resize) travel as ONE block on the upload stream and are resized / normalised by one launch each — no per-video H2D copy,
             # kernel launch or device allocation on this thread
             from .. import ops
-            block = up.up(torch.cat([p for _, p in pending], 0))
+            n_fr = sum(p.shape[0] for _, p in pending)
+            pin = torch.empty((n_fr,) + tuple(pending[0][1].shape[1:]), dtype=torch.uint8, pin_memory=True)   # (cached by torch's host allocator)
+            r = 0
+            for _, p in pending:   # straight into the pinned staging block: one host copy per frame stack
+                pin[r:r + p.shape[0]].copy_(p)
+                r += p.shape[0]
+            block = up.up(pin)
             up.ready(block)
             if tuple(block.shape[1:3]) != (size, size):
                 from .resize import resize_crop_u8
