@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Aggregates a rocprofv3 SQ counter pass (scripts/pmc_mfma.sh) per kernel: mean per launch of every counter, and
-    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs of the chip)
-i.e. the fraction of the launch's SIMD-cycles in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, summed
-over the chip: 16 per v_mfma_f32_16x16x32_f16; GRBM_GUI_ACTIVE = shader-clock cycles the launch took).  The analytic cross-check
-(MFMA instructions the launch must issue x 16 cycles) is printed next to it for the GEMM kernels."""
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
+i.e. the fraction of the launch's SIMD-cycles in which the matrix pipe was busy.  Calibration on this chip (profiles/r03_pmc_mfma.txt):
+SQ_VALU_MFMA_BUSY_CYCLES = 16 x SQ_INSTS_MFMA exactly for the 16x16x32 f16 kernels (16 cycles per MFMA per SIMD, summed over the chip);
+GRBM_GUI_ACTIVE is summed over the 8 XCDs (divided by 8 and by the launch's duration from the kernel trace it gives a 2.1 GHz shader
+clock under the profiler).  mfma_busy x (that clock / 2.4 GHz) is the achieved fraction of the 2.5 PFLOP/s peak."""
 import csv
 import glob
 import hashlib
@@ -15,6 +16,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 SIMDS = 256 * 4
+XCDS = 8
 agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
@@ -34,7 +36,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE",
     act = mean.get("GRBM_GUI_ACTIVE", 0.0)
     busy = mean.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     out[k] = dict(launches=n, counters_per_launch={c: round(x, 1) for c, x in mean.items()},
-                  mfma_busy=round(busy / (act * SIMDS), 4) if act else None)
+                  mfma_busy=round(busy / (act / XCDS * SIMDS), 4) if act else None)
     print(f"{k[:64]:64s} {n:8d} {out[k]['mfma_busy'] if out[k]['mfma_busy'] is not None else float('nan'):9.4f} {mean.get('SQ_INSTS_MFMA', 0):18.0f} {act:12.0f}")
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mertools_amd", "csrc")
 out["_source_sha"] = hashlib.sha256(open(os.path.join(csrc, "gemm16_impl.h"), "rb").read()).hexdigest()[:16]

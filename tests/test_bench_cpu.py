@@ -15,13 +15,16 @@ def _bench():
 
 
 def test_committed_pmc_collection_matches_the_kernel_source():
-    """Editing csrc/gemm16_impl.h without re-collecting the PMC passes (scripts/r2_final.sh) makes this fail — on purpose: the
-    bench would otherwise print traffic = null on the GPU box."""
+    """Editing csrc/gemm16_impl.h without re-collecting the PMC passes (scripts/pmc_traffic.sh, scripts/pmc_mfma.sh) makes this fail — on
+    purpose: the bench would otherwise print traffic = null / mfma_busy = null on the GPU box."""
     b = _bench()
-    for kernel in ("gemm16", "gemm16_mx"):
-        traffic, detail = b.pmc_traffic(kernel, 5e8)
-        assert traffic is not None and traffic > 1e8, (kernel, detail)
-        assert detail["kernel_source_sha"] == b.kernel_source_sha() and detail["source"].startswith("profiles/")
+    traffic, detail = b.pmc_traffic("gemm16", 5e8)   # (the default preset launches the one-pass kernel only)
+    assert traffic is not None and traffic > 1e8, detail
+    assert detail["kernel_source_sha"] == b.kernel_source_sha() and detail["source"].startswith("profiles/")
+    busy = b.pmc_mfma_busy("gemm16")
+    assert busy is not None and 0.05 < busy["mfma_busy"] < 1.0 and busy["kernel_source_sha"] == b.kernel_source_sha(), busy
+    # the counter calibration the definition rests on: 16 busy cycles per 16x16x32 MFMA
+    assert abs(busy["SQ_VALU_MFMA_BUSY_CYCLES"] / busy["SQ_INSTS_MFMA"] - 16.0) < 0.01
 
 
 def test_stale_pmc_collection_is_refused(tmp_path):
@@ -30,14 +33,14 @@ def test_stale_pmc_collection_is_refused(tmp_path):
     (root / "mertools_amd" / "csrc").mkdir(parents=True)
     (root / "profiles").mkdir()
     shutil.copy(os.path.join(ROOT, "mertools_amd", "csrc", "gemm16_impl.h"), root / "mertools_amd" / "csrc" / "gemm16_impl.h")
-    shutil.copy(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json"), root / "profiles" / "r02_pmc_hbm_traffic.json")
+    shutil.copy(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json"), root / "profiles" / "r03_pmc_hbm_traffic.json")
     assert b.pmc_traffic("gemm16", 5e8, root=str(root))[0] is not None
     with open(root / "mertools_amd" / "csrc" / "gemm16_impl.h", "a") as f:
         f.write("// a kernel edit\n")
     traffic, detail = b.pmc_traffic("gemm16", 5e8, root=str(root))
-    assert traffic is None and "r02_pmc_hbm_traffic.json" in detail["note"] and b.kernel_source_sha(str(root)) in detail["note"]
+    assert traffic is None and "r03_pmc_hbm_traffic.json" in detail["note"] and b.kernel_source_sha(str(root)) in detail["note"]
     # a collection without a stamp (round 1's) is never quoted either
-    d = json.load(open(root / "profiles" / "r02_pmc_hbm_traffic.json"))
+    d = json.load(open(root / "profiles" / "r03_pmc_hbm_traffic.json"))
     d.pop("_source_sha")
-    json.dump(d, open(root / "profiles" / "r03_pmc_hbm_traffic.json", "w"))
+    json.dump(d, open(root / "profiles" / "r04_pmc_hbm_traffic.json", "w"))
     assert b.pmc_traffic("gemm16", 5e8, root=str(root))[0] is None
