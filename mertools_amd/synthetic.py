@@ -409,20 +409,77 @@ def heavy_tailed(sd, sigma=0.7, seed=99):
     return out
 
 
-def ln_outliers(sd, channels=3, lo=30.0, hi=100.0, seed=77):
-    """Copy of a synthetic checkpoint in which `channels` channels of every LayerNorm weight are scaled by 30-100x: what pretrained
-    HuBERT / RoBERTa checkpoints do (a few massive LayerNorm-gamma / residual channels), and what stresses the 16-bit activation
-    planes, the bf8 A operand of the MX correction and the batch-mean correction — weight perturbations (heavy_tailed) do not."""
+def _ln_linear_edges(sd):
+    """[(LayerNorm key prefix, [weight keys of the Linear layers that read its output])] of a HuBERT / wav2vec2 (post- or pre-LN),
+    RoBERTa / BERT or CLIP-vision checkpoint — the edges along which a LayerNorm channel scale can be compensated exactly.
+    LayerNorms whose output is itself a saved feature (the last four hidden states of the post-LN encoders) are left out."""
+    keys, edges = set(sd), []
+    n = lambda fmt: sum(1 for i in range(1000) if fmt.format(i) in keys)   # noqa: E731
+    if "feature_projection.layer_norm.weight" in keys:
+        edges.append(("feature_projection.layer_norm", ["feature_projection.projection.weight"]))
+    L = n("encoder.layers.{}.layer_norm.weight")
+    if L and "encoder.layers.0.attention.q_proj.weight" in keys:   # HuBERT / wav2vec2 / WavLM
+        qkv = lambda i: [f"encoder.layers.{i}.attention.{p}_proj.weight" for p in "qkv"]   # noqa: E731
+        ffn = lambda i: [f"encoder.layers.{i}.feed_forward.intermediate_dense.weight"]   # noqa: E731
+        stable = any(k.startswith("feature_extractor.conv_layers.1.layer_norm") for k in keys)   # the "layer"-norm front end comes with pre-LN blocks
+        if stable:
+            edges += [(f"encoder.layers.{i}.layer_norm", qkv(i)) for i in range(L)] + [(f"encoder.layers.{i}.final_layer_norm", ffn(i)) for i in range(L)]
+        else:
+            edges.append(("encoder.layer_norm", qkv(0)))
+            edges += [(f"encoder.layers.{i}.layer_norm", ffn(i)) for i in range(L)]
+            edges += [(f"encoder.layers.{i}.final_layer_norm", qkv(i + 1)) for i in range(L - 4)]
+    L = n("encoder.layer.{}.output.LayerNorm.weight")
+    if L:   # BERT / RoBERTa (post-LN)
+        qkv = lambda i: [f"encoder.layer.{i}.attention.self.{p}.weight" for p in ("query", "key", "value")]   # noqa: E731
+        edges.append(("embeddings.LayerNorm", qkv(0)))
+        edges += [(f"encoder.layer.{i}.attention.output.LayerNorm", [f"encoder.layer.{i}.intermediate.dense.weight"]) for i in range(L)]
+        edges += [(f"encoder.layer.{i}.output.LayerNorm", qkv(i + 1)) for i in range(L - 4)]
+    L = n("vision_model.encoder.layers.{}.layer_norm1.weight")
+    for i in range(L):   # CLIP vision tower (pre-LN): every block LayerNorm feeds Linear layers only
+        pre = f"vision_model.encoder.layers.{i}."
+        edges.append((pre + "layer_norm1", [pre + f"self_attn.{p}_proj.weight" for p in "qkv"]))
+        edges.append((pre + "layer_norm2", [pre + "mlp.fc1.weight"]))
+    return [(ln, cons) for ln, cons in edges if ln + ".weight" in keys and all(c in keys for c in cons)]
+
+
+def ln_outliers(sd, channels=3, lo=30.0, hi=100.0, seed=77, compensate=True):
+    """Copy of a synthetic checkpoint with ACTIVATION outliers: `channels` channels of the block LayerNorms' affine parameters (gamma
+    and beta: the same channels everywhere, as in pretrained checkpoints) are scaled by 30-100x, and — compensate=True — the
+    matching input columns of the Linear layers that read the LayerNorm are divided by the same factor.  What pretrained HuBERT /
+    RoBERTa checkpoints look like to the kernels: a few massive channels in the 16-bit activation planes against tiny weight columns
+    (the rounding residual of those columns is what the MX block scales and the batch-mean correction have to get right), with the
+    Linear outputs — the attention logits among them — of the unperturbed network; in the post-LN encoders the outlier channels also
+    ride the residual stream into the next LayerNorm, as massive activations do.  compensate=False scales gamma only: the attention
+    logits then grow by the square of the factor and the softmax turns into an arg-max that no 16-bit Q / K plane can reproduce —
+    a different (ill-conditioned) network rather than an outlier test; kept for the record (scratch measurements in DESIGN.md §4)."""
     g = _g(seed)
-    out, chosen = {}, {}
-    for k, v in sd.items():
-        if v.dim() == 1 and k.endswith("weight") and ("layer_norm" in k.lower() or "layernorm" in k.lower() or k.endswith("LayerNorm.weight")):
-            v = v.clone()
-            if v.numel() not in chosen:   # the same channels in every LayerNorm of a width, as in pretrained checkpoints
-                chosen[v.numel()] = (torch.randperm(v.numel(), generator=g)[:channels], lo + (hi - lo) * torch.rand(channels, generator=g))
-            idx, f = chosen[v.numel()]
-            v[idx] = v[idx] * f
-        out[k] = v
+    out = dict(sd)
+    chosen = {}
+
+    def pick(numel):
+        if numel not in chosen:   # the same channels in every LayerNorm of a width
+            chosen[numel] = (torch.randperm(numel, generator=g)[:channels], lo + (hi - lo) * torch.rand(channels, generator=g))
+        return chosen[numel]
+
+    if not compensate:
+        for k, v in sd.items():
+            if v.dim() == 1 and k.endswith("weight") and ("layer_norm" in k.lower() or "layernorm" in k.lower() or k.endswith("LayerNorm.weight")):
+                idx, f = pick(v.numel())
+                v = v.clone()
+                v[idx] = v[idx] * f
+                out[k] = v
+        return out
+    for ln, consumers in _ln_linear_edges(sd):
+        idx, f = pick(sd[ln + ".weight"].numel())
+        for suffix in (".weight", ".bias"):
+            if ln + suffix in out:
+                v = out[ln + suffix].clone()
+                v[idx] = v[idx] * f
+                out[ln + suffix] = v
+        for c in consumers:
+            w = out[c].clone()
+            w[:, idx] = w[:, idx] / f
+            out[c] = w
     return out
 
 
