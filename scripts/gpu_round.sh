@@ -8,7 +8,7 @@ O=gpurun_out/$tag; mkdir -p "$O"
 export TMPDIR=/tmp
 timeout 60 scripts/probes/abi_selftest.bin > "$O/abi_selftest.jsonl" 2>&1; echo "abi rc=$?"
 timeout 1500 python -m pytest tests -m gpu -q -s --no-header -p no:cacheprovider > "$O/suite.log" 2>&1; echo "suite rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" "$O/suite.log" | tail -6
-grep -E "^\.?[a-z0-9A-Z/ -]+(\[|:).*(utt|frames?)=" "$O/suite.log" > "$O/parity_lines.txt"
+grep -E "(utt|frames?)=" "$O/suite.log" | grep -v "print(" > "$O/parity_lines.txt"
 timeout 900 python bench.py --steps 20 --warmup 5 --e2e 512 > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
 timeout 200 python bench.py --steps 20 --warmup 5 --modalities a --batch 32 --no-cpu-baseline --no-sustained > "$O/bench_audio_b32.json" 2>> "$O/bench.err"; echo "audio rc=$?"
 timeout 200 python bench.py --steps 20 --warmup 5 --modalities a --no-cpu-baseline --no-sustained > "$O/bench_audio_b64.json" 2>> "$O/bench.err"; echo "audio64 rc=$?"
