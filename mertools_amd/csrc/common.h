@@ -67,10 +67,11 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 
 // GELU(x) = x Phi(x) = max(x, 0) - |x| T(|x|) with T(a) = erfc(a / sqrt 2) / 2 = exp2(Q(a)): Q is a degree-6 polynomial fitted
-// on [0, 5.5] under the weight a T(a) (the error as it appears in the GELU value; past 5.5 |x| T(|x|) < 1.1e-7 and the clamp
-// keeps it there).  |result - exact| <= 2.6e-7 absolute in fp32 arithmetic (the erf route above: 1.5e-7 on erf) for
-// min + 6 FMA + v_exp_f32 + max + FMA, against ~15 VALU + v_rcp_f32 + v_exp_f32: the activation is the largest single VALU
-// cost of the fc1 / conv GEMM epilogues.
+// on [0, 5.5] under the weight a T(a) (the error as it appears in the GELU value).  Past 5.5 both the polynomial argument AND the
+// factor in front of it are clamped: the tail term is then the constant 5.5 T(5.5) = 1.0e-7 instead of growing with |x| (the
+// unclamped factor gave -|x| 1.9e-8, e.g. 2.3e-7 at x = -12 and more for the large conv pre-activations).  |result - exact| <= 5e-7
+// absolute in fp32 arithmetic for min + 6 FMA + v_exp_f32 + max + FMA, against ~15 VALU + v_rcp_f32 + v_exp_f32 for the erf route:
+// the activation is the largest single VALU cost of the fc1 / conv GEMM epilogues.
 __device__ __forceinline__ float gelu_exp2poly(float x) {
   const float a = fminf(fabsf(x), 5.5f);
   float q = 3.589585917e-05f;
@@ -80,7 +81,7 @@ __device__ __forceinline__ float gelu_exp2poly(float x) {
   q = fmaf(q, a, -4.586574375e-01f);
   q = fmaf(q, a, -1.151242835e+00f);
   q = fmaf(q, a, -9.999880846e-01f);
-  return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+  return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
 
 __device__ __forceinline__ float act_apply(float x, int act) {

@@ -352,18 +352,24 @@ namespace mer {
 // workgroups of layernorm_rows_kernel<T, NV> that fit the device at once (occupancy x CUs), cached per instantiation
 template <typename T, int NV>
 static int ln_rows_grid_nv() {
-  static int grid = 0;
-  if (grid == 0) {
-    int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+  // per device (a process may drive several GPUs: the 2-GPU device test, config4); a benign race at first use computes the same value twice
+  static int grid[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (grid[dev] == 0) {
+    int cus = 0, per = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, layernorm_rows_kernel<T, NV>, 256, 0) != hipSuccess || cus * per <= 0) {
       (void)hipGetLastError();
-      grid = -1;   // fall back to the one-row kernel
+      grid[dev] = -1;   // fall back to the one-row kernel
     } else {
-      grid = cus * per;
+      grid[dev] = cus * per;
     }
   }
-  return grid;
+  return grid[dev];
 }
 template <typename T>
 static int ln_rows_grid(int nv) {

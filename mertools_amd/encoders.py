@@ -205,25 +205,33 @@ class _HipModule:
     def _ints(self, values):
         """Device int32 copy of a small host list (segment tables, sequence lengths), cached by content: a pageable H2D copy
         blocks the host until the current stream has drained, which would stop the host from queueing the next batch while
-        this one runs — and the drivers / bench pass the same tables batch after batch."""
+        this one runs — and the drivers / bench pass the same tables batch after batch.  The first copy of a key is a pinned
+        non-blocking copy on the stream that is current; an event recorded behind it is what every LATER user of the cached table —
+        possibly on another stream (bench --split, the per-modality streams) — waits for before its kernels read the table."""
         key = tuple(int(v) for v in values)
         cache = self.__dict__.setdefault("_int_cache", {})
-        t = cache.get(key)
-        if t is None:
-            if len(cache) >= 256:
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 256:   # (entries other streams may still be reading stay alive through their tensors' references in flight)
                 cache.clear()
+                self.__dict__.get("_int_pins", {}).clear()
             host = torch.tensor(key, dtype=torch.int32)
             if self.device.type == "cuda":   # pinned staging + async copy: a table that changes every batch (ragged audio) must not stall the host either
                 host = host.pin_memory()
                 t = host.to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
                 self.__dict__.setdefault("_int_pins", {})[key] = host   # alive as long as the cached device copy
-                if len(self._int_pins) > 256:
-                    for k in list(self._int_pins):
-                        if k not in cache and k != key:
-                            del self._int_pins[k]
+                cache[key] = (t, ev, torch.cuda.current_stream(self.device).cuda_stream)
             else:
                 t = host
-            cache[key] = t
+                cache[key] = (t, None, None)
+            return t
+        t, ev, st = hit
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != st and not ev.query():
+                cur.wait_event(ev)
         return t
 
     def _seg(self, seg_start, seg_len):
