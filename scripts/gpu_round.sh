@@ -9,11 +9,11 @@ export TMPDIR=/tmp
 timeout 60 scripts/probes/abi_selftest.bin > "$O/abi_selftest.jsonl" 2>&1; echo "abi rc=$?"
 timeout 1500 python -m pytest tests -m gpu -q -s --no-header -p no:cacheprovider > "$O/suite.log" 2>&1; echo "suite rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" "$O/suite.log" | tail -6
 grep -E "(utt|frames?)=" "$O/suite.log" | grep -v "print(" > "$O/parity_lines.txt"
-timeout 900 python bench.py --steps 20 --warmup 5 --e2e 512 > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
-timeout 200 python bench.py --steps 20 --warmup 5 --modalities a --batch 32 --no-cpu-baseline --no-sustained > "$O/bench_audio_b32.json" 2>> "$O/bench.err"; echo "audio rc=$?"
-timeout 200 python bench.py --steps 20 --warmup 5 --modalities a --no-cpu-baseline --no-sustained > "$O/bench_audio_b64.json" 2>> "$O/bench.err"; echo "audio64 rc=$?"
-timeout 200 python bench.py --steps 20 --warmup 5 --modalities v --no-cpu-baseline --no-sustained > "$O/bench_visual_b64.json" 2>> "$O/bench.err"; echo "visual rc=$?"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$O/prof" -o step -- python "$OLDPWD/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-roofline --no-large --no-sustained --streams 0 > /dev/null 2>&1; echo "prof rc=$?")
+timeout 900 python bench.py --steps 20 --warmup 5 > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
+timeout 200 python bench.py --steps 20 --warmup 5 --modalities a --batch 32 --no-cpu-baseline --no-sustained --e2e 0 > "$O/bench_audio_b32.json" 2>> "$O/bench.err"; echo "audio rc=$?"
+timeout 200 python bench.py --steps 20 --warmup 5 --modalities a --no-cpu-baseline --no-sustained --e2e 0 > "$O/bench_audio_b64.json" 2>> "$O/bench.err"; echo "audio64 rc=$?"
+timeout 200 python bench.py --steps 20 --warmup 5 --modalities v --no-cpu-baseline --no-sustained --e2e 0 > "$O/bench_visual_b64.json" 2>> "$O/bench.err"; echo "visual rc=$?"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$O/prof" -o step -- python "$OLDPWD/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-roofline --no-large --no-sustained --e2e 0 --streams 0 > /dev/null 2>&1; echo "prof rc=$?")
 f=$(find "$O/prof" -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && cp "$f" "$O/kernel_stats.csv"; rm -rf "$O/prof"
 timeout 200 scripts/probes/gemm16_bench.bin 20 20 all > "$O/gemm16_bench.jsonl" 2>&1; echo "gemm16_bench rc=$?"
 python - "$O" <<'P'

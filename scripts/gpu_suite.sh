@@ -25,7 +25,7 @@ if [[ $what == bench || $what == all ]]; then
 fi
 if [[ $what == prof || $what == all ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-large --no-sustained --no-parity --streams 0 > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?" | tee -a "$OLDPWD/gpurun_out/suite.log")
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-large --no-sustained --no-parity --e2e 0 --streams 0 > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?" | tee -a "$OLDPWD/gpurun_out/suite.log")
   find gpurun_out/prof -name "*kernel_stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && head -30 "$f"
   # keep only the small summaries
   find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete

@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   d=$R/gpurun_out/pmc/$c
   rm -rf "$d"
   (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o pmc -- \
-     python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-large --no-sustained --no-parity > "$R/gpurun_out/pmc/$c.log" 2>&1; echo "$c rc=$?")
+     python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-large --no-sustained --no-parity --e2e 0 > "$R/gpurun_out/pmc/$c.log" 2>&1; echo "$c rc=$?")
   ls "$d" | head
 done
 python scripts/pmc_summarize.py gpurun_out/pmc | tee gpurun_out/pmc/summary.txt
