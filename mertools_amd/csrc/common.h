@@ -67,11 +67,15 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 
 // GELU(x) = x Phi(x) = max(x, 0) - |x| T(|x|) with T(a) = erfc(a / sqrt 2) / 2 = exp2(Q(a)): Q is a degree-6 polynomial fitted
-// on [0, 5.5] under the weight a T(a) (the error as it appears in the GELU value).  Past 5.5 both the polynomial argument AND the
-// factor in front of it are clamped: the tail term is then the constant 5.5 T(5.5) = 1.0e-7 instead of growing with |x| (the
-// unclamped factor gave -|x| 1.9e-8, e.g. 2.3e-7 at x = -12 and more for the large conv pre-activations).  |result - exact| <= 5e-7
-// absolute in fp32 arithmetic for min + 6 FMA + v_exp_f32 + max + FMA, against ~15 VALU + v_rcp_f32 + v_exp_f32 for the erf route:
-// the activation is the largest single VALU cost of the fc1 / conv GEMM epilogues.
+// on [0, 5.5] under the weight a T(a) (the error as it appears in the GELU value); past 5.5 the polynomial ARGUMENT is clamped, the
+// factor |x| in front is not, so the tail term is |x| T(5.5) = 1.9e-8 |x| instead of ~0.  |result - exact| <= 5e-7 absolute in fp32
+// arithmetic for |x| <= 12 (4.8e-7 at x = 4.1, 2.3e-7 at x = -12), growing as 1.9e-8 |x| beyond (1.9e-6 at |x| = 100: below half an
+// ulp of any 16-bit output of that magnitude's neighbourhood, and 2e-8 relative to a pre-activation that large).
+// Cost: min + 6 FMA + v_exp_f32 + max + FMA, against ~15 VALU + v_rcp_f32 + v_exp_f32 for the erf route — the activation is the
+// largest single VALU cost of the fc1 / conv GEMM epilogues.
+// Do not "tidy" the last line into fmaf(-a, ...): tried in round 3 — the inlined copies of the epilogues then disagree in the last fp32
+// bit (36 of 776 k f16 outputs differ between the packed and the generic epilogue), which also breaks the bit-equality of a row's
+// result under a different position in its tile (padding invariance of the batch: tests/test_encoders_gpu.py::test_hubert_ragged_batch).
 __device__ __forceinline__ float gelu_exp2poly(float x) {
   const float a = fminf(fabsf(x), 5.5f);
   float q = 3.589585917e-05f;
@@ -81,7 +85,7 @@ __device__ __forceinline__ float gelu_exp2poly(float x) {
   q = fmaf(q, a, -4.586574375e-01f);
   q = fmaf(q, a, -1.151242835e+00f);
   q = fmaf(q, a, -9.999880846e-01f);
-  return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+  return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
 
 __device__ __forceinline__ float act_apply(float x, int act) {
