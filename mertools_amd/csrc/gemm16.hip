@@ -183,8 +183,16 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;
-  // 256x256 (8 waves, staggered schedule) wins whenever there are enough rows; narrow / short problems keep 4-wave tiles
-  if (tile == 0) tile = (a->N <= 64) ? 2 : ((a->M >= 1024 && a->N >= 192) ? 3 : 1);
+  // 256x256 (8 waves, staggered schedule) wins whenever there are enough tiles to occupy the chip; narrow / short problems keep
+  // 4-wave tiles: N <= 64 -> 128x64; fewer than 1024 rows, or a narrow output (N <= 1024) that makes at most 96 tiles of 256x256
+  // (RoBERTa's attention-output / fc2 GEMMs at 64 clips, HuBERT's at 32: 48 / 96 tiles on 256 CUs) -> 128x128, four times the
+  // workgroups (measured, profiles/r03_gemm16_bench_tile1_short_m.txt: 27.9 -> 17.9 us, 67.4 -> 46.8 us, 30.7 -> 24.0 us,
+  // 72.2 -> 60.5 us; the wide QKV / fc1 launches and anything with 144+ tiles are faster on 256x256).  The MX preset keeps its kernel.
+  if (tile == 0) {
+    const long long t256 = cdiv(a->M, 256) * cdiv(a->N, 256);
+    const bool few_narrow = t256 <= 96 && a->N <= 1024 && a->passes != 4;
+    tile = (a->N <= 64) ? 2 : ((a->M >= 1024 && a->N >= 192 && !few_narrow) ? 3 : 1);
+  }
   hipStream_t st = (hipStream_t)stream;
   int passes = a->passes;
   if (passes == 4) {

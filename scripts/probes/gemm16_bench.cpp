@@ -1,7 +1,7 @@
 // gemm16_bench.cpp — times the REAL mer_gemm16 kernels through the C ABI of libmer_hip.so, without Python or torch, so that one
 // GPU-box call costs ~15 s instead of ~45 s (no interpreter / torch import): the tool for A/B-ing kernel changes next round.
 //
-//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | roberta | all;   MER_TILE=3|4 forces a tile class
+//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | roberta | hubert32 | all;   MER_TILE=3|4 forces a tile class
 //
 // For every (shape, epilogue) of the bench's block GEMMs it runs pre-blocked W (mer_w_block_pack) with hot operands (one set of planes,
 // re-launched) and with cold ones (four rotating A / output plane sets).  Operands are pseudo-random f16 values: constant-filled planes
@@ -175,9 +175,18 @@ int main(int argc, char** argv) {
       {"roberta fc1 (gelu)", Mr, 3072, 768, 1, MER_ACT_GELU, false, false, true},
       {"roberta fc2 (residual, fp32 out)", Mr, 768, 3072, 1, MER_ACT_NONE, true, true, false},
   };
+  // HuBERT-base at BASELINE configs[1]'s batch 32: 32 x 249 rows (32 row tiles of 256)
+  const int Mh2 = 7968;
+  const Shape hubert32[] = {
+      {"hubert b32 QKV", Mh2, 2304, 768, 1, MER_ACT_NONE, false, false, true},
+      {"hubert b32 out-proj (residual, fp32 out)", Mh2, 768, 768, 1, MER_ACT_NONE, true, true, false},
+      {"hubert b32 fc1 (gelu)", Mh2, 3072, 768, 1, MER_ACT_GELU, false, false, true},
+      {"hubert b32 fc2 (residual, fp32 out)", Mh2, 768, 3072, 1, MER_ACT_NONE, true, true, false},
+  };
   const bool all = !strcmp(set, "all");
   if (all || !strcmp(set, "clip")) for (const Shape& s : clip) run_shape(s, warm, reps);
   if (all || !strcmp(set, "hubert")) for (const Shape& s : hubert) run_shape(s, warm, reps);
   if (all || !strcmp(set, "roberta")) for (const Shape& s : roberta) run_shape(s, warm, reps);
+  if (all || !strcmp(set, "hubert32")) for (const Shape& s : hubert32) run_shape(s, warm, reps);
   return 0;
 }

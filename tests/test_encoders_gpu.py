@@ -326,6 +326,24 @@ def test_clip_base16_heavy_tailed(dev):
         del m
 
 
+def test_clip_base16_48frames_full_tile_selection(dev):
+    """48 frames = 9456 rows: EVERY block GEMM takes the 256x256 kernel (37 x 3 = 111 tiles for the N = 768 ones: above the 96-tile
+    switch to 128x128), i.e. the bench's kernel selection for the CLIP tower including the fp32 + residual epilogues."""
+    from mertools_amd.encoders import HipCLIPModel
+    from util import rel_err
+    cfg = W.clip_config("base16")
+    sd = W.clip_state_dict(cfg, 0)
+    px = W.synth_frames(48, seed=4325)
+    ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
+    m = HipCLIPModel(sd, cfg, device=dev)
+    out = m.get_image_features(px.to(dev))
+    pooled = m.extract_utterance(px.to(dev), [8] * 6)
+    torch.cuda.synchronize()
+    e, eu = rel_err(out.cpu(), ref)[0], rel_err(pooled.cpu(), ref.view(6, 8, -1).mean(1))[0]
+    print(f"clip-B/16 48 frames [mean]: frames={e:.2e} utt={eu:.2e}")
+    assert eu <= TOL and e <= TOL
+
+
 def test_clip_base32_frames(dev):
     """CLIP-ViT-B/32 (extract_vision_huggingface.py:64-72 model list): 50 tokens per frame -> the short-T attention
     instantiation; 32 frames = 1600 rows so the block GEMMs take the 256x256 kernels."""
