@@ -49,10 +49,9 @@ def read_pcm16(path):
         with wave.open(path, 'rb') as w:
             if w.getsampwidth() != 2 or w.getcomptype() != 'NONE':
                 return None
-            raw = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2')
             if w.getnchannels() > 1:
                 return None   # (the float path keeps the reference's channel handling)
-            return raw, w.getframerate()
+            return np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').copy(), w.getframerate()   # (writable: torch.from_numpy)
     except (wave.Error, EOFError):
         return None
 
@@ -261,7 +260,10 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
         """device_preprocess fast path: one-row clips of ONE length and sample type travel as a single pinned [B, L] block on the
         upload stream and are normalised by one kernel — no per-clip H2D copy, launch or device allocation on this thread."""
         from .. import ops
-        block = torch.from_numpy(np.stack([it['raw'] for it in items]))
+        first = items[0]['raw']
+        block = torch.empty((len(items), len(first)), dtype=torch.from_numpy(first[:1]).dtype, pin_memory=True)   # (cached by torch's host allocator)
+        for i, it in enumerate(items):   # straight into the pinned staging block: one host copy per clip
+            block[i].copy_(torch.from_numpy(it['raw']))
         dev_block = up.up(block)
         up.ready(dev_block)
         flush(items, ops.wave_normalize(dev_block, do_normalize))
@@ -327,7 +329,14 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
                     pending.append(dict(vid=vid, raw=iv, rows=1, len=len(iv)))
             else:
                 pending.append(dict(vid=vid, iv=iv, rows=iv.shape[0], len=iv.shape[1]))
-            if len(pending) >= window:
+            # a full batch of clips of ONE length needs no sorting window: cut it as soon as it exists (a corpus of equal-length
+            # clips would otherwise sit on the host until `window` files have been read, with the GPU idle)
+            same = [it for it in pending if it['len'] == pending[-1]['len'] and it['rows'] == pending[-1]['rows'] and ('raw' in it) == ('raw' in pending[-1])]
+            if sum(it['rows'] for it in same) >= batch_rows:
+                ids = {id(it) for it in same}
+                pending = [it for it in pending if id(it) not in ids]
+                emit(same)
+            elif len(pending) >= window:
                 batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=window // 2)
                 for b in batches:
                     emit(b)

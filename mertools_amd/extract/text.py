@@ -94,7 +94,7 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
     for idx, row in df.iterrows():
         sentence = row['chinese'] if language == 'chinese' else row['english']
         if pd.isna(sentence) == False and len(sentence) > 0:  # noqa: E712 (reference's test)
-            ids = tokenizer(sentence, return_tensors='pt')['input_ids'][0]
+            ids = tokenizer(sentence)['input_ids']   # (a plain list: the per-sentence tensor round trip of return_tensors='pt' is most of the call)
             todo.append((row['name'], ids))
         else:
             save_embeddings(os.path.join(save_dir, f"{row['name']}.npy"), [], feature_level, feature_dim)
@@ -107,7 +107,7 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
             batch = torch.full((len(chunk), T), pad_id, dtype=torch.int64)
             lens = []
             for r, (_, ids) in enumerate(chunk):
-                batch[r, :len(ids)] = ids
+                batch[r, :len(ids)] = torch.as_tensor(ids, dtype=torch.int64)
                 lens.append(len(ids))
             names = [name for name, _ in chunk]
             if feature_level == 'FRAME':
