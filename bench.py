@@ -528,10 +528,10 @@ def e2e(args, dev):
         def run_v(names, out, asyn=True):
             visual.extract(mv, os.path.join(root, "face"), out, "UTTERANCE", vids=names, frames_per_batch=8 * B, device_preprocess=True, workers=8, rank=0, world=1, async_save=asyn)
 
-        def run_t(n, out, asyn=True):
+        def run_t(n, out, asyn=True, tokenizer=None):
             sub = os.path.join(root, f"trans_{n}.csv")
             pd.read_csv(csv).head(n).to_csv(sub, index=False)
-            text.extract_embedding("roberta-base", sub, out, "UTTERANCE", gpu=dev.index or 0, model=mt, tokenizer=tok, batch_size=B, rank=0, world=1, async_save=asyn)
+            text.extract_embedding("roberta-base", sub, out, "UTTERANCE", gpu=dev.index or 0, model=mt, tokenizer=tokenizer or tok, batch_size=B, rank=0, world=1, async_save=asyn)
 
         # warm-up + byte-identity of the asynchronous path: the first 32 clips with and without it
         import contextlib
@@ -572,6 +572,22 @@ def e2e(args, dev):
                 alone[name] = time.perf_counter() - t0
         nfiles = sum(len(os.listdir(os.path.join(root, d))) for d in ("out_a", "out_v", "out_t/roberta-base-UTT"))
         assert nfiles == 3 * N, f"e2e: {nfiles} feature files for {N} clips x 3 modalities"
+        # the text driver again with the Rust tokenizer of the same vocabulary (the reference prescribes use_fast=False; the ids — checked
+        # here — and therefore the files are the same): what the driver does when the host stage is not pure Python
+        fast_t = None
+        try:
+            ftok = tr.BertTokenizerFast(os.path.join(root, "vocab.txt"))
+            if all(ftok(s_)["input_ids"] == tok(s_)["input_ids"] for s_ in sents[:64]):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    run_t(N, os.path.join(root, "out_tf"), tokenizer=ftok)
+                    torch.cuda.synchronize()
+                    fast_t = time.perf_counter() - t0
+                for f in sorted(os.listdir(os.path.join(root, "out_t/roberta-base-UTT")))[:64]:
+                    same = same and open(os.path.join(root, "out_t/roberta-base-UTT", f), "rb").read() == open(os.path.join(root, "out_tf/roberta-base-UTT", f), "rb").read()
+        except Exception:
+            fast_t = None
         # ... and the three drivers on three host threads at once, each on its own HIP stream (one interpreter: they share the GIL)
         secs = {}
 
@@ -599,6 +615,9 @@ def e2e(args, dev):
                 "kernel_only_clips_per_s_same_schedule": round(kern_seq, 1), "frac_of_kernel_only": round(N / seq / kern_seq, 3),
                 "per_modality": {m: {"seconds": round(alone[m], 3), "clips_per_s": round(N / alone[m], 1), "kernel_only_clips_per_s": round(kern[m], 1),
                                      "frac": round(N / alone[m] / kern[m], 3)} for m in "avt"},
+                "with_fast_tokenizer": (None if fast_t is None else {"text_seconds": round(fast_t, 3), "clips_per_s": round(N / (seq - alone["t"] + fast_t), 1),
+                                                                    "frac_of_kernel_only": round(N / (seq - alone["t"] + fast_t) / kern_seq, 3),
+                                                                    "note": "BertTokenizerFast of the same vocabulary: identical ids and identical .npy bytes (checked)"}),
                 "three_threads_at_once": {"seconds": round(wall, 3), "clips_per_s": round(N / wall, 1), "per_modality_seconds": {k: round(v, 3) for k, v in secs.items()}},
                 "inputs": "PCM16 wav (5 s) + uint8 frame stacks [8,224,224,3] + transcription csv (64 tokens), on /dev/shm", "outputs": f"{nfiles} .npy files (UTT)",
                 "drivers": "extract.audio / visual / text: device_preprocess, 8 read-ahead threads, batched pinned uploads on a side stream, pinned async D2H + worker-thread np.save; "
