@@ -262,15 +262,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 
 // QS = 16-query sub-tiles per wave: with QS = 2 every K fragment (ds_read_b128) and every V^T fragment (two transpose reads)
 // pulled out of LDS feeds two MFMAs, and a key block staged through LDS serves 128 queries — half the L2 -> LDS staging
 // traffic and half the LDS reads per FLOP of the QS = 1 form (which staged 401 KB of K / V per head 25 times at T = 1568).
-template <typename T, int QS, bool PF>
+// Staging (round 3): a two-slot LDS ring filled by LDS-DMA (global_load_lds, as the GEMM's loader): the loads of key block i + 1 are
+// issued BEFORE block i is computed and cost no registers (round 2's register prefetch lost a resident wave per SIMD to its 28 VGPRs),
+// and one barrier per key block is left.  A DMA piece is 1 KiB = 8 unpadded 128-byte rows, so bank conflicts are avoided by an XOR
+// of the 16-byte chunk index applied on the SOURCE side: K rows with (row >> 1) & 7 (the ds_read_b128 lane groups of the score
+// MFMAs: the GEMM's analysis), V rows with ((row >> 1) & 3) << 1 (the transpose reads touch chunk PAIRS of rows 4 lg + li / 4).
+// Rows past klen are fetched from the last valid row (the score mask makes their P exactly 0).
+typedef __attribute__((address_space(3))) void attn_lds_t;
+typedef const __attribute__((address_space(1))) void attn_glb_t;
+template <typename T, int QS>
 __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, long long ld, T* oh, T* ol,
                                                           long long ldo, int Tn, float scale_log2e, const int* kv_len, int hm) {
   typedef typename T16<T>::v8 v8;
   typedef typename T16<T>::v4 v4;
-  constexpr int KB = 64, KS = 72;
-  __shared__ __attribute__((aligned(16))) T Ks[KB * KS];
-  __shared__ __attribute__((aligned(16))) T Vs[KB * KS];
+  constexpr int KB = 64, KS = 64;   // unpadded rows: the swizzle replaces the padding
+  __shared__ __attribute__((aligned(1024))) T Ks[2][KB * KS];
+  __shared__ __attribute__((aligned(1024))) T Vs[2][KB * KS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
@@ -301,36 +309,30 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
     m[u] = -INFINITY;
     lsum[u] = 0.f;
   }
-  // register prefetch: the next key block's global loads are issued before this block's MFMAs and land in LDS after them
-  // (KB * 8 = 512 16-byte chunks per operand = 2 per thread and operand), so the L2 round trip overlaps the compute
-  constexpr int PER = KB * 8 / 256;
-  u32x4 kreg[PER], vreg[PER];
-  auto fetch = [&](int k0) __attribute__((always_inline)) {
+  // LDS-DMA of one key block into slot `slot`: 8 pieces of 1 KiB per operand, two per wave; lane l of a piece lands on row
+  // piece * 8 + l / 8, physical chunk l % 8, and fetches the logical chunk that the swizzle maps there
+  const int d_row = lane >> 3, d_pc = lane & 7;
+  auto issue = [&](int k0, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int c = tid + it * 256;
-      const int row = c >> 3, ch = c & 7;
-      kreg[it] = u32x4{0u, 0u, 0u, 0u};
-      vreg[it] = u32x4{0u, 0u, 0u, 0u};
-      if (k0 + row < klen) {
-        kreg[it] = *reinterpret_cast<const u32x4*>(kb + (long long)(k0 + row) * ld + ch * 8);
-        vreg[it] = *reinterpret_cast<const u32x4*>(vb + (long long)(k0 + row) * ld + ch * 8);
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;
+      const int row = piece * 8 + d_row;
+      int kr = k0 + row;
+      kr = kr < klen ? kr : klen - 1;
+      const int kc = d_pc ^ ((row >> 1) & 7), vc = d_pc ^ (((row >> 1) & 3) << 1);
+      __builtin_amdgcn_global_load_lds((attn_glb_t*)(kb + (long long)kr * ld + kc * 8), (attn_lds_t*)(Ks[slot] + piece * 8 * KS), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((attn_glb_t*)(vb + (long long)kr * ld + vc * 8), (attn_lds_t*)(Vs[slot] + piece * 8 * KS), 16, 0, 0);
     }
   };
-  if (PF) fetch(0);
-  for (int k0 = 0; k0 < klen; k0 += KB) {
-    __syncthreads();  // previous block fully consumed
-    if (!PF) fetch(k0);
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int c = tid + it * 256;
-      const int row = c >> 3, ch = c & 7;
-      *reinterpret_cast<u32x4*>(Ks + row * KS + ch * 8) = kreg[it];
-      *reinterpret_cast<u32x4*>(Vs + row * KS + ch * 8) = vreg[it];
-    }
-    __syncthreads();
-    if (PF && k0 + KB < klen) fetch(k0 + KB);
+  if (klen > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int slot = 0;
+  for (int k0 = 0; k0 < klen; k0 += KB, slot ^= 1) {
+    // the other slot's readers all passed the barrier that ended the previous iteration: refill it while this block computes
+    if (k0 + KB < klen) issue(k0 + KB, slot ^ 1);
+    const T* Kc = Ks[slot];
+    const T* Vc = Vs[slot];
     f32x4 s[QS][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -338,12 +340,13 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
       for (int u = 0; u < QS; ++u) s[u][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const v8 kf = *reinterpret_cast<const v8*>(Ks + (kt * 16 + li) * KS + kk * 32 + lg * 8);
+        const int row = kt * 16 + li;
+        const v8 kf = *reinterpret_cast<const v8*>(Kc + row * KS + (((kk * 4 + lg) ^ ((row >> 1) & 7)) << 3));
 #pragma unroll
         for (int u = 0; u < QS; ++u) s[u][kt] = T16<T>::mfma(kf, qf[u][kk], s[u][kt]);
       }
     }
-    // softmax bookkeeping in as few VALU slots as possible (see attn_sp_kernel): raw-score max, one packed FMA per two scores,
+  // softmax bookkeeping in as few VALU slots as possible (see attn_sp_kernel): raw-score max, one packed FMA per two scores,
     // and the key mask only in the last key block (wave-uniform test) — the running max m[] is kept in the RAW domain
     float alpha[QS];
     const bool tail = k0 + KB > klen;
@@ -395,7 +398,9 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
         }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const T* vr = Vs + ((2 * c) * 16 + lg * 4 + (li >> 2)) * KS + dt * 16 + (li & 3) * 4;
+        // row 32 c + 4 lg + li / 4 (and 16 rows further: the same (row >> 1) & 3), logical chunk 2 dt + (li & 3) / 2, half (li & 1)
+        const int vrow = (2 * c) * 16 + lg * 4 + (li >> 2);
+        const T* vr = Vc + vrow * KS + (((dt * 2 + ((li >> 1) & 1)) ^ (((vrow >> 1) & 3) << 1)) << 3) + (li & 1) * 4;
         const v4 v0 = tr_read4<T>(vr);
         const v4 v1 = tr_read4<T>(vr + 16 * KS);
         v8 vf;
@@ -408,6 +413,8 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
         for (int u = 0; u < QS; ++u) o[u][dt] = T16<T>::mfma(vf, pf[u], o[u][dt]);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next block has landed ...
+    __syncthreads();                                      // ... and every wave is done reading the current slot
   }
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
@@ -481,13 +488,13 @@ static int launch_attn(const void* q, const void* k, const void* v, long long ld
   else if (Tn <= 512) MER_ATTN_CASE(32);
   else {
     // QS = 16-query sub-tiles per wave (64 * QS queries per workgroup), PF = register prefetch of the next key block
-#define MER_ATTN_STREAM(QS_, PF_)                                                                                          \
+#define MER_ATTN_STREAM(QS_)                                                                                          \
   do {                                                                                                                     \
     dim3 sgrid((unsigned)cdiv(Tn, 64 * QS_), H, B);                                                                        \
-    hipLaunchKernelGGL((attn_stream_kernel<T, QS_, PF_>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
+    hipLaunchKernelGGL((attn_stream_kernel<T, QS_>), sgrid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, ld, \
                        (T*)oh, (T*)ol, ldo, Tn, sl2, kv_len, hm);                                                          \
   } while (0)
-    MER_ATTN_STREAM(2, false);   // (QS = 1 and the register-prefetch form measured slower: profiles/r02_attention_variants.jsonl)
+    MER_ATTN_STREAM(2);   // (QS = 1 and round 2's register-prefetch form measured slower: profiles/r02_attention_variants.jsonl)
 #undef MER_ATTN_STREAM
   }
 #undef MER_ATTN_CASE
