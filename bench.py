@@ -31,6 +31,11 @@ import os
 import sys
 import time
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  An RCCL process group creates streams of its own, after which
+# the three modality streams share queues and serialise: 32.4 instead of 30.2 ms per step on ONE GPU with a one-rank group and no
+# collective at all (--force-dist; profiles/r03_rccl_hw_queues.txt).  8 queues restore the overlap.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -359,7 +364,7 @@ def measure(args, config, steps, warmup, dev, dist, rank, world, sustain_s=0.0, 
 
     # N > 1: the fusion-minibatch exchange of configs[3] — every rank's [B, Da | Dt | Dv] rows in ONE fused RCCL all-gather
     # (distributed.gather_fusion_batch) on its own stream, so it overlaps the next step's extraction; timed with its own events
-    comm = torch.cuda.Stream(device=dev) if (dist is not None and mods == set("avt")) else None
+    comm = torch.cuda.Stream(device=dev) if (dist is not None and mods == set("avt") and not os.environ.get("MER_BENCH_NO_EXCHANGE")) else None
     ag_events = []
 
     def exchange(out):

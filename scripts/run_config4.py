@@ -10,6 +10,7 @@ Prints one JSON line (rank 0): clips/s of the whole loop (extract + exchange + f
 import argparse
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # RCCL's own streams otherwise crowd the modality streams out of the 4 default hardware queues (bench.py)
 import sys
 import time
 
