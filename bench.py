@@ -266,6 +266,9 @@ def oracle_features(kind, size, x):
         return torch.stack(R.bert_hidden_states(W.bert_state_dict(bc, 0), dict(vars(bc), roberta=True), x, torch.ones_like(x)))[[-4, -3, -2, -1]].sum(0)[:, 1:-1].mean(1)
 
 
+DETAIL = {}   # filled by parity_check: per-modality companions of the max-norm figure (last call)
+
+
 def parity_check(feats, inputs, mods, config="base", nclip=2):
     """Features of the first `nclip` clips of the last timed step (computed inside the full batch, i.e. by the kernels the
     timing selected) against the CPU oracle on the same weights and inputs.  north_star tolerance: 1e-3 (max-norm relative).
@@ -280,7 +283,12 @@ def parity_check(feats, inputs, mods, config="base", nclip=2):
         t0 = time.perf_counter()
         ref = oracle_features(kind, size, inputs[m][:rows].cpu())
         secs[m] = (time.perf_counter() - t0) / nclip
-        out[m] = float((feats[m][:nclip].double().cpu() - ref.double()).abs().max() / ref.double().abs().max())
+        x, r = feats[m][:nclip].double().cpu(), ref.double()
+        out[m] = float((x - r).abs().max() / r.abs().max())
+        # the asserted figure is max-norm relative; two norm-free companions so that small-magnitude dimensions are not invisible:
+        # the worst clip's cosine distance and the RMS error relative to the RMS feature
+        DETAIL[m] = {"one_minus_cosine_max": float(f"{(1.0 - torch.nn.functional.cosine_similarity(x, r, dim=-1)).max().item():.3e}"),
+                     "rms_rel": float(f"{((x - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item():.3e}")}
     return {k: float(f"{v:.3e}") for k, v in out.items()}, secs
 
 
@@ -441,6 +449,7 @@ def measure(args, config, steps, warmup, dev, dist, rank, world, sustain_s=0.0, 
     res["whole_step_tflops"] = gflop_clip * B * world * steps / dt / 1e3
     if rank == 0 and want_parity:
         res["parity"], res["oracle_secs"] = parity_check(feats, inputs, mods, config, nclip=2 if config == "base" else 1)
+        res["parity_detail"] = dict(DETAIL)
 
     if want_roofline:
         lib = _lib.lib()
@@ -681,7 +690,7 @@ def main():
             large = {"workload": CONFIGS["large"]["workload"], "value": round(lr["value"], 2), "unit": "clips/s", "ms_per_step": round(lr["ms_per_step"], 3),
                      "clips_per_gpu_per_step": B, "dtype": args.dtype, "precision": args.precision, "gflop_per_clip": lr["gflop_per_clip"],
                      "whole_step_tflops": round(lr["whole_step_tflops"], 2), "whole_step_frac": round(lr["whole_step_tflops"] / PEAK_F16_TFLOPS, 4),
-                     "parity": lr.get("parity")}
+                     "parity": lr.get("parity"), "parity_detail": lr.get("parity_detail")}
             if lr.get("roofline"):
                 rf = lr["roofline"]
                 large["roofline"] = {k: rf[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "launches", "share_of_gpu_time")}
@@ -704,6 +713,7 @@ def main():
                        "gflop_per_clip": r["gflop_per_clip"]},
             "roofline": r.get("roofline"),
             "parity": parity,
+            "parity_detail": r.get("parity_detail"),
         }
         if "sustained" in r:
             res["sustained"] = r["sustained"]
