@@ -181,7 +181,9 @@ int mer_split16(const float* x, void* hi, void* lo, long long n, int dtype, mer_
 /* HuBERT / wav2vec2 layer-0 feature extractor for feat_extract_norm == "group":
  * Conv1d(1->C, k, stride, no bias) -> GroupNorm(C groups == per-channel over time, eps 1e-5,
  * affine) -> GELU, written channels-last as 16-bit planes [B, T0, C].
- * (HF:hubert/modeling_hubert.py:154-175.)  stats: device scratch of 2*B*C doubles. */
+ * (HF:hubert/modeling_hubert.py:154-175.)  stats: device scratch of 2*B*C doubles (no initialisation needed).
+ * For k <= 10, C % 8 == 0, C >= 65 the statistics come from the clip's input autocorrelation (sum y^2 = w'Rw, fp64) and the
+ * conv is computed once; other shapes take a two-pass kernel. */
 int mer_hubert_conv0_gn(const float* wav, int B, int L, const float* w /*[C,k]*/, int C, int k, int stride,
                         const float* gamma, const float* beta, float eps, double* stats,
                         void* out_hi, void* out_lo, int dtype, mer_stream_t stream);

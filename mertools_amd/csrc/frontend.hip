@@ -73,99 +73,142 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, int L, int
   }
 }
 
-// Fast path (k <= 10, C % 8 == 0): a thread owns 8 CONSECUTIVE channels (80 weights in registers) and every 4th frame of
-// the workgroup's 256-frame chunk, so the apply pass writes one 16-byte store per frame and lane — a wave emits whole
-// 1 KiB channel rows (C = 512) instead of 2-byte scattered stores — and the stats pass needs 8x fewer LDS broadcasts
-// per FMA.  Waves of a workgroup cover the same channels at different frames; their partial sums meet in LDS.
+// Fast path (k <= 10, C % 8 == 0, C >= 65).  The GroupNorm statistics do not need the conv output at all: with
+// S_j = sum_t x[t*stride+j] and R_jj' = sum_t x[t*stride+j] x[t*stride+j'] (10 + 55 numbers per clip),
+// sum_t y_c = w_c . S and sum_t y_c^2 = w_c' R w_c.  conv0_moments_kernel accumulates S and R in fp64 (the products of two
+// fp32 values are exact there, so a high-pass filter on a strongly correlated signal — w'Rw orders of magnitude below
+// |w|^2 tr R — loses nothing), one partial per (clip, chunk) summed in a fixed order: no atomics, bit-reproducible.
+// conv0_affine_kernel turns them into the per-(clip, channel) scale/shift; the apply kernel then computes the conv ONCE.
+// `stats` ([B][2C] doubles) holds per clip: [0, nchunk*65) the partial moments, [C, 2C) the 2C fp32 scale/shift values.
 constexpr int C0_KF = 10;
-template <typename T, bool APPLY>
+constexpr int C0_NM = C0_KF + C0_KF * (C0_KF + 1) / 2;
+constexpr int C0_MCH = 2048;   // frames per moments workgroup (when the stats buffer has room for that many partials)
+
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* wav, int L, int T0, int C, int k, int stride, int nchunk,
+                                                            double* stats, const int* valid) {
+  __shared__ double red[4][C0_NM];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int Tv = valid ? valid[b] : T0;   // ragged batch: statistics over the row's own frames only
+  const int per = (T0 + nchunk - 1) / nchunk;
+  const int tb = ch * per;
+  const int te = (tb + per) < Tv ? (tb + per) : Tv;
+  const float* xb = wav + (long long)b * L;
+  double m[C0_NM];
+#pragma unroll
+  for (int i = 0; i < C0_NM; ++i) m[i] = 0.0;
+  for (int t = tb + (int)threadIdx.x; t < te; t += 256) {
+    double xv[C0_KF];
+#pragma unroll
+    for (int j = 0; j < C0_KF; ++j) xv[j] = j < k ? (double)xb[(long long)t * stride + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < C0_KF; ++j) m[j] += xv[j];
+    int i = C0_KF;
+#pragma unroll
+    for (int j = 0; j < C0_KF; ++j)
+#pragma unroll
+      for (int j2 = j; j2 < C0_KF; ++j2, ++i) m[i] = fma(xv[j], xv[j2], m[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < C0_NM; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m[i] += __shfl_xor(m[i], off);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < C0_NM; ++i) red[wv][i] = m[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < C0_NM)
+    stats[(long long)b * 2 * C + (long long)ch * C0_NM + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void conv0_affine_kernel(const float* w, int C, int k, const float* gamma, const float* beta, float eps,
+                                                           int T0, int nchunk, double* stats, const int* valid) {
+  __shared__ double mo[C0_NM];
+  const int b = blockIdx.x;
+  const double Tv = (double)(valid ? valid[b] : T0);
+  double* sb = stats + (long long)b * 2 * C;
+  if (threadIdx.x < C0_NM) {
+    double a = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) a += sb[ch * C0_NM + threadIdx.x];
+    mo[threadIdx.x] = a;
+  }
+  __syncthreads();
+  float* gb = reinterpret_cast<float*>(sb + C);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double wr[C0_KF];
+#pragma unroll
+    for (int j = 0; j < C0_KF; ++j) wr[j] = j < k ? (double)w[c * k + j] : 0.0;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int j = 0; j < C0_KF; ++j) s = fma(wr[j], mo[j], s);
+    int i = C0_KF;
+#pragma unroll
+    for (int j = 0; j < C0_KF; ++j)
+#pragma unroll
+      for (int j2 = j; j2 < C0_KF; ++j2) {
+        const double ww = wr[j] * wr[j2];
+        q = fma(j2 == j ? ww : 2.0 * ww, mo[i], q);
+        ++i;
+      }
+    const double mean_d = s / Tv;
+    const double var_d = q / Tv - mean_d * mean_d;
+    const float rstd = 1.0f / sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + eps);
+    const float ga = gamma[c] * rstd;
+    gb[c] = ga;
+    gb[C + c] = beta[c] - (float)mean_d * ga;
+  }
+}
+
+// Apply pass: a thread owns 8 CONSECUTIVE channels (80 weights in registers) and every 4th frame of the workgroup's
+// 256-frame chunk, so it writes one 16-byte store per frame and lane — a wave emits whole 1 KiB channel rows (C = 512)
+// instead of 2-byte scattered stores.
+template <typename T>
 __global__ __launch_bounds__(256) void conv0_fast_kernel(const float* wav, int L, int T0, const float* w, int C, int k,
-                                                         int stride, const float* gamma, const float* beta, float eps,
-                                                         double* stats, T* ohi, T* olo, const int* valid) {
+                                                         int stride, const double* stats, T* ohi, T* olo) {
   __shared__ float xs[C0_TCH * 8 + C0_KMAX];
-  __shared__ float part[2][4][64 * 8];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * C0_TCH;
   const int nt = (T0 - t0) < C0_TCH ? (T0 - t0) : C0_TCH;
-  const int Tv = valid ? valid[b] : T0;   // ragged batch: statistics over the row's own frames only
-  const int nts = (Tv - t0) < nt ? ((Tv - t0) > 0 ? (Tv - t0) : 0) : nt;
   const int nin = (nt - 1) * stride + k;
   const float* xb = wav + (long long)b * L + (long long)t0 * stride;
   for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[i];
   __syncthreads();
+  const float* gb = reinterpret_cast<const float*>(stats + (long long)b * 2 * C + C);
   const int lane = threadIdx.x & 63, tq = threadIdx.x >> 6;
-  for (int cb = 0; cb < C; cb += 512) {   // uniform trip count: the loop body contains workgroup barriers
-    const int c0 = cb + lane * 8;
-    const bool on = c0 < C;               // C % 8 == 0: a lane's 8 channels are all in or all out
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {   // C % 8 == 0: a lane's 8 channels are all in or all out
     float wr[8][C0_KF];
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int j = 0; j < C0_KF; ++j) wr[c][j] = (on && j < k) ? w[(c0 + c) * k + j] : 0.f;
-    if (!APPLY) {
-      float s[8], q[8];
+      for (int j = 0; j < C0_KF; ++j) wr[c][j] = j < k ? w[(c0 + c) * k + j] : 0.f;
+    float ga[8], be[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) s[c] = q[c] = 0.f;
-      for (int t = tq; t < nts; t += 4) {
-        float xv[C0_KF];
+    for (int c = 0; c < 8; ++c) {
+      ga[c] = gb[c0 + c];
+      be[c] = gb[C + c0 + c];
+    }
+    for (int t = tq; t < nt; t += 4) {
+      float xv[C0_KF];
 #pragma unroll
-        for (int j = 0; j < C0_KF; ++j) xv[j] = xs[t * stride + j];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          float y = 0.f;
-#pragma unroll
-          for (int j = 0; j < C0_KF; ++j) y = fmaf(wr[c][j], xv[j], y);
-          s[c] += y;
-          q[c] = fmaf(y, y, q[c]);
-        }
-      }
+      for (int j = 0; j < C0_KF; ++j) xv[j] = xs[t * stride + j];
+      typename T16<T>::v8 h, l;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        part[0][tq][lane * 8 + c] = s[c];
-        part[1][tq][lane * 8 + c] = q[c];
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_KF; ++j) y = fmaf(wr[c][j], xv[j], y);
+        const float z = act_apply(fmaf(y, ga[c], be[c]), MER_ACT_GELU);
+        T hh, ll;
+        split16<T>(z, hh, ll);
+        h[c] = hh;
+        l[c] = ll;
       }
-      __syncthreads();
-      if (tq == 0 && on) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int i = lane * 8 + c;
-          const float ss = (part[0][0][i] + part[0][1][i]) + (part[0][2][i] + part[0][3][i]);
-          const float qq = (part[1][0][i] + part[1][1][i]) + (part[1][2][i] + part[1][3][i]);
-          atomicAdd(&stats[((long long)b * C + c0 + c) * 2 + 0], (double)ss);
-          atomicAdd(&stats[((long long)b * C + c0 + c) * 2 + 1], (double)qq);
-        }
-      }
-      __syncthreads();
-    } else if (on) {
-      float ga[8], be[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double mean_d = stats[((long long)b * C + c0 + c) * 2 + 0] / (double)Tv;
-        const double var_d = stats[((long long)b * C + c0 + c) * 2 + 1] / (double)Tv - mean_d * mean_d;
-        const float rstd = 1.0f / sqrtf((float)(var_d > 0.0 ? var_d : 0.0) + eps);
-        ga[c] = gamma[c0 + c] * rstd;
-        be[c] = beta[c0 + c] - (float)mean_d * ga[c];
-      }
-      for (int t = tq; t < nt; t += 4) {
-        float xv[C0_KF];
-#pragma unroll
-        for (int j = 0; j < C0_KF; ++j) xv[j] = xs[t * stride + j];
-        typename T16<T>::v8 h, l;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          float y = 0.f;
-#pragma unroll
-          for (int j = 0; j < C0_KF; ++j) y = fmaf(wr[c][j], xv[j], y);
-          const float z = act_apply(fmaf(y, ga[c], be[c]), MER_ACT_GELU);
-          T hh, ll;
-          split16<T>(z, hh, ll);
-          h[c] = hh;
-          l[c] = ll;
-        }
-        const long long o = ((long long)b * T0 + t0 + t) * C + c0;
-        *reinterpret_cast<typename T16<T>::v8*>(ohi + o) = h;
-        if (olo) *reinterpret_cast<typename T16<T>::v8*>(olo + o) = l;
-      }
+      const long long o = ((long long)b * T0 + t0 + t) * C + c0;
+      *reinterpret_cast<typename T16<T>::v8*>(ohi + o) = h;
+      if (olo) *reinterpret_cast<typename T16<T>::v8*>(olo + o) = l;
     }
   }
 }
@@ -598,19 +641,24 @@ extern "C" int mer_hubert_conv0_gn_ragged(const float* wav, int B, int L, const 
   MER_REQUIRE(L >= k, MER_ESHAPE, "mer_hubert_conv0_gn: L=%d < k=%d", L, k);
   const int T0 = (L - k) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
+  ProfScope prof("hubert_conv0_gn", 2.0 * (double)B * T0 * C * k, (double)B * L * 4 * 2 + (double)B * T0 * C * (out_lo ? 4 : 2), st);
+  if (k <= C0_KF && C % 8 == 0 && C >= C0_NM) {
+    int nchunk = (int)cdiv(T0, C0_MCH);
+    if (nchunk > C / C0_NM) nchunk = C / C0_NM;
+    hipLaunchKernelGGL(conv0_moments_kernel, dim3((unsigned)nchunk, B), block, 0, st, wav, L, T0, C, k, stride, nchunk, stats, valid_frames);
+    hipLaunchKernelGGL(conv0_affine_kernel, dim3((unsigned)B), block, 0, st, w, C, k, gamma, beta, eps, T0, nchunk, stats, valid_frames);
+    if (dtype == MER_DT_F16)
+      hipLaunchKernelGGL((conv0_fast_kernel<f16>), grid, block, 0, st, wav, L, T0, w, C, k, stride, (const double*)stats, (f16*)out_hi, (f16*)out_lo);
+    else
+      hipLaunchKernelGGL((conv0_fast_kernel<bf16>), grid, block, 0, st, wav, L, T0, w, C, k, stride, (const double*)stats, (bf16*)out_hi, (bf16*)out_lo);
+    return check_launch("hubert_conv0_gn");
+  }
   hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st);
   MER_REQUIRE(e == hipSuccess, MER_ELAUNCH, "mer_hubert_conv0_gn: memset failed: %s", hipGetErrorString(e));
-  dim3 grid((unsigned)cdiv(T0, C0_TCH), B), block(256);
-  ProfScope prof("hubert_conv0_gn", 2.0 * 2 * (double)B * T0 * C * k, (double)B * L * 4 * 2 + (double)B * T0 * C * (out_lo ? 4 : 2), st);
-  const bool fast = k <= C0_KF && C % 8 == 0;
-#define MER_CONV0(K, TT, AP, OH, OL) hipLaunchKernelGGL((K<TT, AP>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats, OH, OL, valid_frames)
-  if (dtype == MER_DT_F16) {
-    if (fast) { MER_CONV0(conv0_fast_kernel, f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(conv0_fast_kernel, f16, true, (f16*)out_hi, (f16*)out_lo); }
-    else { MER_CONV0(conv0_kernel, f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(conv0_kernel, f16, true, (f16*)out_hi, (f16*)out_lo); }
-  } else {
-    if (fast) { MER_CONV0(conv0_fast_kernel, bf16, false, (bf16*)nullptr, (bf16*)nullptr); MER_CONV0(conv0_fast_kernel, bf16, true, (bf16*)out_hi, (bf16*)out_lo); }
-    else { MER_CONV0(conv0_kernel, bf16, false, (bf16*)nullptr, (bf16*)nullptr); MER_CONV0(conv0_kernel, bf16, true, (bf16*)out_hi, (bf16*)out_lo); }
-  }
+#define MER_CONV0(TT, AP, OH, OL) hipLaunchKernelGGL((conv0_kernel<TT, AP>), grid, block, 0, st, wav, L, T0, w, C, k, stride, gamma, beta, eps, stats, OH, OL, valid_frames)
+  if (dtype == MER_DT_F16) { MER_CONV0(f16, false, (f16*)nullptr, (f16*)nullptr); MER_CONV0(f16, true, (f16*)out_hi, (f16*)out_lo); }
+  else { MER_CONV0(bf16, false, (bf16*)nullptr, (bf16*)nullptr); MER_CONV0(bf16, true, (bf16*)out_hi, (bf16*)out_lo); }
 #undef MER_CONV0
   return check_launch("hubert_conv0_gn");
 }

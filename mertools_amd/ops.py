@@ -231,15 +231,17 @@ def attention_hm(qkv_hm, B, T, H, scale, *, kv_len=None, out_lo=False):
     return oh, ol
 
 
-def hubert_conv0_gn(wav, w, gamma, beta, eps=1e-5, *, stride=5, dtype="f16", lo=False):
+def hubert_conv0_gn(wav, w, gamma, beta, eps=1e-5, *, stride=5, dtype="f16", lo=False, valid_frames=None):
+    """valid_frames: int32 [B] — GroupNorm statistics over each row's first valid_frames[b] frames only (ragged batch)."""
     B, L = wav.shape
     Cc, k = w.shape
     T0 = (L - k) // stride + 1
     stats = torch.empty((B, Cc, 2), dtype=torch.float64, device=wav.device)
     oh = torch.empty((B, T0, Cc), dtype=torch16(dtype), device=wav.device)
     ol = torch.empty_like(oh) if lo else None
-    _lib.check(_lib.lib().mer_hubert_conv0_gn(_p(wav), B, L, _p(w), Cc, k, stride, _p(gamma), _p(beta), eps, _p(stats),
-                                              _p(oh), _p(ol), dt_code(dtype), stream()), "mer_hubert_conv0_gn")
+    _lib.check(_lib.lib().mer_hubert_conv0_gn_ragged(_p(wav), B, L, _p(w), Cc, k, stride, _p(gamma), _p(beta), eps, _p(stats),
+                                                     _p(oh), _p(ol), dt_code(dtype), _p(valid_frames), stream()),
+               "mer_hubert_conv0_gn")
     return oh, ol
 
 

@@ -239,6 +239,42 @@ def test_hubert_conv0_groupnorm_gelu(dev):
     assert_close((oh.float() + ol.float()).cpu(), ref, 5e-6, "conv0+GN+GELU")
 
 
+def test_hubert_conv0_statistics_on_a_correlated_signal(dev):
+    """The GroupNorm statistics come from the clip's 10x10 autocorrelation (w'Rw), not from the conv output.  The hard case for
+    that identity: a DC offset plus a slow sine (R entries ~0.3, all nearly equal) under difference filters whose output energy
+    is five orders of magnitude smaller — the moments must be exact enough to survive the cancellation.  Ragged rows: statistics
+    over the row's own frames only, several moment chunks per clip."""
+    ops = _ops()
+    B, L, C, k, s = 3, 40000, 512, 10, 5
+    t = torch.arange(L, dtype=torch.float64)
+    wav = (0.3 + 0.5 * torch.sin(2 * math.pi * 50.0 * t / 16000.0))[None].repeat(B, 1)
+    wav = (wav + 1e-3 * _rand((B, L), 31).double()).float()
+    w = _rand((C, k), 32) * 0.3
+    w[0] = 0
+    w[0, 0], w[0, 1] = 1.0, -1.0                      # first difference
+    w[1] = 0
+    w[1, 3], w[1, 4], w[1, 5] = 1.0, -2.0, 1.0         # second difference
+    w[2] = 0.1                                         # moving average (DC passes: mean >> std)
+    w[3:64] -= w[3:64].mean(dim=1, keepdim=True)       # zero-DC random filters
+    g, b = _rand((C,), 33) * 0.1 + 1.0, _rand((C,), 34) * 0.1
+    T0 = (L - k) // s + 1
+    valid = torch.tensor([T0, 4100, 257], dtype=torch.int32)
+    y = F.conv1d(wav[:, None].double(), w[:, None].double(), stride=s)
+    ref = torch.empty(B, T0, C)
+    for i in range(B):
+        v = int(valid[i])
+        mu = y[i, :, :v].mean(dim=1, keepdim=True)
+        var = y[i, :, :v].var(dim=1, unbiased=False, keepdim=True)
+        z = (y[i] - mu) / torch.sqrt(var + 1e-5) * g.double()[:, None] + b.double()[:, None]
+        ref[i] = F.gelu(z).t().float()
+    oh, ol = ops.hubert_conv0_gn(wav.to(dev), w.to(dev), g.to(dev), b.to(dev), 1e-5, stride=s, lo=True, valid_frames=valid.to(dev))
+    torch.cuda.synchronize()
+    out = (oh.float() + ol.float()).cpu()
+    for i in range(B):
+        v = int(valid[i])
+        assert_close(out[i, :v], ref[i, :v], 1e-4, f"conv0+GN+GELU, correlated signal, row {i} ({v} frames)")
+
+
 def test_vit_patchify_and_assemble(dev):
     ops = _ops()
     N, P, S, D = 3, 16, 64, 128
