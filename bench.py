@@ -544,9 +544,11 @@ def e2e(args, dev):
         def run_v(names, out, asyn=True):
             visual.extract(mv, os.path.join(root, "face"), out, "UTTERANCE", vids=names, frames_per_batch=8 * B, device_preprocess=True, workers=8, rank=0, world=1, async_save=asyn)
 
+        for n in {32, N}:   # the transcription files of the warm-up and of the timed runs (corpus preparation: not timed)
+            pd.read_csv(csv).head(n).to_csv(os.path.join(root, f"trans_{n}.csv"), index=False)
+
         def run_t(n, out, asyn=True, tokenizer=None):
             sub = os.path.join(root, f"trans_{n}.csv")
-            pd.read_csv(csv).head(n).to_csv(sub, index=False)
             text.extract_embedding("roberta-base", sub, out, "UTTERANCE", gpu=dev.index or 0, model=mt, tokenizer=tokenizer or tok, batch_size=B, rank=0, world=1, async_save=asyn)
 
         # warm-up + byte-identity of the asynchronous path: the first 32 clips with and without it
@@ -577,15 +579,19 @@ def e2e(args, dev):
             torch.cuda.synchronize()
             kern[name] = 8 * B / (time.perf_counter() - t0)
         # the reference runs its three extraction scripts one after the other: each driver alone over the corpus (its own host + GPU time)
-        alone = {}
+        alone, stages = {}, {}
+        from mertools_amd.extract import pipeline
         with contextlib.redirect_stdout(io.StringIO()):
             for name, fn in (("a", lambda: run_a(wavs, os.path.join(root, "out_a"))), ("v", lambda: run_v(vids, os.path.join(root, "out_v"))),
                              ("t", lambda: run_t(N, os.path.join(root, "out_t")))):
                 torch.cuda.synchronize()
+                pipeline.trace_enable(True)   # where the GPU-feeding thread's wall time goes (a handful of perf_counter calls per batch)
                 t0 = time.perf_counter()
                 fn()
                 torch.cuda.synchronize()
                 alone[name] = time.perf_counter() - t0
+                stages[name] = {k: round(v * 1e3, 2) for k, v in sorted(pipeline.TRACE.items())}
+                pipeline.trace_enable(False)
         nfiles = sum(len(os.listdir(os.path.join(root, d))) for d in ("out_a", "out_v", "out_t/roberta-base-UTT"))
         assert nfiles == 3 * N, f"e2e: {nfiles} feature files for {N} clips x 3 modalities"
         # the text driver again with the Rust tokenizer of the same vocabulary (the reference prescribes use_fast=False; the ids — checked
@@ -630,14 +636,16 @@ def e2e(args, dev):
                 "definition": "the three drivers one after the other over the corpus (how the reference's three extraction scripts are run): N / (t_audio + t_visual + t_text)",
                 "kernel_only_clips_per_s_same_schedule": round(kern_seq, 1), "frac_of_kernel_only": round(N / seq / kern_seq, 3),
                 "per_modality": {m: {"seconds": round(alone[m], 3), "clips_per_s": round(N / alone[m], 1), "kernel_only_clips_per_s": round(kern[m], 1),
-                                     "frac": round(N / alone[m] / kern[m], 3)} for m in "avt"},
+                                     "frac": round(N / alone[m] / kern[m], 3), "feeding_thread_ms": stages[m]} for m in "avt"},
                 "with_fast_tokenizer": (None if fast_t is None else {"text_seconds": round(fast_t, 3), "clips_per_s": round(N / (seq - alone["t"] + fast_t), 1),
                                                                     "frac_of_kernel_only": round(N / (seq - alone["t"] + fast_t) / kern_seq, 3),
                                                                     "note": "BertTokenizerFast of the same vocabulary: identical ids and identical .npy bytes (checked)"}),
                 "three_threads_at_once": {"seconds": round(wall, 3), "clips_per_s": round(N / wall, 1), "per_modality_seconds": {k: round(v, 3) for k, v in secs.items()}},
                 "inputs": "PCM16 wav (5 s) + uint8 frame stacks [8,224,224,3] + transcription csv (64 tokens), on /dev/shm", "outputs": f"{nfiles} .npy files (UTT)",
-                "drivers": "extract.audio / visual / text: device_preprocess, 8 read-ahead threads, batched pinned uploads on a side stream, pinned async D2H + worker-thread np.save; "
-                           "text: the reference's slow (pure-Python) BertTokenizer",
+                "drivers": "extract.audio / visual / text: device_preprocess, 8 read-ahead threads (frame stacks read straight into pinned memory), uploads on a side stream, "
+                           "pinned async D2H + worker-thread .npy writes; text: transformers' BertTokenizer (use_fast=False, as the reference asks), the csv's sentences in one call",
+                "feeding_thread_ms": "wall time of the driver's GPU-feeding thread per stage (extract.pipeline.span): read_wait = blocked on the read-ahead threads, stage = batch "
+                                     "assembly + upload, forward = the encoder call (asynchronous launches), submit = hand-over to the writer, drain = waiting for the writer at the end",
                 "byte_identical_to_sync_path": bool(same)}
     finally:
         shutil.rmtree(root, ignore_errors=True)

@@ -8,11 +8,14 @@ back per clip instead of 13 x [T,D] hidden states.
 """
 import math
 import os
+import struct
 import time
 import wave
 
 import numpy as np
 import torch
+
+from .pipeline import npy_save, span
 
 MAXLEN = 16000 * 10
 WHISPER_BASE = 'whisper-base'        # reference :35-36
@@ -44,16 +47,36 @@ _SF = []   # [soundfile module or None], resolved once (a failing import costs a
 
 
 def read_pcm16(path):
-    """(int16 samples, sample_rate) of a PCM16 WAV without the float64 round trip, or None when the file is something else."""
+    """(int16 samples, sample_rate) of a mono PCM16 WAV without the float64 round trip, or None when the file is anything else (the
+    caller then takes the float reader).  The RIFF chunks are walked here — one read of the file, no per-chunk Python objects: the
+    stdlib `wave` reader costs more interpreter time per clip than the GPU needs for it — and the result is what `wave` returns
+    (tests/test_round3_cpu.py: extra chunks, odd chunk sizes, truncated data)."""
     try:
-        with wave.open(path, 'rb') as w:
-            if w.getsampwidth() != 2 or w.getcomptype() != 'NONE':
-                return None
-            if w.getnchannels() > 1:
-                return None   # (the float path keeps the reference's channel handling)
-            return np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').copy(), w.getframerate()   # (writable: torch.from_numpy)
-    except (wave.Error, EOFError):
+        with open(path, 'rb') as f:
+            buf = bytearray(os.fstat(f.fileno()).st_size)
+            n = f.readinto(buf)
+    except OSError:
         return None
+    if n < 12 or buf[0:4] != b'RIFF' or buf[8:12] != b'WAVE':
+        return None
+    pos, rate = 12, None
+    while pos + 8 <= n:
+        size = int.from_bytes(buf[pos + 4:pos + 8], 'little')
+        body = pos + 8
+        tag = bytes(buf[pos:pos + 4])
+        if tag == b'fmt ':
+            if size < 16 or body + 16 > n:
+                return None
+            fmt, channels, rate, _, _, bits = struct.unpack_from('<HHIIHH', buf, body)
+            if fmt != 1 or channels != 1 or bits != 16:   # (multi-channel files keep the reference's channel handling)
+                return None
+        elif tag == b'data':
+            if rate is None:
+                return None
+            count = min(size, n - body) // 2
+            return np.frombuffer(buf, dtype='<i2', count=count, offset=body), rate   # (a bytearray: writable, torch.from_numpy takes it)
+        pos = body + size + (size & 1)
+    return None
 
 
 def read_audio(path):
@@ -80,7 +103,7 @@ def save_feature(csv_file, feature, feature_level):
         feature = np.array(feature).squeeze()
         if len(feature.shape) != 1:
             feature = np.mean(feature, axis=0)
-    np.save(csv_file, feature)
+    npy_save(csv_file, feature)   # np.save's bytes (extract.pipeline)
 
 
 def load_model(model_name, gpu, precision="mean"):
@@ -217,7 +240,8 @@ def plan_batches(pending, batch_rows, ragged, final, max_stretch=1.5, keep_at_mo
 
 
 def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, do_normalize=True, batch_rows=32,
-            reader=read_audio, device_preprocess=False, workers=0, rank=None, world=None, window=256, ragged=True, async_save=True):
+            reader=read_audio, device_preprocess=False, workers=0, rank=None, world=None, window=256, ragged=True, async_save=True,
+            ramp_up=True):
     """device_preprocess: run the feature extractor's normalisation on the GPU instead of numpy.
     workers: threads that read and normalise the clips ahead of the batching loop (extract.prefetch; 0 = in line).
     rank / world: this process's share of `audio_files` (distributed.shard: sorted(files)[rank::world]; default = the
@@ -226,7 +250,9 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
     ragged: batch clips of DIFFERENT lengths together (rows zero-padded to the longest, mer_hubert_forward_ragged makes each
     clip equal to its batch-of-one forward); False = only clips of identical length share a batch.
     async_save: features leave the GPU through pinned buffers without blocking this thread and are written by worker threads
-    (extract.pipeline.AsyncWriter; the same bytes reach the same files); False = the reference's blocking copy + in-line np.save."""
+    (extract.pipeline.AsyncWriter; the same bytes reach the same files); False = the reference's blocking copy + in-line np.save.
+    ramp_up: the first two batches are cut at a quarter / half of `batch_rows` (and of `window`), so that the GPU starts while the
+    read-ahead is still filling instead of after a full batch of files has been read — a fixed cost per run, visible on small corpora."""
     from .prefetch import prefetch_map
     from .. import distributed
     if rank is None:
@@ -260,13 +286,16 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
         """device_preprocess fast path: one-row clips of ONE length and sample type travel as a single pinned [B, L] block on the
         upload stream and are normalised by one kernel — no per-clip H2D copy, launch or device allocation on this thread."""
         from .. import ops
-        first = items[0]['raw']
-        block = torch.empty((len(items), len(first)), dtype=torch.from_numpy(first[:1]).dtype, pin_memory=True)   # (cached by torch's host allocator)
-        for i, it in enumerate(items):   # straight into the pinned staging block: one host copy per clip
-            block[i].copy_(torch.from_numpy(it['raw']))
-        dev_block = up.up(block)
-        up.ready(dev_block)
-        flush(items, ops.wave_normalize(dev_block, do_normalize))
+        with span("stage"):
+            first = items[0]['raw']
+            block = torch.empty((len(items), len(first)), dtype=torch.from_numpy(first[:1]).dtype, pin_memory=True)   # (cached by torch's host allocator)
+            dst = block.numpy()
+            for i, it in enumerate(items):   # straight into the pinned staging block: one host copy per clip
+                dst[i] = it['raw']
+            dev_block = up.up(block)
+            up.ready(dev_block)
+            rows = ops.wave_normalize(dev_block, do_normalize)
+        flush(items, rows)
 
     def flush(items, rows=None):
         L = max(it['len'] for it in items)
@@ -287,25 +316,36 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
         T = model.out_frames(L)
         vids = [it['vid'] for it in items]
         if feature_level == 'UTTERANCE':
-            pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid)
+            with span("forward"):
+                pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid)
 
             def save_utt(arr, vids=vids):
                 for vid, feat in zip(vids, arr):
                     save_feature(os.path.join(save_dir, f"{vid}.npy"), feat, feature_level)
-            out.submit(pooled, save_utt)
+            with span("submit"):
+                out.submit(pooled, save_utt)
         else:
             starts, lens = model.clip_segments(L, chunks, valid)
-            _, frames, _ = model.forward_raw(rows, frames=True, valid_samples=valid)
+            with span("forward"):
+                _, frames, _ = model.forward_raw(rows, frames=True, valid_samples=valid)
 
             def save_frames(arr, vids=vids, starts=starts, lens=lens):
                 for vid, s0, n in zip(vids, starts, lens):
                     save_feature(os.path.join(save_dir, f"{vid}.npy"), arr[s0:s0 + n], feature_level)
-            out.submit(frames, save_frames)
+            with span("submit"):
+                out.submit(frames, save_frames)
 
     from .pipeline import writer
     pending = []
+    emitted = 0
+
+    def ramp(full):
+        return max(1, full >> max(0, 2 - emitted)) if ramp_up else full
+
     with writer(model.device, async_save) as out:
         def emit(b):
+            nonlocal emitted
+            emitted += 1
             if any('raw' in it for it in b):
                 same = len({(it['len'], it['raw'].dtype) for it in b if 'raw' in it}) == 1 and all('raw' in it for it in b)
                 if same:
@@ -317,7 +357,7 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
                             it['iv'] = ops.wave_normalize(torch.from_numpy(it['raw'])[None].to(model.device), do_normalize)
             flush(b)
 
-        for audio_file, iv in prefetch_map(host_stage, audio_files, workers):
+        for audio_file, iv in prefetch_map(host_stage, audio_files, workers, chunk=4):
             vid = os.path.basename(audio_file)[:-4]
             if device_preprocess:
                 if len(iv) > MAXLEN:   # > 10 s: chunked after the normalisation (reference :40-50)
@@ -332,12 +372,12 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
             # a full batch of clips of ONE length needs no sorting window: cut it as soon as it exists (a corpus of equal-length
             # clips would otherwise sit on the host until `window` files have been read, with the GPU idle)
             same = [it for it in pending if it['len'] == pending[-1]['len'] and it['rows'] == pending[-1]['rows'] and ('raw' in it) == ('raw' in pending[-1])]
-            if sum(it['rows'] for it in same) >= batch_rows:
+            if sum(it['rows'] for it in same) >= ramp(batch_rows):
                 ids = {id(it) for it in same}
                 pending = [it for it in pending if id(it) not in ids]
                 emit(same)
-            elif len(pending) >= window:
-                batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=window // 2)
+            elif len(pending) >= ramp(window):
+                batches, pending = plan_batches(pending, batch_rows, ragged, final=False, keep_at_most=ramp(window) // 2)
                 for b in batches:
                     emit(b)
         batches, pending = plan_batches(pending, batch_rows, ragged, final=True)

@@ -10,24 +10,63 @@ results are alive at a time.  workers = 0 is the plain in-line loop.
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 
+from .pipeline import span
 
-def prefetch_map(fn, items, workers=0, depth=None):
-    """Generator over fn(item) for item in items, in order, computed up to `depth` items ahead on `workers` threads."""
+
+class _Raised:
+    __slots__ = ("exc",)
+
+    def __init__(self, exc):
+        self.exc = exc
+
+
+def prefetch_map(fn, items, workers=0, depth=None, chunk=1):
+    """Generator over fn(item) for item in items, in order, computed up to `depth` items ahead on `workers` threads.
+    chunk: items per task — a task costs tens of microseconds of interpreter time on the consuming thread (future, queue, wake-up),
+    which is what a 160 KB wav read costs; chunk > 1 amortises it.  Order, laziness and where an exception surfaces are unchanged."""
     if workers <= 0:
         for it in items:
             yield fn(it)
         return
-    depth = depth or 4 * workers
+    chunk = max(1, int(chunk))
+    depth = depth or 4 * workers * chunk
+    ntasks = max(1, -(-depth // chunk))
+
+    def run(group):
+        out = []
+        for x in group:
+            try:
+                out.append(fn(x))
+            except BaseException as e:   # delivered when the consumer reaches this item; the rest of the group is not started
+                out.append(_Raised(e))
+                break
+        return out
+
+    def drain(fut):
+        with span("read_wait"):
+            res = fut.result()
+        for r in res:
+            if isinstance(r, _Raised):
+                raise r.exc
+            yield r
+
     with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="mer-prefetch") as pool:
         window = deque()
         it = iter(items)
         try:
-            for x in it:
-                window.append(pool.submit(fn, x))
-                if len(window) >= depth:
-                    yield window.popleft().result()
+            while True:
+                group = []
+                for x in it:
+                    group.append(x)
+                    if len(group) >= chunk:
+                        break
+                if not group:
+                    break
+                window.append(pool.submit(run, group))
+                if len(window) >= ntasks:
+                    yield from drain(window.popleft())
             while window:
-                yield window.popleft().result()
+                yield from drain(window.popleft())
         finally:
             for f in window:   # consumer stopped early or an item raised: drop what has not started yet
                 f.cancel()

@@ -7,6 +7,8 @@ import time
 import numpy as np
 import torch
 
+from .pipeline import npy_save, span
+
 PROBE = '今天天气真好'
 
 
@@ -54,7 +56,7 @@ def save_embeddings(csv_file, embeddings, feature_level, feature_dim):
             embeddings = np.zeros((feature_dim,))
         elif len(embeddings.shape) == 2:
             embeddings = np.mean(embeddings, axis=0)
-    np.save(csv_file, embeddings)
+    npy_save(csv_file, embeddings)   # np.save's bytes (extract.pipeline)
 
 
 def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, punc_case=None, language='chinese',
@@ -80,24 +82,32 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
         torch.cuda.set_device(max(gpu, 0))   # reference: torch.cuda.set_device(gpu) (extract_text_huggingface.py:192-193)
         model = HipBertModel.from_hf(AutoModel.from_pretrained(model_dir), device=f'cuda:{max(gpu, 0)}')
         tokenizer = AutoTokenizer.from_pretrained(model_dir, use_fast=False)
-    start, end = find_start_end_pos(tokenizer)
-    batch_pos, feature_dim = find_batchpos_embdim(tokenizer, model, gpu)
+    with span("probe"):
+        start, end = find_start_end_pos(tokenizer)
+        batch_pos, feature_dim = find_batchpos_embdim(tokenizer, model, gpu)
     pad_id = model.config.pad_token_id if model.config.pad_token_id is not None else 0
-    df = pd.read_csv(trans_dir)
+    with span("read_wait"):
+        df = pd.read_csv(trans_dir)
     from ..distributed import rank_world
     if rank is None or world is None:
         rank, world = rank_world()
     if world > 1:   # this process's share of the sentences: sorted names [rank::world] (sentences are independent, no collective)
         mine = set(sorted(str(n) for n in df['name'])[rank::world])
         df = df[[str(n) in mine for n in df['name']]]
-    todo = []
-    for idx, row in df.iterrows():
-        sentence = row['chinese'] if language == 'chinese' else row['english']
-        if pd.isna(sentence) == False and len(sentence) > 0:  # noqa: E712 (reference's test)
-            ids = tokenizer(sentence)['input_ids']   # (a plain list: the per-sentence tensor round trip of return_tensors='pt' is most of the call)
-            todo.append((row['name'], ids))
-        else:
-            save_embeddings(os.path.join(save_dir, f"{row['name']}.npy"), [], feature_level, feature_dim)
+    # The reference's per-row loop (:216-233: `for idx, row in df.iterrows()`, one tokenizer call per sentence) as column operations:
+    # the same test per sentence, the same ids — iterrows builds a Series per row and costs as much as the tokenizer.
+    names = df['name'].tolist()
+    sentences = (df['chinese'] if language == 'chinese' else df['english']).tolist()
+    keep = [pd.isna(s) == False and len(s) > 0 for s in sentences]  # noqa: E712 (reference's test)
+    for name, k in zip(names, keep):
+        if not k:
+            save_embeddings(os.path.join(save_dir, f"{name}.npy"), [], feature_level, feature_dim)
+    kept = [s for s, k in zip(sentences, keep) if k]
+    # one call over the list = one call per sentence (no padding / truncation is requested, so each row is tokenised on its own);
+    # a Rust-backed tokenizer spreads the list over the host cores
+    with span("tokenize"):
+        ids_all = tokenizer(kept)['input_ids'] if kept else []
+    todo = list(zip([n for n, k in zip(names, keep) if k], ids_all))
     todo.sort(key=lambda it: len(it[1]))
     from .pipeline import writer
     with writer(model.device, async_save) as out:   # pinned non-blocking D2H + np.save on worker threads (extract.pipeline)
@@ -111,22 +121,26 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
                 lens.append(len(ids))
             names = [name for name, _ in chunk]
             if feature_level == 'FRAME':
-                _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
+                with span("forward"):
+                    _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
 
                 def save_frames(arr, names=names, lens=lens, T=T):
                     arr = arr.reshape(len(names), T, -1)
                     for r, name in enumerate(names):
                         e = lens[r] + end if end is not None else lens[r]
                         save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r, start:e], feature_level, feature_dim)
-                out.submit(frames, save_frames)
+                with span("submit"):
+                    out.submit(frames, save_frames)
             else:
-                pooled = model.extract_utterance(batch, lens, start, end)
+                with span("forward"):
+                    pooled = model.extract_utterance(batch, lens, start, end)
 
                 def save_utt(arr, names=names, lens=lens):
                     for r, name in enumerate(names):
                         n_tok = (lens[r] + (end if end is not None else 0)) - start
                         save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r] if n_tok > 0 else [], feature_level, feature_dim)
-                out.submit(pooled, save_utt)
+                with span("submit"):
+                    out.submit(pooled, save_utt)
     print(f'Total {len(df)} files done! Time used ({model_name}): {time.time() - start_time:.1f}s.')
 
 

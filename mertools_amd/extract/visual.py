@@ -7,6 +7,8 @@ import os
 import numpy as np
 import torch
 
+from .pipeline import npy_save, span
+
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
@@ -68,11 +70,11 @@ def save_embeddings(save_file, embeddings, feature_level, embedding_dim):
             embeddings = np.zeros((embedding_dim,))
         elif len(embeddings.shape) == 2:
             embeddings = np.mean(embeddings, axis=0)
-    np.save(save_file, embeddings)
+    npy_save(save_file, embeddings)   # np.save's bytes (extract.pipeline)
 
 
 def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, frames_per_batch=512, reader=func_read_frames,
-            device_preprocess=False, workers=0, rank=None, world=None, async_save=True):
+            device_preprocess=False, workers=0, rank=None, world=None, async_save=True, ramp_up=True):
     """CLIP branch of the reference main loop.  `model`: HipCLIPModel.  One .npy per video.
     device_preprocess: frames that already have the model's resolution go to the GPU as uint8 (a quarter of the fp32 bytes)
     and are rescaled / normalised there (mer_image_normalize_u8); other sizes keep the host PIL path —
@@ -81,13 +83,15 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
     workers: threads that read and pre-process videos ahead of the GPU loop (extract.prefetch; 0 = in line, as the reference).
     rank / world: this process's share of the videos (distributed.my_share: sorted(vids)[rank::world]; default = the
     torch.distributed rank / world size).  Videos are independent: no collective.  (The reference's EMBEDDING_DIM fallback for
-    an empty video is the running maximum over the videos THIS process has seen before it.)"""
+    an empty video is the running maximum over the videos THIS process has seen before it.)
+    ramp_up: the first two batches are cut at a quarter / half of `frames_per_batch`: the GPU starts while the read-ahead is still
+    filling instead of after a full batch of frame stacks has been read (a fixed cost per run, visible on small corpora)."""
     from .prefetch import prefetch_map
     from ..distributed import my_share
     os.makedirs(save_dir, exist_ok=True)
     vids = my_share(vids if vids is not None else os.listdir(face_dir), rank, world)
     embedding_dim = -1
-    pending, nframes = [], 0
+    pending, nframes, emitted = [], 0, 0
     size = model.config.vision_config.image_size
 
     up = None
@@ -96,30 +100,28 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
         up = Uploader(model.device)
 
     def flush():
-        nonlocal pending, nframes, embedding_dim
+        nonlocal pending, nframes, embedding_dim, emitted
         if not pending:
             return
+        emitted += 1
         if all(p.dtype == torch.uint8 and not p.is_cuda for _, p in pending) and len({tuple(p.shape[1:]) for _, p in pending}) == 1:
             # device_preprocess fast path: the batch's uint8 frames (all of the model's resolution, or all of one size awaiting the GPU
             # resize) travel as ONE block on the upload stream and are resized / normalised by one launch each — no per-video H2D copy,
             # kernel launch or device allocation on this thread
             from .. import ops
-            n_fr = sum(p.shape[0] for _, p in pending)
-            pin = torch.empty((n_fr,) + tuple(pending[0][1].shape[1:]), dtype=torch.uint8, pin_memory=True)   # (cached by torch's host allocator)
-            r = 0
-            for _, p in pending:   # straight into the pinned staging block: one host copy per frame stack
-                pin[r:r + p.shape[0]].copy_(p)
-                r += p.shape[0]
-            block = up.up(pin)
-            up.ready(block)
-            if tuple(block.shape[1:3]) != (size, size):
-                from .resize import resize_crop_u8
-                block = resize_crop_u8(block, size)
-            px = ops.image_normalize_u8(block, CLIP_MEAN, CLIP_STD, bgr=True)
+            with span("stage"):
+                block = up.gather([p for _, p in pending])
+                up.ready(block)
+                if tuple(block.shape[1:3]) != (size, size):
+                    from .resize import resize_crop_u8
+                    block = resize_crop_u8(block, size)
+                px = ops.image_normalize_u8(block, CLIP_MEAN, CLIP_STD, bgr=True)
         else:
-            px = torch.cat([_to_px(p) for _, p in pending], 0)
+            with span("stage"):
+                px = torch.cat([_to_px(p) for _, p in pending], 0)
         counts = [p.shape[0] for _, p in pending]
-        feats = model.get_image_features(px)  # [sum(frames), P], on the device
+        with span("forward"):
+            feats = model.get_image_features(px)  # [sum(frames), P], on the device
         embedding_dim = max(embedding_dim, feats.shape[-1])
 
         def save(arr, vids=[vid for vid, _ in pending], counts=counts, dim=embedding_dim):
@@ -127,11 +129,23 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             for vid, n in zip(vids, counts):
                 save_embeddings(os.path.join(save_dir, f'{vid}.npy'), arr[r:r + n], feature_level, dim)
                 r += n
-        out.submit(feats, save)   # async_save: pinned non-blocking D2H + np.save on worker threads (extract.pipeline)
+        with span("submit"):
+            out.submit(feats, save)   # async_save: pinned non-blocking D2H + np.save on worker threads (extract.pipeline)
         pending, nframes = [], 0
 
     def host_stage(vid):   # everything that needs no GPU: file read + (PIL) pre-processing
-        frames = reader(face_dir, vid)
+        frames = None
+        if device_preprocess and reader is func_read_frames:   # the frame stack straight into pinned memory (no pageable copy)
+            npy_path = os.path.join(face_dir, vid, f'{vid}.npy')
+            assert os.path.exists(npy_path), f'Error: {vid} does not have frames.npy!'
+            from .pipeline import read_into_pinned
+            pin = read_into_pinned(npy_path)
+            if pin is not None and pin.dtype == torch.uint8 and pin.dim() == 4 and len(pin) > 0 and (
+                    tuple(pin.shape[1:3]) == (size, size) or device_preprocess == 'resize'):
+                return vid, 'u8', pin
+            frames = pin.numpy() if pin is not None else None
+        if frames is None:
+            frames = reader(face_dir, vid)
         if len(frames) == 0:
             return vid, None, None
         if device_preprocess and frames.dtype == np.uint8 and (frames.shape[1:3] == (size, size) or device_preprocess == 'resize'):
@@ -151,12 +165,13 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
         return ops.image_normalize_u8(p, CLIP_MEAN, CLIP_STD, bgr=True)
 
     with writer(model.device, async_save) as out:
-        for vid, kind, px in prefetch_map(host_stage, vids, workers):
+        for vid, kind, px in prefetch_map(host_stage, vids, workers, chunk=2):
             if kind is None:
                 flush()
                 save_embeddings(os.path.join(save_dir, f'{vid}.npy'), np.zeros((0,)), feature_level, embedding_dim)
                 continue
-            if nframes + len(px) > frames_per_batch:
+            cap = max(1, frames_per_batch >> max(0, 2 - emitted)) if ramp_up else frames_per_batch
+            if nframes + len(px) > cap:
                 flush()
             pending.append((vid, px))
             nframes += len(px)

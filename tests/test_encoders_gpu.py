@@ -365,6 +365,35 @@ def test_clip_base32_frames(dev):
         del m
 
 
+# ---- speech-like dynamics: loud and quiet passages in one clip.  Stationary noise (every other audio test here) cannot see a
+# correction that is not scale-equivariant; this can (tests/test_round3_cpu.py::test_batch_mean_bias_is_unsound_in_huberts_conv_stack).
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_hubert_loud_and_quiet_passages(dev, size):
+    from mertools_amd.encoders import HipHubertModel
+    from util import rel_err
+    cfg = W.hubert_config(size)
+    sd = W.hubert_state_dict(cfg, 1)
+    g = torch.Generator().manual_seed(11)
+    B, L = 2, 32000
+    env = torch.where((torch.arange(L) // 4800) % 2 == 0, 1.0, 0.01)       # 0.3 s loud, 0.3 s 40 dB down
+    wav = torch.randn(B, L, generator=g) * 0.1 * env
+    wav = (wav - wav.mean(1, keepdim=True)) / torch.sqrt(wav.var(1, unbiased=False, keepdim=True) + 1e-7)
+    feat = torch.stack(R.hubert_hidden_states(sd, vars(cfg), wav))[[-4, -3, -2, -1]].sum(0)
+    T = feat.shape[1]
+    res = {}
+    for prec in ("mean", "mx", "mean_all"):
+        m = HipHubertModel(sd, cfg, device=dev, precision=prec)
+        _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[b * T for b in range(B)], seg_len=[T] * B)
+        torch.cuda.synchronize()
+        res[prec] = (rel_err(pooled.cpu(), feat.mean(1))[0], rel_err(fr.cpu().view(B, T, -1), feat)[0])
+        print(f"hubert-{size} loud/quiet [{prec}]: utt={res[prec][0]:.2e} frame={res[prec][1]:.2e}")
+        del m
+    for prec in ("mean", "mx"):
+        assert res[prec][0] <= TOL, res
+        assert res[prec][1] <= (TOL if size == "base" else 1.5e-3), res   # (tiny model, one-plane activations: the per-frame maximum sits at 1e-3)
+    assert res["mean_all"][0] > 2 * res["mean"][0], res   # the batch-mean bias in the conv stack is what this test is here to keep out
+
+
 # ---- ragged audio batches: clips of different lengths in ONE batch, each equal to its batch-of-one forward (the reference
 # runs batch 1 and never pads or masks audio: extract_audio_huggingface.py:93-100) ----
 @pytest.mark.parametrize("style", ["tiny-base", "tiny-large", "tiny-wavlm", "base", "large"])

@@ -249,3 +249,28 @@ def test_plan_batches_bounds_padding_and_memory():
     assert padded <= 1.25 * sum(it["len"] for g in out for it in g)
     out2, keep2 = audio.plan_batches(keep, 32, True, True)
     assert not keep2 and sum(len(g) for g in out2) == len(keep)
+
+
+def test_prefetch_map_chunked_tasks_keep_order_laziness_and_exceptions():
+    seen = []
+
+    def fn(i):
+        time.sleep(0.001 * ((7 * i) % 5))
+        seen.append(i)
+        if i == 21:
+            raise ValueError("item 21")
+        return i * i
+
+    assert list(prefetch_map(fn, range(20), workers=3, chunk=4)) == [i * i for i in range(20)]
+    assert list(prefetch_map(fn, range(19), workers=3, chunk=4, depth=5)) == [i * i for i in range(19)]   # ragged last group
+    out = []
+    with pytest.raises(ValueError, match="item 21"):
+        for x in prefetch_map(fn, range(40), workers=4, chunk=4):
+            out.append(x)
+    assert out == [i * i for i in range(21)]          # the items before it in the same group are still delivered
+    seen.clear()
+    g = prefetch_map(lambda i: seen.append(i) or i, range(1000), workers=2, chunk=4, depth=8)
+    assert [next(g) for _ in range(3)] == [0, 1, 2] and len(seen) <= 3 + 8 + 2 * 4
+    g.close()
+    time.sleep(0.05)
+    assert len(seen) < 40
