@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--no-large", action="store_true", help="skip the BASELINE configs[4] (large trio) sub-object of the headline line")
     ap.add_argument("--no-sustained", action="store_true", help="skip the sustained (>= --sustain-seconds) line")
     ap.add_argument("--sustain-seconds", type=float, default=20.0)
-    ap.add_argument("--e2e", type=int, default=256, help="N > 0: also run N clips files -> .npy through the drop-in drivers (extra key `e2e`, headline line on one GPU only); 0 skips it")
+    ap.add_argument("--e2e", type=int, default=1024, help="N > 0: also run N clips files -> .npy through the drop-in drivers (extra key `e2e`, headline line on one GPU only); 0 skips it")
     return ap.parse_args()
 
 
