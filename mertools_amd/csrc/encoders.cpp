@@ -413,8 +413,11 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   MER_REQUIRE(Tn >= 1, MER_ESHAPE, "mer_hubert_forward: input too short");
   const int M = B * Tn;
   const P16 none = {nullptr, nullptr};
-  // conv_passes == 5: batch-mean correction of the conv GEMMs / the projection; in a ragged batch only the output frames that come
-  // from a clip's own samples count (the zero tail's frames look nothing like speech and would drag the mean with the padding)
+  // conv_passes == 5 (the "mean_all" STUDY preset — not what "mean" ships): batch-mean correction of the conv GEMMs / the projection.
+  // Unsound for real audio: the conv layers read un-normalised GELU outputs, a quiet passage's rows are 20-50x smaller than the batch
+  // mean, the bias is an absolute offset they cannot absorb and the projection's LayerNorm magnifies it (1e-2 on loud / quiet clips,
+  // DESIGN.md §4, test_hubert_loud_and_quiet_passages).  "mean" runs the conv stack with conv_passes == 4 (per-row MX correction) and
+  // keeps the batch-mean bias behind LayerNorms.  In a ragged batch only the output frames that come from a clip's own samples count.
   MER_TRY(corr_begin(st, p.tf.corr));
   const bool corr_on = cps == 5 && p.tf.corr.base;
 
