@@ -27,6 +27,10 @@ def lin(x, w, b=None):
     elif MODE["corr"] == "gmean":                                           # ONE mean token for the whole batch (all clips, all tokens)
         m = a16.reshape(-1, a16.shape[-1]).mean(dim=0, keepdim=True)
         out = out + _lin(m, wl)
+    elif MODE["corr"] == "smean":                                           # batch mean token, scaled per row by the row's projection on it
+        m = a16.reshape(-1, a16.shape[-1]).mean(dim=0, keepdim=True)
+        alpha = (a16 * m).sum(-1, keepdim=True) / (m * m).sum().clamp_min(1e-30)
+        out = out + alpha * _lin(m, wl)
     elif MODE["corr"] == "calrec":
         CAL["rec"].append(a16.reshape(-1, a16.shape[-1]).mean(dim=0, keepdim=True))
     elif MODE["corr"] == "cal":
@@ -52,6 +56,15 @@ def conv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     elif MODE["corr"] == "gmean":
         full = _conv(a16, wl, None, stride, padding, dilation, groups)
         out = out + full.mean(dim=(0, 2), keepdim=True)
+    elif MODE["corr"] == "smean":
+        # im2col rows r = (b, t): m = mean row, alpha_r = <a_r, m> / <m, m>, correction alpha_r * (m w_lo^T)
+        k = w.shape[-1]
+        cols = a16.unfold(2, k, stride)                                  # [B, Ci, T, k]
+        cols = cols.permute(0, 2, 1, 3).reshape(a16.shape[0], cols.shape[2], -1)   # [B, T, Ci*k]  (ci-major, like w.reshape(Co, -1))
+        m = cols.reshape(-1, cols.shape[-1]).mean(0)                      # [Ci*k]
+        alpha = (cols @ m) / (m @ m).clamp_min(1e-30)                     # [B, T]
+        c = wl.reshape(wl.shape[0], -1) @ m                               # [Co]
+        out = out + alpha[:, None, :] * c[None, :, None]
     elif MODE["corr"] == "calrec":
         CAL["rec"].append(_conv(a16, wl, None, stride, padding, dilation, groups).mean(dim=(0, 2), keepdim=True))
     elif MODE["corr"] == "cal":
