@@ -274,3 +274,54 @@ def test_prefetch_map_chunked_tasks_keep_order_laziness_and_exceptions():
     g.close()
     time.sleep(0.05)
     assert len(seen) < 40
+
+
+def test_ramp_up_cuts_the_first_two_batches_small_and_changes_no_feature(tmp_path):
+    """ramp_up: the first two batches are a quarter / half of the batch size (the GPU starts while the read-ahead is still filling);
+    with encoders whose rows do not look at each other the files are the same with and without it."""
+    rng = np.random.RandomState(2)
+    files = []
+    for i in range(40):                      # equal-length clips: the driver cuts a batch as soon as it is full
+        p = str(tmp_path / f"c{i:02d}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes((np.clip(rng.randn(4000) * 0.1, -1, 1 - 1 / 32768) * 32768).astype("<i2").tobytes())
+        files.append(p)
+
+    class Counting(_Audio):
+        def __init__(self):
+            self.batches = []
+
+        def extract_utterance(self, rows, clip_chunks=None, valid_samples=None):
+            self.batches.append(rows.shape[0])
+            return super().extract_utterance(rows, clip_chunks, valid_samples)
+
+    got = {}
+    for ramp in (True, False):
+        m = Counting()
+        d = str(tmp_path / f"ramp{ramp}")
+        audio.extract("stub", files, d, "UTTERANCE", 0, model=m, workers=2, batch_rows=16, ramp_up=ramp)
+        got[ramp] = (m.batches, [np.load(os.path.join(d, f"c{i:02d}.npy")) for i in range(40)])
+    assert got[True][0] == [4, 8, 16, 12] and got[False][0] == [16, 16, 8]
+    assert all(np.array_equal(a, b) for a, b in zip(got[True][1], got[False][1]))
+
+    face, vids = _faces(tmp_path, [(4, 32, 32)] * 12)
+
+    class CountingVision(_Vision):
+        def __init__(self):
+            self.batches = []
+
+        def get_image_features(self, px):
+            self.batches.append(px.shape[0])
+            return super().get_image_features(px)
+
+    outs = {}
+    for ramp in (True, False):
+        m = CountingVision()
+        d = tmp_path / f"vis{ramp}"
+        visual.extract(m, face, str(d), "UTTERANCE", vids=vids, frames_per_batch=16, workers=2, ramp_up=ramp)
+        outs[ramp] = (m.batches, [np.load(d / f"{v}.npy") for v in vids])
+    assert outs[True][0] == [4, 8, 16, 16, 4] and outs[False][0] == [16, 16, 16]
+    assert all(np.array_equal(a, b) for a, b in zip(outs[True][1], outs[False][1]))
