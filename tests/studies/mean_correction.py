@@ -56,6 +56,31 @@ def conv(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     elif MODE["corr"] == "gmean":
         full = _conv(a16, wl, None, stride, padding, dilation, groups)
         out = out + full.mean(dim=(0, 2), keepdim=True)
+    elif MODE["corr"] in ("smean2", "nmean"):
+        k = w.shape[-1]
+        cols = a16.unfold(2, k, stride)
+        cols = cols.permute(0, 2, 1, 3).reshape(a16.shape[0], cols.shape[2], -1)
+        flat = cols.reshape(-1, cols.shape[-1])
+        wl2 = wl.reshape(wl.shape[0], -1)
+        if MODE["corr"] == "nmean":
+            # mean of the NORMALISED rows (direction only), scaled back per row by the row's own norm-projection: one token, scale-free
+            nrm = flat.norm(dim=1, keepdim=True).clamp_min(1e-30)
+            u = (flat / nrm).mean(0)
+            alpha = (flat @ u) / (u @ u).clamp_min(1e-30)
+            corr = alpha[:, None] * (wl2 @ u)[None, :]
+        else:
+            # two mean tokens: rows above / below the batch's RMS row norm; each row projected on the span of both (least squares)
+            nrm = flat.norm(dim=1)
+            thr = nrm.pow(2).mean().sqrt() * 0.25
+            hi, lo = flat[nrm >= thr], flat[nrm < thr]
+            m1 = hi.mean(0)
+            m2 = lo.mean(0) if len(lo) else torch.zeros_like(m1)
+            Mx = torch.stack([m1, m2], 1)                                   # [K, 2]
+            G = Mx.T @ Mx + 1e-12 * torch.eye(2)
+            coef = torch.linalg.solve(G, Mx.T @ flat.T).T                   # [rows, 2]
+            corr = coef @ (wl2 @ Mx).T                                      # [rows, Co]
+        corr = corr.reshape(cols.shape[0], cols.shape[1], -1).permute(0, 2, 1)
+        out = out + corr
     elif MODE["corr"] == "smean":
         # im2col rows r = (b, t): m = mean row, alpha_r = <a_r, m> / <m, m>, correction alpha_r * (m w_lo^T)
         k = w.shape[-1]

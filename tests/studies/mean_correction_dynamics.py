@@ -2,7 +2,8 @@
 """CPU-only study: the batch-mean weight-residual correction on NON-STATIONARY audio (0.3 s loud / 0.3 s `quiet` x as loud), HuBERT.
 Columns: no correction | exact second pass | batch-mean bias everywhere ("mean_all") | conv stack exact + bias behind LayerNorms (what
 "mean" ships, with MX in place of exact) | conv stack with the bias scaled per row by the row's projection on the mean token
-(alpha_r = <a_r, m> / <m, m>: a candidate for a one-pass, scale-equivariant conv-stack correction) | the scaled bias everywhere.
+(alpha_r = <a_r, m> / <m, m>: a candidate for a one-pass, scale-equivariant conv-stack correction) | the same with the mean of the
+NORMALISED rows as the token | two tokens (rows above / below a quarter of the RMS row norm), each row projected on their span.
 UTT / FRAME relative errors against the fp32 oracle.  usage: mean_correction_dynamics.py [tiny|base]"""
 import os, sys, torch, numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,7 +25,7 @@ with torch.no_grad():
         R.F.linear, R.F.conv1d = MC._lin, MC._conv
         ref = torch.stack(R.hubert_hidden_states(sd, vars(cfg), iv))[[-4, -3, -2, -1]].sum(0)
         row = []
-        for name, cm, lm in (("none", "none", "none"), ("exact", "exact", "exact"), ("gmean all", "gmean", "gmean"), ("conv exact+gmean", "exact", "gmean"), ("conv smean+gmean", "smean", "gmean"), ("smean all", "smean", "smean")):
+        for name, cm, lm in (("none", "none", "none"), ("exact", "exact", "exact"), ("gmean all", "gmean", "gmean"), ("conv exact+gmean", "exact", "gmean"), ("conv smean+gmean", "smean", "gmean"), ("conv nmean+gmean", "nmean", "gmean"), ("conv smean2+gmean", "smean2", "gmean")):
             def lin2(x, w, b=None, lm=lm):
                 MC.MODE["corr"] = lm; return MC.lin(x, w, b)
             def conv2(x, w, b=None, stride=1, padding=0, dilation=1, groups=1, cm=cm):
