@@ -104,6 +104,10 @@ typedef struct {
    * 256x256 LDS-DMA kernels (a DMA piece becomes 1 KiB contiguous); NULL = not available.  w_lo_blk is only
    * needed for passes 2 / 3. */
   const void* w_hi_blk; const void* w_lo_blk;
+  /* optional pre-blocked, ROW-PERMUTED copy of w_hi (mer_w_block_pack_p) for the persistent 256x256 one-pass kernel (register-direct
+   * epilogue, csrc/gemm16p_impl.h): used when passes == 1, nbatch <= 1, N % 256 == 0, K % 32 == 0, K >= 256 and the output is one
+   * 16-bit plane or fp32 (+ residual); NULL = not available. */
+  const void* w_hi_blkp;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
@@ -130,6 +134,10 @@ int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch,
  * Row-range views stay addressable: the block of column tile t starts at byte t * 256 * K * 2. */
 long long mer_w_block_bytes(int N, int K);
 int mer_w_block_pack(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream);
+/* The same blocks with the rows of every 64-row group permuted — block row 16 q + i holds plane row 4 i + q (i < 16, q < 4) — so
+ * that the four accumulators a lane of the 16x16 MFMA holds for one output row are four CONSECUTIVE columns: the persistent
+ * kernel's epilogue stores whole 128-byte lines straight from registers (no LDS transposition).  N % 256 == 0.  Same size. */
+int mer_w_block_pack_p(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream);
 
 /* Host-side packer of the MX correction plane.  w_res: HOST fp32 [N, K] (row stride ldw) = W - f16(W);
  * out: HOST buffer of mer_mx_packed_bytes(N, K) bytes (then copied to the device once).  Per (256-column tile,
@@ -289,7 +297,8 @@ int mer_inc_i32(int* x, mer_stream_t stream);
 /* ------------------------------------------------------------------------------------------ */
 
 typedef struct { const void* hi; const void* lo; const void* mx;   /* 16-bit weight planes [N,K] (+ MX residual plane for passes == 4, may be null) */
-                 const void* hi_blk; const void* lo_blk; } mer_w16;   /* optional pre-blocked copies of hi / lo (mer_w_block_pack), may be null */
+                 const void* hi_blk; const void* lo_blk;   /* optional pre-blocked copies of hi / lo (mer_w_block_pack), may be null */
+                 const void* hi_blkp; } mer_w16;           /* optional row-permuted pre-blocked copy of hi (mer_w_block_pack_p), may be null */
 
 /* One transformer block (HuBERT / wav2vec2 / CLIP-ViT / VideoMAE / BERT / RoBERTa).
  * wqkv = cat(q,k,v) rows [3D, D]; bqkv fp32 [3D] (zeros where the model has no bias). */

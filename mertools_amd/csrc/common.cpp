@@ -24,6 +24,19 @@ int check_launch(const char* what) {
   return MER_OK;
 }
 
+// multiprocessor count of the current device (the persistent GEMM launches one workgroup per CU); cached per device
+int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cached[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+
 struct ProfRec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
 static std::vector<ProfRec*> g_prof;

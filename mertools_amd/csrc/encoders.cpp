@@ -103,7 +103,7 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
   g.a_hi = a.hi; g.a_lo = a.lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.w_mx = w.mx; g.ldw = K;
-  g.w_hi_blk = w.hi_blk; g.w_lo_blk = w.lo_blk;
+  g.w_hi_blk = w.hi_blk; g.w_lo_blk = w.lo_blk; g.w_hi_blkp = w.hi_blkp;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
@@ -192,11 +192,12 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
       const mer_w16 wkv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
                            (w.wqkv.mx && tiles) ? (const char*)w.wqkv.mx + (long long)(D / 256) * (D / 32) * 5120 : nullptr,
                            (w.wqkv.hi_blk && tiles) ? (const char*)w.wqkv.hi_blk + woff : nullptr,
-                           (w.wqkv.lo_blk && tiles) ? (const char*)w.wqkv.lo_blk + woff : nullptr};
+                           (w.wqkv.lo_blk && tiles) ? (const char*)w.wqkv.lo_blk + woff : nullptr,
+                           (w.wqkv.hi_blkp && tiles) ? (const char*)w.wqkv.hi_blkp + woff : nullptr};
       const P16 ckv = {(char*)b.qkv16.hi + (long long)D * 2, nullptr};
       MER_TRY(gemm(st, dt, ps, M, 2 * D, D, b.cur16, D, wkv, w.bqkv + D, MER_ACT_NONE, nullptr, 0, nullptr, 0, ckv, 3 * D, mc));
       // ... Q for the CLS rows (row n of the A operand = token 0 of sequence n: lda = T * D)
-      const mer_w16 wq = {w.wqkv.hi, w.wqkv.lo, nullptr, nullptr, nullptr};
+      const mer_w16 wq = {w.wqkv.hi, w.wqkv.lo, nullptr, nullptr, nullptr, nullptr};
       MER_TRY(gemm(st, dt, ps, Bseq, D, D, b.cur16, (long long)T * D, wq, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, cls->q16, D, mc));
       MER_TRY(mer_attention_cls(cls->q16.hi, D, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
                                 cls->ctx16.hi, cls->ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, (mer_stream_t)st));
@@ -211,14 +212,15 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx != nullptr) {
       // Q | K columns: one f16 pass (weight rounding there only perturbs softmax logits: no measurable effect on the features);
       // V columns: MX-corrected.  The MX plane is stored per 256-column tile, so the V block starts at tile 2D/256.
-      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr};
+      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr, w.wqkv.hi_blkp};
       MER_TRY(gemm(st, dt, 1, M, 2 * D, D, b.cur16, D, wqk, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
       const long long woff = (long long)2 * D * D * 2;   // bytes into the 16-bit planes
       const mer_w16 wv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
                           w.wqkv.mx ? (const char*)w.wqkv.mx + (long long)(2 * D / 256) * (D / 32) * 5120 : nullptr,
                           // the pre-blocked planes are stored per 256-row tile as well: tile 2D/256 starts woff bytes in
                           w.wqkv.hi_blk ? (const char*)w.wqkv.hi_blk + woff : nullptr,
-                          w.wqkv.lo_blk ? (const char*)w.wqkv.lo_blk + woff : nullptr};
+                          w.wqkv.lo_blk ? (const char*)w.wqkv.lo_blk + woff : nullptr,
+                          w.wqkv.hi_blkp ? (const char*)w.wqkv.hi_blkp + woff : nullptr};
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
       MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, mc));
     } else
@@ -451,7 +453,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
     g.a_hi = src.hi; g.a_lo = src.lo; g.lda = (long long)c.conv_stride[i] * C;
     g.a_rows_per_batch = p.T[i]; g.a_batch_stride = (long long)p.T[i - 1] * C;
     g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.w_mx = w.conv_w[i].mx; g.ldw = g.K;
-    g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk;
+    g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk; g.w_hi_blkp = w.conv_w[i].hi_blkp;
     g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
     const CorrWs ccw = {&p.tf.corr, p.T[i], valid_samples ? p.vlen + (long long)i * B : nullptr};

@@ -1,12 +1,13 @@
 // gemm16.hip — C ABI of the 16-bit MFMA GEMM (mer_gemm16), its options and the weight packers; the kernel template lives in
 // gemm16_impl.h and is instantiated per (tile class, dtype) in gemm16_t3_*.hip / gemm16_small_*.hip.
-#include "gemm16_impl.h"
+#include "gemm16p_impl.h"
 
 namespace mer {
 // debug / tuning switches (mer_set_option; process-global and NOT thread-safe: set them before any forward is in flight)
 int g_gemm_skip = 0;          // "gemm_dbg_skip": 1 = skip the epilogue's global stores, 2 = skip the whole epilogue (timing decomposition)
 int g_gemm_stamp = 0;         // "gemm_stamp": the instrumented (s_memtime) build of the 8-wave kernels, with mer_set_debug_buffer
 int g_gemm_glds = 1;          // "gemm_glds": 0 = register-staged loader instead of LDS-DMA (A/B and the K % 32 != 0 fallback's twin)
+int g_gemm_persist = 1;       // "gemm_persist": 0 = never take the persistent kernel (A/B against gemm16_kernel on the same planes)
 int g_gemm_generic_epi = 0;   // "gemm_generic_epi": 1 = every launch takes the generic epilogue (the specialised ones must equal it)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel
 
@@ -27,6 +28,7 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_glds") == 0) { mer::g_gemm_glds = value; return MER_OK; }
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
   if (name && strcmp(name, "gemm_generic_epi") == 0) { mer::g_gemm_generic_epi = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
@@ -46,7 +48,32 @@ __global__ void w_block_pack_kernel(const u32x4* w, long long ldw8, int N, int n
   n = n < N ? n : N - 1;
   out[idx] = w[n * ldw8 + kt * 4 + (pc ^ swz_of<4>(r))];
 }
+
+// row-permuted variant for the persistent kernel: block row r holds plane row (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3)
+__global__ void w_block_pack_p_kernel(const u32x4* w, long long ldw8, int N, int nk, long long total, u32x4* out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int pc = (int)(idx & 3), r = (int)((idx >> 2) & 255);
+  const long long blk = idx >> 10;
+  const int kt = (int)(blk % nk);
+  const long long tn = blk / nk;
+  long long n = tn * 256 + (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);
+  n = n < N ? n : N - 1;
+  out[idx] = w[n * ldw8 + kt * 4 + (pc ^ swz_of<4>(r))];
+}
 }  // namespace mer
+
+extern "C" int mer_w_block_pack_p(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(w && out, MER_EINVAL, "mer_w_block_pack_p: null pointer");
+  MER_REQUIRE(N > 0 && N % 256 == 0 && K > 0 && K % 32 == 0 && ldw % 8 == 0, MER_ESHAPE,
+              "mer_w_block_pack_p: N must be a multiple of 256, K of 32 and ldw of 8 (N=%d K=%d ldw=%lld)", N, K, ldw);
+  MER_REQUIRE((((uintptr_t)w | (uintptr_t)out) & 15) == 0, MER_EINVAL, "mer_w_block_pack_p: planes must be 16-byte aligned");
+  const long long total = (long long)(N / 256) * (K / 32) * 1024;
+  hipLaunchKernelGGL(w_block_pack_p_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)w, ldw / 8, N, K / 32, total, (u32x4*)out);
+  return check_launch("w_block_pack_p");
+}
 
 extern "C" long long mer_w_block_bytes(int N, int K) {
   if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
@@ -215,6 +242,27 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
     p.w_hi = a->w_hi_blk;
     p.w_lo = a->w_lo_blk;
     p.w_blk = 1;
+  }
+  // the persistent 256x256 kernel (gemm16p_impl.h): one pass, its own row-permuted pre-blocked plane, whole 256-column tiles, a K loop
+  // long enough for its counted waits (8 slabs), one 16-bit plane OR fp32 (+ residual) out, every plane within 32-bit byte offsets
+  if (a->w_hi_blkp && tile == 3 && passes == 1 && g_gemm_persist && g_gemm_glds == 1 && !g_gemm_generic_epi && nbatch == 1 &&
+      a->N % 256 == 0 && a->K % 32 == 0 && a->K >= 256 && a->headmajor_T == 0 && !a->c16_lo && (!a->c16_hi != !a->c32) &&
+      (a->c16_hi ? !a->residual : true)) {
+    const long long a_last = a->a_rows_per_batch > 0
+        ? (long long)((a->M - 1) / a->a_rows_per_batch) * a->a_batch_stride + (long long)((a->M - 1) % a->a_rows_per_batch) * a->lda
+        : (long long)(a->M - 1) * a->lda;
+    const bool act_ok = a->c16_hi ? (a->act != MER_ACT_RELU) : (a->act == MER_ACT_NONE || a->act == MER_ACT_GELU);
+    bool al = (((uintptr_t)a->w_hi_blkp | (uintptr_t)a->bias) & 15) == 0;
+    if (a->c16_hi) al = al && a->ldc16 % 4 == 0 && (((uintptr_t)a->c16_hi) & 7) == 0 && 256ll * a->ldc16 * 2 < (1ll << 31);
+    if (a->c32) al = al && a->ldc32 % 4 == 0 && (((uintptr_t)a->c32) & 15) == 0 && 256ll * a->ldc32 * 4 < (1ll << 31);
+    if (a->residual) al = al && a->ldr % 4 == 0 && (((uintptr_t)a->residual) & 15) == 0 && 256ll * a->ldr * 4 < (1ll << 31);
+    if (act_ok && al && (a_last + a->K) * 2 < (1ll << 32)) {
+      p.w_hi = a->w_hi_blkp;
+      p.w_lo = nullptr;
+      p.w_blk = 2;
+      if (a->dtype == MER_DT_F16) return dispatch_p<f16>(p, st);
+      return dispatch_p<bf16>(p, st);
+    }
   }
   if (a->dtype == MER_DT_F16) return dispatch<f16>(p, nbatch, passes, tile, st);
   return dispatch<bf16>(p, nbatch, passes, tile, st);

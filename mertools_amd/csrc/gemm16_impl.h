@@ -787,7 +787,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
 
 constexpr int MX_NS = 3;   // 3 x 32 KB slab stages + 35 KB of MX group buffers
 // tuning switches (defined in gemm16.hip, set through mer_set_option)
-extern int g_gemm_skip, g_gemm_stamp, g_gemm_glds, g_gemm_generic_epi;
+extern int g_gemm_skip, g_gemm_stamp, g_gemm_glds, g_gemm_generic_epi, g_gemm_persist;
 extern unsigned long long* g_gemm_dbg;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int AP, int WP, int NS, bool MX = false>

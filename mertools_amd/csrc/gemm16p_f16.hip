@@ -1,0 +1,6 @@
+// persistent 256x256 one-pass GEMM, f16 instantiations (see gemm16p_impl.h).
+#include "gemm16p_impl.h"
+
+namespace mer {
+template <> int dispatch_p<f16>(const Gemm16Params& p, hipStream_t st) { return dispatch_p_impl<f16>(p, st); }
+}  // namespace mer

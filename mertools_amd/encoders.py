@@ -68,6 +68,7 @@ def _sd_of(model_or_sd):
 
 
 _WBLK = os.environ.get("MER_WBLK", "1") != "0"   # pre-blocked weight planes (tuning / A-B switch)
+_WBLKP = os.environ.get("MER_WBLKP", "1") != "0"   # ... and the row-permuted copy for the persistent one-pass kernel
 
 
 class _Holder:
@@ -96,6 +97,7 @@ class _Holder:
         w.mx = None
         w.hi_blk = None
         w.lo_blk = None
+        w.hi_blkp = None
         if lo:
             lo_t = lo_t.contiguous().to(self.device)
             self.keep.append(lo_t)
@@ -103,11 +105,15 @@ class _Holder:
         if t.dim() == 2 and t.shape[0] >= 192 and t.shape[1] % 32 == 0 and self.device.type == "cuda" and _WBLK:
             # pre-blocked copies for the 256-wide LDS-DMA kernels (1 KiB contiguous DMA pieces); the row-major planes stay
             # for the small-batch tiles.  Costs a second copy of the weights in HBM (a few hundred MB at most).
-            from .ops import w_block_pack
+            from .ops import w_block_pack, w_block_pack_p
             with torch.cuda.device(self.device):
                 hb = w_block_pack(hi)
                 lb = w_block_pack(lo_t) if lo and hb is not None else None
+                hp = w_block_pack_p(hi) if _WBLKP else None   # the persistent one-pass kernel's plane (rows permuted per 64)
                 torch.cuda.current_stream().synchronize()   # the forwards may run on other streams
+            if hp is not None:
+                self.keep.append(hp)
+                w.hi_blkp = hp.data_ptr()
             if hb is not None:
                 self.keep.append(hb)
                 w.hi_blk = hb.data_ptr()

@@ -57,7 +57,7 @@ def split16_host(x, dtype="f16", lo=True):
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
            out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
-           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None):
+           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, w_hi_blkp=None):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -70,7 +70,7 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.a_rows_per_batch, g.a_batch_stride = a_rows_per_batch, a_batch_stride
     g.w_hi, g.w_lo, g.ldw = _p(w_hi), _p(w_lo), w_hi.stride(0)
     g.w_mx = _p(w_mx)
-    g.w_hi_blk, g.w_lo_blk = _p(w_hi_blk), _p(w_lo_blk)
+    g.w_hi_blk, g.w_lo_blk, g.w_hi_blkp = _p(w_hi_blk), _p(w_lo_blk), _p(w_hi_blkp)
     g.bias, g.act = _p(bias), ACT[act]
     g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     dev = a_hi.device
@@ -109,6 +109,19 @@ def w_block_pack(w16):
         return None
     out = torch.empty(nbytes, dtype=torch.uint8, device=w16.device)
     _lib.check(_lib.lib().mer_w_block_pack(w16.data_ptr(), w16.stride(0), N, K, out.data_ptr(), stream()), "mer_w_block_pack")
+    return out
+
+
+def w_block_pack_p(w16):
+    """Device 16-bit plane [N, K] -> the row-permuted pre-blocked copy the PERSISTENT 256x256 one-pass kernel reads
+    (mer_w_block_pack_p: block row 16 q + i holds plane row 4 i + q of every 64-row group, so that a lane's four accumulators of an
+    output row are four consecutive columns and the epilogue stores whole lines from registers).  None when N % 256 or K % 32 != 0."""
+    assert w16.is_cuda and w16.dim() == 2 and w16.element_size() == 2 and w16.stride(1) == 1
+    N, K = w16.shape
+    if N % 256 != 0 or K % 32 != 0 or w16.stride(0) % 8 != 0:
+        return None
+    out = torch.empty(N * K * 2, dtype=torch.uint8, device=w16.device)
+    _lib.check(_lib.lib().mer_w_block_pack_p(w16.data_ptr(), w16.stride(0), N, K, out.data_ptr(), stream()), "mer_w_block_pack_p")
     return out
 
 

@@ -82,7 +82,9 @@ static void run_shape(const Shape& s, int warm, int reps) {
   void* wlo = s.passes >= 2 && s.passes != 4 ? dev_alloc((size_t)s.N * s.K * 2, 0x11) : nullptr;
   void* wblk = dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0);
   void* wlo_blk = wlo ? dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0) : nullptr;
+  void* wblkp = (s.N % 256 == 0 && s.K % 32 == 0) ? dev_alloc((size_t)s.N * s.K * 2, 0) : nullptr;   // the persistent kernel's plane
   MER(mer_w_block_pack(w, s.K, s.N, s.K, wblk, nullptr));
+  if (wblkp) MER(mer_w_block_pack_p(w, s.K, s.N, s.K, wblkp, nullptr));
   if (wlo) MER(mer_w_block_pack(wlo, s.K, s.N, s.K, wlo_blk, nullptr));
   void* wmx = nullptr;
   if (s.passes == 4) {
@@ -113,8 +115,19 @@ static void run_shape(const Shape& s, int warm, int reps) {
            s.name, s.M, s.N, s.K, s.passes, variant, us, flops / us * 1e-6);
     fflush(stdout);
   };
-  g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk;
-  report("pre-blocked W", time_gemm(g, warm, reps));
+  g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk; g.w_hi_blkp = wblkp;
+  // interleaved A/B in one process (same clocks, same box): the tile kernel (gemm16_kernel) against the persistent one, twice each
+  for (int round = 0; round < 2; ++round) {
+    MER(mer_set_option("gemm_persist", 0));
+    report("tile kernel (gemm16_kernel), pre-blocked W", time_gemm(g, warm, reps));
+    MER(mer_set_option("gemm_persist", 1));
+    if (wblkp && s.passes == 1) report("persistent kernel (gemm16p_kernel)", time_gemm(g, warm, reps));
+  }
+  if (getenv("MER_DECOMP") && wblkp && s.passes == 1) {   // where the persistent kernel's time goes: stores skipped / epilogue skipped
+    MER(mer_set_option("gemm_dbg_skip", 1)); report("persistent, stores skipped", time_gemm(g, warm, reps));
+    MER(mer_set_option("gemm_dbg_skip", 2)); report("persistent, epilogue skipped", time_gemm(g, warm, reps));
+    MER(mer_set_option("gemm_dbg_skip", 0));
+  }
   {   // cold operands: 4 rotating sets of A / residual / output planes (weights stay: they are small and shared by all row tiles)
     constexpr int R = 4;
     mer_gemm16_args gr[R];
@@ -127,10 +140,10 @@ static void run_shape(const Shape& s, int warm, int reps) {
       if (s.out32) { void* p = dev_alloc((size_t)s.M * s.N * 4, 0); extra.push_back(p); gr[r].c32 = (float*)p; }
       if (s.out16) { void* p = dev_alloc((size_t)Mp * s.N * 2, 0); extra.push_back(p); gr[r].c16_hi = p; }
     }
-    report("pre-blocked W, 4 rotating A / output planes (cold operands)", time_gemm_rot(gr, R, warm, reps));
+    report("4 rotating A / output planes (cold operands), default kernel selection", time_gemm_rot(gr, R, warm, reps));
     for (void* p : extra) CK(hipFree(p));
   }
-  for (void* p : {a, w, wlo, wblk, wlo_blk, wmx, (void*)bias, (void*)resid, (void*)c32, c16})
+  for (void* p : {a, w, wlo, wblk, wlo_blk, wblkp, wmx, (void*)bias, (void*)resid, (void*)c32, c16})
     if (p) CK(hipFree(p));
 }
 

@@ -679,3 +679,102 @@ def test_attention_cls(dev, dtype, B, T, H, lens):
             sc[b, :, n:] = float("-inf")
     ref = torch.einsum("bht,bthd->bhd", torch.softmax(sc, -1), v).reshape(B, D)
     assert_close(out.float().cpu(), ref.float(), 6e-3 if dtype == "bf16" else 8e-4, f"attention_cls B={B} T={T} H={H}")
+
+
+def test_w_block_pack_p_layout(dev):
+    """mer_w_block_pack_p: block row 16 q + i of every 64-row group holds plane row 4 i + q (the persistent kernel's lanes then own
+    4 consecutive output columns); k-slab blocking and chunk swizzle as mer_w_block_pack."""
+    ops = _ops()
+    N, K = 512, 96
+    w = torch.arange(N * K, dtype=torch.int32).to(torch.int16).view(N, K).to(dev)
+    out = ops.w_block_pack_p(w.view(torch.float16)).view(torch.int16).cpu().view(2, K // 32, 256, 4, 8)
+    wc = w.cpu()
+    for tn in range(2):
+        for kt in range(K // 32):
+            for r in (0, 1, 15, 16, 17, 47, 63, 64, 100, 255):
+                n = tn * 256 + (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3)
+                for pc in range(4):
+                    lc = pc ^ ((-(r >> 2)) & 3)
+                    assert torch.equal(out[tn, kt, r, pc], wc[n, kt * 32 + lc * 8: kt * 32 + lc * 8 + 8]), (tn, kt, r, pc)
+    assert ops.w_block_pack_p(w.view(torch.float16)[:300]) is None      # N % 256 != 0: no persistent plane
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(10240, 2048, 256), (4100, 768, 768), (66000, 512, 1536), (1500, 2304, 3072), (25600, 2304, 768)])
+def test_gemm16_persistent_equals_tile_kernel(dev, M, N, K, dtype):
+    """The persistent 256x256 one-pass kernel (gemm16p_impl.h: register-direct epilogue over a row-permuted weight plane, next tile's
+    ring issued before the stores, counted vmcnt across the tile switch) against gemm16_kernel on the same operands, bit for bit:
+    every epilogue kind it takes (16-bit out with each activation; fp32 out; fp32 + residual, also updated in place), 51 .. 900
+    tiles (0.2 .. 3.5 per workgroup: first-tile, steady-state and last-tile paths), ragged M (the predicated last row tile),
+    8 .. 96 slabs.  Launched three times each (a stale LDS read or an early store shows up as run-to-run differences)."""
+    from mertools_amd import _lib
+    if dtype == "bf16" and (M, N, K) not in ((4100, 768, 768), (25600, 2304, 768)):
+        pytest.skip("bf16 shares the code path: two shapes are enough")
+    ops = _ops()
+    lib = _lib.lib()
+    a = _rand((M, K), 91)
+    w = _rand((N, K), 92) * 0.05
+    ah, _ = ops.split16(a.to(dev), dtype, lo=False)
+    wh = ops.split16_host(w, dtype)[0].to(dev)
+    hb, hp = ops.w_block_pack(wh), ops.w_block_pack_p(wh)
+    assert hp is not None
+    bias, res = _rand((N,), 93).to(dev), _rand((M, N), 94).to(dev)
+    cases = [dict(out16=True, act=act, bias=bias) for act in (None, "gelu", "quick_gelu", "gelu_new")]
+    cases += [dict(out16=True, act=None, bias=None)]
+    cases += [dict(out32=True, act=act, bias=bias) for act in (None, "gelu")]
+    cases += [dict(out32=True, act=act, bias=bias, residual=res) for act in (None, "gelu")]
+    for kw in cases:
+        kw = dict(kw, passes=1, tile=3, dtype=dtype)
+        try:
+            lib.mer_set_option(b"gemm_persist", 0)
+            r32, r16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, **kw)
+        finally:
+            lib.mer_set_option(b"gemm_persist", 1)
+        for rep in range(3):
+            c32, c16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, **kw)
+            torch.cuda.synchronize()
+            what = f"persistent gemm16 {kw.get('act')} out16={kw.get('out16', False)} res={'residual' in kw} rep {rep}"
+            if r16 is not None:
+                assert torch.equal(c16.view(torch.int16), r16.view(torch.int16)), what
+            if r32 is not None:
+                assert torch.equal(c32, r32), what
+    # in-place residual (the pre-LN residual stream: residual == c32)
+    inplace = res.clone()
+    g = ops.GemmArgs()
+    g.M, g.N, g.K, g.dtype = M, N, K, ops.dt_code(dtype)
+    g.a_hi, g.lda, g.w_hi, g.ldw = ah.data_ptr(), K, wh.data_ptr(), K
+    g.w_hi_blk, g.w_hi_blkp = hb.data_ptr(), hp.data_ptr()
+    g.bias, g.act, g.residual, g.ldr, g.c32, g.ldc32 = bias.data_ptr(), ops.ACT[None], inplace.data_ptr(), N, inplace.data_ptr(), N
+    g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, 1, 3
+    ops.gemm16_raw(g)
+    ref32, _, _ = ops.gemm16(ah, wh, w_hi_blk=hb, bias=bias, residual=res, out32=True, passes=1, tile=3, dtype=dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(inplace, ref32), "persistent gemm16, residual updated in place"
+    true = a.double() @ w.double().T + bias.cpu().double() + res.cpu().double()
+    assert_close(ref32.cpu(), true.float(), 1e-3 if dtype == "f16" else 8e-3, "persistent gemm16 vs fp64")
+
+
+def test_gemm16_persistent_conv_rows(dev):
+    """Implicit-im2col row mapping (HuBERT's strided Conv1d over channels-last planes: overlapping windows, a_rows_per_batch /
+    a_batch_stride) through the persistent kernel == the tile kernel, bit for bit, with the GELU epilogue of the conv stack."""
+    from mertools_amd import _lib
+    ops = _ops()
+    lib = _lib.lib()
+    B, Tin, C, k, s = 24, 1599, 512, 3, 2
+    Tout = (Tin - k) // s + 1
+    x = _rand((B * Tin, C), 95)
+    w = _rand((C, k * C), 96) * 0.03
+    xh, _ = ops.split16(x.to(dev), "f16", lo=False)
+    wh = ops.split16_host(w, "f16")[0].to(dev)
+    hb, hp = ops.w_block_pack(wh), ops.w_block_pack_p(wh)
+    kw = dict(act="gelu", out16=True, passes=1, tile=3, M=B * Tout, lda=s * C, a_rows_per_batch=Tout, a_batch_stride=Tin * C)
+    try:
+        lib.mer_set_option(b"gemm_persist", 0)
+        _, ref, _ = ops.gemm16(xh, wh, w_hi_blk=hb, w_hi_blkp=hp, **kw)
+    finally:
+        lib.mer_set_option(b"gemm_persist", 1)
+    _, out, _ = ops.gemm16(xh, wh, w_hi_blk=hb, w_hi_blkp=hp, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    win = x.view(B, Tin, C).unfold(1, k, s).permute(0, 1, 3, 2).reshape(B * Tout, k * C)    # [B, Tout, C, k] -> (kk, ci) order
+    assert_close(out.float().cpu(), F.gelu(win.double() @ w.double().T).float(), 2e-3, "persistent conv GEMM vs fp64")

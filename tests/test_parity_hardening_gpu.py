@@ -1,0 +1,153 @@
+"""Heterogeneous batches and batch-composition invariance of the shipped presets (GPU, base-size encoders).
+
+The reference runs batch 1 in fp32 (MERBench/feature_extraction/audio/extract_audio_huggingface.py:93-110,
+visual/extract_vision_huggingface.py:118-122, text/extract_text_huggingface.py:225-249): a clip's features are a function of the clip.
+Every other GPU parity test batches i.i.d. clips.  Here a clip sits among 63 clips that look nothing like it (tones / digital
+silence, flat grey frames, one repeated token) and is compared — per clip, UTT and FRAME, 1e-3 — with its own oracle forward; and the
+same 64 clips are extracted as one batch of 64 and as eight batches of 8 (what sharding over 8 GPUs does to a batch)."""
+import math
+
+import pytest
+import torch
+
+from oracle import encoders_ref as R
+from oracle import weights as W
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+PRESETS = ["default", "mx"]
+
+
+def _kw(preset):
+    return {} if preset == "default" else {"precision": preset}
+
+
+def _norm(wav):
+    """Wav2Vec2FeatureExtractor normalisation (extract_audio_huggingface.py:94); digital silence stays zero."""
+    return (wav - wav.mean(1, keepdim=True)) / torch.sqrt(wav.var(1, unbiased=False, keepdim=True) + 1e-7)
+
+
+def _audio_mix(B, L=80000, seed=5001):
+    """clip 0: noise (what every other test feeds); 1 .. B/2: tones of different pitch; the rest: digital silence."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(L, dtype=torch.float32) / 16000.0
+    rows = [0.1 * torch.randn(L, generator=g)]
+    for b in range(1, B):
+        if b <= B // 2:
+            rows.append(0.3 * torch.sin(2 * math.pi * (110.0 * (1 + b % 7)) * t))
+        else:
+            rows.append(torch.zeros(L))
+    return _norm(torch.stack(rows))
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_hubert_noise_clip_among_tones_and_silence(dev, preset):
+    from mertools_amd.encoders import HipHubertModel
+    cfg = W.hubert_config("base")
+    sd = W.hubert_state_dict(cfg, 0)
+    B = 64
+    wav = _audio_mix(B)
+    m = HipHubertModel(sd, cfg, device=dev, **_kw(preset))
+    _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
+    torch.cuda.synchronize()
+    fr = fr.cpu().view(B, 249, 768)
+    worst = {}
+    for b in (0, 1, B - 1):      # the noise clip, a tone, a silent clip: each against its own batch-of-one oracle forward
+        hs = R.hubert_hidden_states(sd, vars(cfg), wav[b:b + 1])
+        feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)[0]
+        worst[b] = (rel_err(pooled[b].cpu(), feat.mean(0))[0], rel_err(fr[b], feat)[0])
+    print(f"hubert-base noise clip among tones / silence [{m.precision}]: " +
+          "  ".join(f"clip{b}: utt={u:.2e} frame={f:.2e}" for b, (u, f) in worst.items()))
+    for b, (u, f) in worst.items():
+        assert u <= TOL and f <= TOL, (preset, b, u, f)
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_roberta_sentence_among_repeated_tokens(dev, preset):
+    from mertools_amd.encoders import HipBertModel
+    cfg = W.bert_config("roberta-base")
+    sd = W.bert_state_dict(cfg, 0)
+    B, T = 16, 64
+    ids = W.synth_tokens(B, T, seed=5002)
+    for b in range(1, B):        # one real sentence among 15 that repeat a single token
+        ids[b, 1:-1] = 1000 + 37 * b
+    m = HipBertModel(sd, cfg, device=dev, **_kw(preset))
+    _, fr, pooled = m.forward_raw(ids.to(dev), lengths=[T] * B, frames=True, seg_start=[b * T + 1 for b in range(B)], seg_len=[T - 2] * B)
+    torch.cuda.synchronize()
+    fr = fr.cpu().view(B, T, -1)
+    out = {}
+    for b in (0, 1):
+        ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids[b:b + 1], torch.ones_like(ids[b:b + 1]))
+        feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)[0]
+        out[b] = (rel_err(pooled[b].cpu(), feat[1:-1].mean(0))[0], rel_err(fr[b], feat)[0])
+    print(f"roberta-base sentence among repeated tokens [{preset}]: " + "  ".join(f"row{b}: utt={u:.2e} frame={f:.2e}" for b, (u, f) in out.items()))
+    for b, (u, f) in out.items():
+        assert u <= TOL and f <= TOL, (preset, b, u, f)
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_clip_textured_frames_among_grey(dev, preset):
+    from mertools_amd.encoders import HipCLIPModel
+    cfg = W.clip_config("base16")
+    sd = W.clip_state_dict(cfg, 0)
+    N = 64
+    px = W.synth_frames(N, seed=5003)
+    grey = ((torch.full((3,), 0.5) - torch.tensor([0.48145466, 0.4578275, 0.40821073])) / torch.tensor([0.26862954, 0.26130258, 0.27577711]))
+    px[8:] = grey.view(1, 3, 1, 1)      # 8 textured frames among 56 flat grey ones
+    m = HipCLIPModel(sd, cfg, device=dev, **_kw(preset))
+    out = m.get_image_features(px.to(dev)).cpu()
+    torch.cuda.synchronize()
+    vcfg = dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim)
+    ref = R.clip_image_features(sd, vcfg, px[:9])
+    e_tex = max(rel_err(out[i], ref[i])[0] for i in range(8))
+    e_grey = rel_err(out[8], ref[8])[0]
+    e_utt = rel_err(out[:8].mean(0), ref[:8].mean(0))[0]
+    print(f"clip-B/16 textured frames among grey [{preset}]: worst frame={e_tex:.2e} grey frame={e_grey:.2e} utt(8 frames)={e_utt:.2e}")
+    assert e_tex <= TOL and e_grey <= TOL and e_utt <= TOL, (preset, e_tex, e_grey, e_utt)
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+@pytest.mark.parametrize("kind", ["hubert", "roberta", "clip"])
+def test_features_do_not_depend_on_the_batch_split(dev, kind, preset):
+    """The same 64 clips as one batch of 64 and as eight batches of 8 (clip-sharding over 8 GPUs, SURVEY §8e: "bit-parity with
+    single-GPU").  Reported and bounded: the difference must stay an order of magnitude under the parity bar."""
+    from mertools_amd.encoders import HipBertModel, HipCLIPModel, HipHubertModel
+    if kind == "hubert":
+        cfg = W.hubert_config("base")
+        m = HipHubertModel(W.hubert_state_dict(cfg, 0), cfg, device=dev, **_kw(preset))
+        x = _audio_mix(64, seed=5004)
+        x[32:] = W.synth_audio(32, 80000, seed=5005)       # half heterogeneous, half noise
+
+        def run(xb):
+            B = xb.shape[0]
+            _, fr, pooled = m.forward_raw(xb.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
+            return pooled.cpu(), fr.cpu().view(B, 249, -1)
+    elif kind == "roberta":
+        cfg = W.bert_config("roberta-base")
+        m = HipBertModel(W.bert_state_dict(cfg, 0), cfg, device=dev, **_kw(preset))
+        x = W.synth_tokens(64, 64, seed=5006)
+        for b in range(0, 64, 4):
+            x[b, 1:-1] = 2000 + b
+
+        def run(xb):
+            B = xb.shape[0]
+            _, fr, pooled = m.forward_raw(xb.to(dev), lengths=[64] * B, frames=True, seg_start=[b * 64 + 1 for b in range(B)], seg_len=[62] * B)
+            return pooled.cpu(), fr.cpu().view(B, 64, -1)
+    else:
+        cfg = W.clip_config("base16")
+        m = HipCLIPModel(W.clip_state_dict(cfg, 0), cfg, device=dev, **_kw(preset))
+        x = W.synth_frames(64, seed=5007)
+        x[::3] = 0.0
+
+        def run(xb):
+            f = m.get_image_features(xb.to(dev)).cpu()
+            return f, f[:, None, :]
+    u1, f1 = run(x)
+    parts = [run(x[i:i + 8]) for i in range(0, 64, 8)]
+    torch.cuda.synchronize()
+    u8, f8 = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    du = max(rel_err(u8[b], u1[b])[0] for b in range(64))
+    df = max(rel_err(f8[b], f1[b])[0] for b in range(64))
+    print(f"{kind}-base 1x64 vs 8x8 batches [{preset}]: worst clip utt diff={du:.2e} frame diff={df:.2e}")
+    assert du <= 1e-4 and df <= 2e-4, (kind, preset, du, df)
