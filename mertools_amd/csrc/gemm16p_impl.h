@@ -30,13 +30,13 @@ namespace mer {
 
 constexpr int P_RING = 4 * 32768;          // 4 stages x (A 16 KB + W 16 KB)
 constexpr int P_BIAS = 2 * 8 * 1024;       // bias row of the tile (256 fp32), one private copy per wave, two tile parities
-constexpr int P_SMEM = P_RING + P_BIAS;
+constexpr int P_STAMP = 2 * 12 * 16 * 8;   // timeline stamps (mer_set_debug_buffer): 2 wave groups x 12 tiles x 16 slots, dumped at exit
+constexpr int P_SMEM = P_RING + P_BIAS + P_STAMP;
 
-// counted wait with the epilogue's still-in-flight stores (sx = 0, 8 or 32, wave-uniform) added to the allowance
+// counted wait with the epilogue's still-in-flight stores (sx = 0 or 32, wave-uniform) added to the allowance
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_plus(int sx) {
   if (sx == 32) wait_vmcnt<N + 32>();
-  else if (sx == 8) wait_vmcnt<N + 8>();
   else wait_vmcnt<N>();
 }
 
@@ -158,12 +158,13 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     if (p.bias) bq = *reinterpret_cast<const f32x4*>(smem + P_RING + par * 8192 + wave * 1024 + (wn * 64 + li * 4) * 4);
     const bool interior = tm_ * 256 + 256 <= p.M;   // (N % 256 == 0: no column edge)
     if (interior) {
+      // Plain (compiler-scheduled) loads and stores: hipcc counts its own memory operations exactly (vmcnt(N) names the N youngest
+      // operations that may stay in flight, so the LDS-DMA requests it knows nothing about — all older — do not disturb its
+      // counts), and hand-written asm loads are not safe here: the register allocator copied their destination registers before
+      // the data had landed.  What the K loop needs from this function is only an upper bound on the stores it leaves in flight.
       const bool st = (p.dbg_skip & 3) != 1;
-      // one uniform base per tile (SGPR pair) + a per-lane byte offset that walks down the rows (one v_add per store): 32 separate
-      // scalar bases cost 64 SGPRs per epilogue copy and spilled
       if constexpr (EPI == 0) {
-        const unsigned long long cb = uniform64((unsigned long long)((T*)p.c16_hi + (long long)m0 * p.ldc16 + n0));
-        asm volatile("s_nop 4" :: "s"(cb));   // v_readfirstlane -> SGPR -> VMEM address: 5 wait states (hipcc does not pad an asm statement)
+        char* cb = (char*)((T*)p.c16_hi + (long long)m0 * p.ldc16 + n0);
         const unsigned rstep = (unsigned)p.ldc16 * 2;
         unsigned vo = opaque((unsigned)(4 * lg) * rstep + li * 8);
 #pragma unroll
@@ -173,15 +174,14 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
             typename T16<T>::v4 h;
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) h[nt] = T16<T>::from_f32(act_apply(acc[mt][nt][r] + bq[nt], ACT));
-            if (st) gstore8_nt_s(cb, vo, __builtin_bit_cast(u32x2, h));
+            if (st) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, h), reinterpret_cast<u32x2*>(cb + vo));
             vo += rstep;
           }
           vo += 12 * rstep;
         }
         return st ? 32 : 0;
       } else {
-        const unsigned long long cb = uniform64((unsigned long long)(p.c32 + (long long)m0 * p.ldc32 + n0));
-        asm volatile("s_nop 4" :: "s"(cb));   // v_readfirstlane -> SGPR -> VMEM address: 5 wait states (hipcc does not pad an asm statement)
+        char* cb = (char*)(p.c32 + (long long)m0 * p.ldc32 + n0);
         const unsigned cstep = (unsigned)p.ldc32 * 4;
         unsigned vo = opaque((unsigned)(4 * lg) * cstep + li * 16);
         if constexpr (EPI == 1) {
@@ -192,60 +192,40 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
               f32x4 v;
 #pragma unroll
               for (int nt = 0; nt < TN; ++nt) v[nt] = act_apply(acc[mt][nt][r] + bq[nt], ACT);
-              if (st) gstore16_s(cb, vo, v);
+              if (st) *reinterpret_cast<f32x4*>(cb + vo) = v;
               vo += cstep;
             }
             vo += 12 * cstep;
           }
           return st ? 32 : 0;
         } else {
-          // residual rows one row tile (4 loads) at a time, two row tiles in flight; every wait names the operations issued after
-          // the loads it needs: the next row tile's 4 loads and the previous one's 4 stores
-          const unsigned long long rb = uniform64((unsigned long long)(p.residual + (long long)m0 * p.ldr + n0));
-          asm volatile("s_nop 4" :: "s"(rb));
+          // residual rows two row tiles (8 loads) ahead of the stores; the residual may BE the output (the pre-LN stream is updated
+          // in place), so the compiler keeps this source order: loads of row tile mt + 2 are issued before the stores of row tile mt
+          const char* rb = (const char*)(p.residual + (long long)m0 * p.ldr + n0);
           const unsigned rstep = (unsigned)p.ldr * 4;
           unsigned ro = opaque((unsigned)(4 * lg) * rstep + li * 16);
-          f32x4 ra[4], rb2[4];
-          auto issue = [&](f32x4 (&dst)[4]) __attribute__((always_inline)) {
+          f32x4 rr[3][4];
+          auto issue = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { gload16_s(dst[r], rb, ro); ro += rstep; }
+            for (int r = 0; r < 4; ++r) { rr[slot][r] = *reinterpret_cast<const f32x4*>(rb + ro); ro += rstep; }
             ro += 12 * rstep;
           };
-          auto finish = [&](f32x4 (&src)[4], int mt) __attribute__((always_inline)) {
+          issue(0);
+          issue(1);
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) {
+            if (mt + 2 < TM) issue((mt + 2) % 3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               f32x4 v;
 #pragma unroll
-              for (int nt = 0; nt < TN; ++nt) v[nt] = act_apply(acc[mt][nt][r] + bq[nt], ACT) + src[r][nt];
-              if (st) gstore16_s(cb, vo, v);
+              for (int nt = 0; nt < TN; ++nt) v[nt] = act_apply(acc[mt][nt][r] + bq[nt], ACT) + rr[mt % 3][r][nt];
+              if (st) *reinterpret_cast<f32x4*>(cb + vo) = v;
               vo += cstep;
             }
             vo += 12 * cstep;
-          };
-#define MER_WAIT4(N, a) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: "memory")
-          issue(ra);
-          issue(rb2);
-          if (st) {
-            MER_WAIT4(4, ra);  finish(ra, 0);  issue(ra);      // younger than row tile 0's loads: row tile 1's
-            MER_WAIT4(8, rb2); finish(rb2, 1); issue(rb2);     // ... than row tile 1's: stores 0 + loads 2
-            MER_WAIT4(8, ra);  finish(ra, 2);  issue(ra);
-            MER_WAIT4(8, rb2); finish(rb2, 3); issue(rb2);
-            MER_WAIT4(8, ra);  finish(ra, 4);  issue(ra);
-            MER_WAIT4(8, rb2); finish(rb2, 5); issue(rb2);
-            MER_WAIT4(8, ra);  finish(ra, 6);                  // ... than row tile 6's: stores 5 + loads 7
-            MER_WAIT4(4, rb2); finish(rb2, 7);                 // ... than row tile 7's: stores 6
-          } else {   // timing decomposition (stores skipped): loads only
-            MER_WAIT4(4, ra);  finish(ra, 0);  issue(ra);
-            MER_WAIT4(4, rb2); finish(rb2, 1); issue(rb2);
-            MER_WAIT4(4, ra);  finish(ra, 2);  issue(ra);
-            MER_WAIT4(4, rb2); finish(rb2, 3); issue(rb2);
-            MER_WAIT4(4, ra);  finish(ra, 4);  issue(ra);
-            MER_WAIT4(4, rb2); finish(rb2, 5); issue(rb2);
-            MER_WAIT4(4, ra);  finish(ra, 6);
-            MER_WAIT4(0, rb2); finish(rb2, 7);
           }
-#undef MER_WAIT4
-          return st ? 8 : 0;   // everything but the last two row tiles' stores has retired (the wait for row tile 7's loads)
+          return st ? 32 : 0;
         }
       }
     }
@@ -300,7 +280,17 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   int sx = 0;                       // stores of the last epilogue that the next counted waits may leave in flight
   int ptm = 0, ptn = 0;             // group 1: the tile whose accumulators it still holds
   bool have_prev = false;
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+  // timeline instrumentation (tuning runs only): lane 0 of waves 0 and 4 stamps s_memtime into LDS (no VMEM traffic that would
+  // disturb the counted waits), slots: 0 tile start, 1-8 past the mid barrier of slabs 0-7, 9 K loop done, 10 next ring issued,
+  // 11 epilogue done, 12 past X' ; group 1: 13 / 14 around its in-loop epilogue
+  unsigned long long* stl = reinterpret_cast<unsigned long long*>(smem + P_RING + P_BIAS);
+  auto stamp = [&](int slot) __attribute__((always_inline)) {
+    if (p.dbg && (wave & 3) == 0 && seq < 12 && lane == 0) stl[((wave >> 2) * 12 + seq) * 16 + slot] = __builtin_amdgcn_s_memtime();
+  };
+  if (p.dbg) {
+    for (int i = tid; i < P_STAMP / 8; i += 512) stl[i] = 0;
+    __builtin_amdgcn_s_barrier();
+  }
 
   for (;;) {
     const int Ln = L + (int)gridDim.x;
@@ -308,11 +298,14 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     int ntm = 0, ntn = 0;
     if (has_next) tile_of(Ln, ntm, ntn);
     if (g1) __builtin_amdgcn_s_barrier();   // A0: group 1 runs one phase behind
+    stamp(0);
     for (int kt = 0; kt < nk; ++kt) {
       if (kt >= 1 && kt + 3 < nk) glds_slab(kt + 3, (kt + 3) & 3);   // into the stage slab kt - 1 was read from
       if (kt == 0 && g1) {                  // group 1's epilogue of the previous tile, beside group 0's first MATH phase
         __builtin_amdgcn_sched_barrier(0);
+        stamp(13);
         if (have_prev) sx = epilogue(ptm, ptn, (seq + 1) & 1);
+        stamp(14);
         __builtin_amdgcn_sched_barrier(0);   // the fresh accumulators must not be live beside the ones being stored
         zero_acc();
         __builtin_amdgcn_sched_barrier(0);
@@ -322,10 +315,17 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
       if (kt + 3 < nk) {
         if (kt < 3) wait_vmcnt_plus<8>(sx);
         else wait_vmcnt<8>();
-      } else wait_vmcnt<0>();
+      } else {
+        wait_vmcnt<0>();
+        // ... and tell hipcc's scoreboard so: it still believes the previous epilogue's stores (and loads on paths not taken) are in
+        // flight and would otherwise protect their registers with a near-zero vmcnt in front of the next epilogue — i.e. right
+        // behind the ring issue, waiting for 16 KiB of DMA to land before the first store
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) expcnt(7) lgkmcnt(15)
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();         // mid
+      if (kt < 8) stamp(1 + kt);
       if (kt == nk - 1 && g1 && has_next) issue_ring(ntn, ntm * 256, (seq + 1) & 1);   // every LDS read of this tile is over
       __builtin_amdgcn_s_setprio(1);
       math();
@@ -337,16 +337,20 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
         }
       } else __builtin_amdgcn_s_barrier();  // end
     }
+    stamp(9);
     if (!g1 || !has_next) {   // group 0: every tile, right behind its last MATH phase; group 1: only the last tile's (one call site less)
       if (has_next) issue_ring(ntn, ntm * 256, (seq + 1) & 1);
+      stamp(10);
       __builtin_amdgcn_sched_barrier(0);
       sx = epilogue(tm, tn, seq & 1);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(11);
       if (has_next) {
         zero_acc();
         wait_vmcnt_plus<12>(sx);
         __builtin_amdgcn_s_barrier();       // X'
       }
+      stamp(12);
     } else {
       ptm = tm; ptn = tn; have_prev = true;
       sx = 0;
@@ -355,7 +359,10 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     if (!has_next) break;
     L = Ln; tm = ntm; tn = ntn;
   }
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  if (p.dbg) {
+    __syncthreads();
+    for (int i = tid; i < P_STAMP / 8; i += 512) p.dbg[(long long)blockIdx.x * (P_STAMP / 8) + i] = stl[i];
+  }
 }
 
 int device_cu_count();

@@ -150,6 +150,8 @@ def dropout(x, p, training):
 
 
 def linear(x, lin, relu=False):
+    if lin.out_features == 0:   # MER2024: output_dim2 = 0 -> nn.Linear(hidden, 0), an empty [B, 0] head (no kernel to launch)
+        return x.new_zeros((x.shape[0], 0))
     return LinearFn.apply(x, lin.weight, lin.bias, relu)
 
 

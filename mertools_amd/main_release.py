@@ -140,6 +140,11 @@ def build_parser():
     p.add_argument('--epochs', type=int, default=100)
     p.add_argument('--print_iters', type=int, default=1e8)
     p.add_argument('--gpu', default=0, type=int)
+    # MER2024/main-release.py:96-99: noise-robustness and multi-feature fusion studies
+    p.add_argument('--train_snr', type=lambda x: None if x == 'None' else str(x), default=None, help='train snr (selects the feature directory)')
+    p.add_argument('--test_snr', type=lambda x: None if x == 'None' else str(x), default=None, help='test snr (selects the feature directory)')
+    p.add_argument('--fusion_topn', type=int, default=None, help='attention_topn: feature sets per modality slot')
+    p.add_argument('--fusion_modality', type=str, default='AVT', help='attention_topn: AVT | AV | AT | VT')
     # additions (not in the reference)
     p.add_argument('--seed', type=int, default=None, help='seed python/numpy/torch RNGs (the reference never seeds)')
     p.add_argument('--hip_adam', action='store_true', default=False, help='optimizer step (and grad clip) in one HIP kernel per tensor')
@@ -170,6 +175,10 @@ def main(argv=None):
         args.save_root = f'{args.save_root}-cross'
     whole_features = [f for f in [args.audio_feature, args.text_feature, args.video_feature] if f is not None]
     args.save_root += {0: '-others', 1: '-unimodal', 2: '-bimodal', 3: '-trimodal'}[len(set(whole_features))]
+    if args.test_snr is not None:       # MER2024/main-release.py:151-154
+        args.save_root = f'{args.save_root}-noise'
+    if args.fusion_topn is not None:
+        args.save_root = f'{args.save_root}-multitop'
     tune = args.hyper_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'toolkit', 'model-tune.yaml')
     with open(tune) as fh:
         model_config = dict(yaml.safe_load(fh)[args.model])
@@ -184,6 +193,10 @@ def main(argv=None):
     os.makedirs(save_modelroot, exist_ok=True)
     feature_name = "+".join(sorted(set(whole_features)))
     prefix_name = f'features:{feature_name}_dataset:{args.dataset}_model:{args.model}+{args.feat_type}+{args.e2e_name}'
+    if args.test_snr is not None:       # MER2024/main-release.py:188-191
+        prefix_name += f'_trainsnr:{args.train_snr}_testsnr:{args.test_snr}'
+    if args.fusion_topn is not None:
+        prefix_name += f'_fusiontopn:{args.fusion_topn}_modality:{args.fusion_modality}'
 
     print('====== Reading Data =======')
     dataloader_class = get_dataloaders(args)
@@ -252,7 +265,10 @@ def main(argv=None):
         _, test_result = dataloader_class.calculate_results(emo_probs, emo_labels, val_preds, val_labels)
         save_path = f'{save_resroot}/test{jj + 1}_{prefix_name}_{test_result}_{name_time}.npz'
         print(f'save results in {save_path}')
-        np.savez_compressed(save_path, args=np.array(args, dtype=object))
+        if args.dataset == 'MER2024':   # MER2024/main-release.py:288-290 also stores the fold-averaged test probabilities
+            np.savez_compressed(save_path, emo_probs=emo_probs, args=np.array(args, dtype=object))
+        else:
+            np.savez_compressed(save_path, args=np.array(args, dtype=object))
     return folder_save
 
 

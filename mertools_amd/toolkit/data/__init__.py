@@ -2,9 +2,11 @@
 from torch.utils.data import Dataset
 
 from .feat_data import Data_Feat
+from .feat_data_topn import Data_Feat_TOPN
 
 MODEL_DATASET_MAP = {k: Data_Feat for k in ['attention', 'lf_dnn', 'lmf', 'misa', 'mmim', 'tfn', 'mfn', 'graph_mfn',
                                             'ef_lstm', 'mfm', 'mctn', 'mult']}
+MODEL_DATASET_MAP['attention_topn'] = Data_Feat_TOPN     # MER2024/toolkit/data/__init__.py:27: several feature sets per modality
 
 
 class get_datasets(Dataset):

@@ -15,9 +15,14 @@ class Data_Feat(Dataset):
     def __init__(self, args, names, labels):
         self.names, self.labels = names, labels
         feat_root = config.PATH_TO_FEATURES[args.dataset]
-        audio_root = os.path.join(feat_root, args.audio_feature)
-        text_root = os.path.join(feat_root, args.text_feature)
-        video_root = os.path.join(feat_root, args.video_feature)
+        # MER2024's noise-robustness runs (MER2024/toolkit/data/feat_data.py:13-22): `args.snr` re-points every modality at
+        # <model><sep><snr><sep>UTT, <sep> being the separator the feature name already uses before its UTT suffix
+        snr = getattr(args, 'snr', None)
+
+        def root_of(name):
+            return os.path.join(feat_root, name if snr is None else f'{name[:-4]}{name[-4]}{snr}{name[-4]}UTT')
+
+        audio_root, text_root, video_root = root_of(args.audio_feature), root_of(args.text_feature), root_of(args.video_feature)
         print(f'audio feature root: {audio_root}')
         self.feat_type, self.feat_scale = args.feat_type, args.feat_scale
         assert self.feat_scale >= 1

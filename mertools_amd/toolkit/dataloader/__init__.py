@@ -1,8 +1,9 @@
-"""get_dataloaders(args) — mirror of MERBench/toolkit/dataloader/__init__.py:14-42 for the corpora on the hot
-path (MER2023; MER2024 shares the class).  Other corpora keep the same pattern and are out of scope."""
+"""get_dataloaders(args) — mirror of MERBench/toolkit/dataloader/__init__.py:14-42 (MER2024/toolkit/dataloader/__init__.py for
+the MER2024 entry) for the corpora on the hot path.  Other corpora keep the same pattern and are out of scope."""
 from .mer2023 import MER2023
+from .mer2024 import MER2024
 
-DATALOADER_MAP = {'MER2023': MER2023}
+DATALOADER_MAP = {'MER2023': MER2023, 'MER2024': MER2024}
 
 
 class get_dataloaders:

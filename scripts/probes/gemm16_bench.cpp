@@ -19,6 +19,7 @@
 #define MER(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s:%d rc=%d %s\n", __FILE__, __LINE__, rc_, mer_last_error()); exit(101); } } while (0)
 
 extern "C" int mer_set_option(const char* name, int value);
+extern "C" int mer_set_debug_buffer(void* device_u64_buffer);
 
 struct Shape { const char* name; int M, N, K; int passes; int act; bool residual, out32, out16; };
 
@@ -122,6 +123,24 @@ static void run_shape(const Shape& s, int warm, int reps) {
     report("tile kernel (gemm16_kernel), pre-blocked W", time_gemm(g, warm, reps));
     MER(mer_set_option("gemm_persist", 1));
     if (wblkp && s.passes == 1) report("persistent kernel (gemm16p_kernel)", time_gemm(g, warm, reps));
+  }
+  if (const char* sd = getenv("MER_STAMP")) if (wblkp && s.passes == 1) {   // s_memtime timeline of the persistent kernel (gemm16p_impl.h: stamp slots)
+    const size_t nb = 256 * 384 * 8;
+    void* dbg = dev_alloc(nb, 0);
+    MER(mer_set_option("gemm_persist", 1));
+    for (int i = 0; i < 5; ++i) MER(mer_gemm16(&g, nullptr));
+    MER(mer_set_debug_buffer(dbg));
+    MER(mer_gemm16(&g, nullptr));
+    CK(hipDeviceSynchronize());
+    MER(mer_set_debug_buffer(nullptr));
+    std::vector<char> host(nb);
+    CK(hipMemcpy(host.data(), dbg, nb, hipMemcpyDeviceToHost));
+    char fn[512];
+    static int idx = 0;
+    snprintf(fn, sizeof(fn), "%s/stamps_%02d.bin", sd, idx++);
+    if (FILE* f = fopen(fn, "wb")) { fwrite(host.data(), 1, nb, f); fclose(f); }
+    printf("{\"shape\": \"%s\", \"stamps\": \"%s\"}\n", s.name, fn);
+    CK(hipFree(dbg));
   }
   if (getenv("MER_DECOMP") && wblkp && s.passes == 1) {   // where the persistent kernel's time goes: stores skipped / epilogue skipped
     MER(mer_set_option("gemm_dbg_skip", 1)); report("persistent, stores skipped", time_gemm(g, warm, reps));

@@ -259,9 +259,72 @@ def hf_goldens():
     np.savez_compressed(os.path.join(OUT, "encoders_tiny_hf.npz"), **res)
 
 
+def mer2024_goldens():
+    """MER2024's dataloader class and Attention_TOPN, run from the reference's own sources (MER2024/toolkit/dataloader/mer2024.py,
+    MER2024/toolkit/models/attention_topn.py) on a small synthetic label file (the reference ships none for MER2024)."""
+    ref_toolkit()
+    from sklearn.metrics import accuracy_score, f1_score, mean_squared_error
+    emos = ['neutral', 'angry', 'happy', 'sad', 'worried', 'surprise']
+    rng = np.random.RandomState(2024)
+    train = {f"sample_{i:05d}": {"emo": emos[rng.randint(0, 6)], "val": float(rng.randn())} for i in range(137)}
+    test1 = {f"test_{i:05d}": {"emo": emos[rng.randint(0, 6)]} for i in range(31)}
+    label_path = os.path.join(OUT, "mer2024_label-6way.npz")
+    np.savez_compressed(label_path, train_corpus=train, test1_corpus=test1)
+    cfg = argparse.Namespace(PATH_TO_LABEL={"MER2024": label_path})
+    ns = {"np": np, "random": random, "accuracy_score": accuracy_score, "f1_score": f1_score, "mean_squared_error": mean_squared_error,
+          "emo2idx_mer": {e: i for i, e in enumerate(emos)}, "config": cfg}
+    exec_defs(REF + "/MER2024/toolkit/dataloader/mer2024.py", {"MER2024"}, ns)
+    args = argparse.Namespace(debug=False, batch_size=32, num_workers=0, dataset="MER2024")
+    obj = ns["MER2024"](args)
+    res = dict(output_dim1=np.array(args.output_dim1), output_dim2=np.array(args.output_dim2), metric_name=np.array(args.metric_name))
+    for split in ["train", "test1"]:
+        names, labels = obj.read_names_labels(label_path, split)
+        res[f"labels_{split}_names"] = np.array(names)
+        res[f"labels_{split}_emo"] = np.array([l["emo"] for l in labels], dtype=np.int64)
+        res[f"labels_{split}_val"] = np.array([float(l["val"]) for l in labels], dtype=np.float64)
+    res["debug_n"] = np.array(len(obj.read_names_labels(label_path, "train", debug=True)[0]))
+    random.seed(2024)
+    for i, (tr, ev) in enumerate(obj.random_split_indexes(137, 5)):
+        res[f"fold{i}_train"] = np.array(tr, dtype=np.int64)
+        res[f"fold{i}_eval"] = np.array(ev, dtype=np.int64)
+    probs, labs = rng.rand(40, 6), rng.randint(0, 6, 40)
+    r, sres = obj.calculate_results(probs, labs, [], [])
+    res.update(metric_probs=probs, metric_labs=labs, metric_acc=np.array(r["emoacc"]), metric_f1=np.array(r["emofscore"]),
+               metric_str=np.array(sres), metric_keys=np.array(sorted(r)))
+    # the model-selection metric under metric_name == 'emo' (MER2024/toolkit/utils/metric.py:22-24)
+    nsm = {"np": np}
+    exec_defs(REF + "/MER2024/toolkit/utils/metric.py", {"gain_metric_from_results", "overall_metric", "gain_cv_results"}, nsm)
+    res["metric_emo"] = np.array(nsm["gain_metric_from_results"](r, "emo"))
+    res["cv_str"] = np.array(nsm["gain_cv_results"]([{"eval_emofscore": 0.5, "eval_emoacc": 0.25}, {"eval_emofscore": 0.75, "eval_emoacc": 0.5}]))
+    np.savez_compressed(os.path.join(OUT, "index_paths_mer2024.npz"), **res)
+
+    # Attention_TOPN: 2 feature sets per modality slot (6 streams), the emotion-only head of MER2024 (output_dim2 = 0)
+    sys.path.insert(0, REF + "/MER2024")
+    for k in [k for k in sys.modules if k == "toolkit" or k.startswith("toolkit.")]:
+        del sys.modules[k]
+    nsa = {"torch": torch, "nn": torch.nn, "F": torch.nn.functional}
+    exec_defs(REF + "/MER2024/toolkit/models/modules/encoder.py", {"MLPEncoder"}, nsa)
+    exec_defs(REF + "/MER2024/toolkit/models/attention_topn.py", {"Attention_TOPN"}, nsa)
+    dims = [96, 48, 80, 64, 32, 72]
+    a2 = argparse.Namespace(audio_dim=dims, output_dim1=6, output_dim2=0, dropout=0.0, hidden_dim=64, grad_clip=-1.0)
+    torch.manual_seed(2024)
+    model = nsa["Attention_TOPN"](a2).eval()
+    batch = {f"feat{i}": torch.randn(16, d) for i, d in enumerate(dims)}
+    with torch.no_grad():
+        f, e, v, il = model(batch)
+    np.savez_compressed(os.path.join(OUT, "fusion_attention_topn.npz"), dims=np.array(dims), features=f.numpy(), emos_out=e.numpy(),
+                        vals_out=v.numpy(), interloss=il.numpy(), **{f"x_{k}": x.numpy() for k, x in batch.items()},
+                        **{f"init_{k}": p.numpy() for k, p in model.state_dict().items()})
+    sys.path.remove(REF + "/MER2024")
+
+
 if __name__ == "__main__":
+    if "--mer2024" in sys.argv:      # (re-runs only the MER2024 vectors: the other files stay byte-identical)
+        mer2024_goldens()
+        sys.exit(0)
     hf_goldens()
     fusion_goldens()
     fusion_frame_goldens()
     index_goldens()
+    mer2024_goldens()
     print("wrote:", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
