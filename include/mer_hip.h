@@ -104,10 +104,13 @@ typedef struct {
    * 256x256 LDS-DMA kernels (a DMA piece becomes 1 KiB contiguous); NULL = not available.  w_lo_blk is only
    * needed for passes 2 / 3. */
   const void* w_hi_blk; const void* w_lo_blk;
-  /* optional pre-blocked, ROW-PERMUTED copy of w_hi (mer_w_block_pack_p) for the persistent 256x256 one-pass kernel (register-direct
-   * epilogue, csrc/gemm16p_impl.h): used when passes == 1, nbatch <= 1, N % 256 == 0, K % 32 == 0, K >= 256 and the output is one
-   * 16-bit plane or fp32 (+ residual); NULL = not available. */
-  const void* w_hi_blkp;
+  /* optional pre-blocked, ROW-PERMUTED copies of w_hi (mer_w_block_pack_p) for the persistent 256x256 one-pass kernel (register-direct
+   * epilogue, csrc/gemm16p_impl.h): w_hi_blkp = layout 0, read when the output is ONE 16-bit plane; w_hi_blkq = layout 1, read when
+   * the output is fp32 (+ residual).  Used when passes == 1, nbatch <= 1, N % 256 == 0, K % 32 == 0, K >= 256; NULL = not available. */
+  const void* w_hi_blkp; const void* w_hi_blkq;
+  /* bias_seg_rows > 0: `bias` is a TABLE [ceil(M / bias_seg_rows), bias_ld] (fp32) and output row m takes row m / bias_seg_rows of it
+   * (mer_seq_bias: one correction row per sequence); 0: `bias` is a vector [N].  Not with batching. */
+  int bias_seg_rows; long long bias_ld;
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
@@ -128,16 +131,31 @@ int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch,
                   int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
                   void* scratch, float* out, mer_stream_t stream);
 
+/* Per-SEQUENCE weight-residual correction (precision "mean"): table[s, n] = bias[n] + mean_{sampled rows of sequence s}(A)[k] * w_lo[n, k]
+ * for the ceil(M / seg_rows) sequences of seg_rows consecutive rows of the A plane (rows addressed like mer_gemm16's A operand).  The
+ * sample of a sequence is rows h, h + s, h + 2 s, ... below its valid length (valid_rows[s], or seg_rows), s the largest power of two
+ * that leaves at least 16 samples, h = s / 2; sums are exact 64-bit fixed-point integers, one owner per element (no atomics): the row
+ * of a sequence depends on that sequence alone, bit for bit — whatever else is in the batch.  The one-pass GEMM that follows takes the
+ * table through mer_gemm16_args.bias / bias_seg_rows / bias_ld.  scratch: device, mer_seq_bias_scratch_bytes(nseq, K) bytes, 16-byte
+ * aligned (the 16-bit mean plane); table: device fp32 [nseq, ldt].  Two small launches on `stream`. */
+long long mer_seq_bias_scratch_bytes(int nseq, int K);
+int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
+                 int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
+                 void* scratch, float* table, long long ldt, mer_stream_t stream);
+
 /* Pre-blocked weight plane: a DEVICE 16-bit plane w [N, K] (row stride ldw, K % 32 == 0) is re-laid as
  * [ceil(N/256)][K/32] blocks of 16 KB, each the exact LDS image (256 rows x 64 B, 16-byte chunks XOR-swizzled) of
  * that (column tile, k-slab) — rows beyond N repeat row N-1.  out: DEVICE buffer of mer_w_block_bytes(N, K) bytes.
  * Row-range views stay addressable: the block of column tile t starts at byte t * 256 * K * 2. */
 long long mer_w_block_bytes(int N, int K);
 int mer_w_block_pack(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream);
-/* The same blocks with the rows of every 64-row group permuted — block row 16 q + i holds plane row 4 i + q (i < 16, q < 4) — so
- * that the four accumulators a lane of the 16x16 MFMA holds for one output row are four CONSECUTIVE columns: the persistent
- * kernel's epilogue stores whole 128-byte lines straight from registers (no LDS transposition).  N % 256 == 0.  Same size. */
-int mer_w_block_pack_p(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream);
+/* The same blocks with the rows of every 128-row group permuted so that the eight accumulators a lane of the 16x16 MFMA holds for
+ * one output row (eight column tiles of the wave's 128 columns) are CONSECUTIVE columns and the persistent kernel's epilogue stores
+ * whole 128-byte lines straight from registers (no LDS transposition): block row 16 q + i (i < 16, q < 8) holds plane row
+ *   layout 0 (16-bit outputs: one 16-byte store per lane and row):  8 i + q
+ *   layout 1 (fp32 outputs: two 16-byte stores per lane and row):   64 (q / 4) + 4 i + q % 4.
+ * N % 256 == 0.  Same size as mer_w_block_bytes(N, K). */
+int mer_w_block_pack_p(const void* w, long long ldw, int N, int K, int layout, void* out, mer_stream_t stream);
 
 /* Host-side packer of the MX correction plane.  w_res: HOST fp32 [N, K] (row stride ldw) = W - f16(W);
  * out: HOST buffer of mer_mx_packed_bytes(N, K) bytes (then copied to the device once).  Per (256-column tile,
@@ -298,7 +316,7 @@ int mer_inc_i32(int* x, mer_stream_t stream);
 
 typedef struct { const void* hi; const void* lo; const void* mx;   /* 16-bit weight planes [N,K] (+ MX residual plane for passes == 4, may be null) */
                  const void* hi_blk; const void* lo_blk;   /* optional pre-blocked copies of hi / lo (mer_w_block_pack), may be null */
-                 const void* hi_blkp; } mer_w16;           /* optional row-permuted pre-blocked copy of hi (mer_w_block_pack_p), may be null */
+                 const void* hi_blkp; const void* hi_blkq; } mer_w16;   /* optional row-permuted pre-blocked copies of hi (mer_w_block_pack_p layout 0 / 1), may be null */
 
 /* One transformer block (HuBERT / wav2vec2 / CLIP-ViT / VideoMAE / BERT / RoBERTa).
  * wqkv = cat(q,k,v) rows [3D, D]; bqkv fp32 [3D] (zeros where the model has no bias). */

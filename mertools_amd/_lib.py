@@ -36,12 +36,13 @@ class GemmArgs(C.Structure):
         ("a_so", c_ll), ("a_si", c_ll), ("w_si", c_ll), ("bias_si", c_ll), ("c_so", c_ll), ("c_si", c_ll),
         ("passes", c_int), ("tile", c_int), ("headmajor_T", c_int), ("headmajor_H", c_int),
         ("w_mx", c_void_p),
-        ("w_hi_blk", c_void_p), ("w_lo_blk", c_void_p), ("w_hi_blkp", c_void_p),
+        ("w_hi_blk", c_void_p), ("w_lo_blk", c_void_p), ("w_hi_blkp", c_void_p), ("w_hi_blkq", c_void_p),
+        ("bias_seg_rows", c_int), ("bias_ld", c_ll),
     ]
 
 
 class W16(C.Structure):
-    _fields_ = [("hi", c_void_p), ("lo", c_void_p), ("mx", c_void_p), ("hi_blk", c_void_p), ("lo_blk", c_void_p), ("hi_blkp", c_void_p)]
+    _fields_ = [("hi", c_void_p), ("lo", c_void_p), ("mx", c_void_p), ("hi_blk", c_void_p), ("lo_blk", c_void_p), ("hi_blkp", c_void_p), ("hi_blkq", c_void_p)]
 
 
 class TfLayer(C.Structure):
@@ -124,7 +125,7 @@ _PROTOS = {
     "mer_mx_pack": (c_int, [c_void_p, c_ll, c_int, c_int, c_void_p]),
     "mer_w_block_bytes": (c_ll, [c_int, c_int]),
     "mer_w_block_pack": (c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
-    "mer_w_block_pack_p": (c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
+    "mer_w_block_pack_p": (c_int, [c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mer_gemm32": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_int, c_void_p, c_ll, c_int,
                            c_int, c_int, c_int, c_void_p]),
     "mer_layernorm": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_ll,
@@ -170,6 +171,9 @@ _PROTOS = {
     "mer_hubert_forward_bias": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     "mer_attention_cls": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "mer_seq_bias_scratch_bytes": (c_ll, [c_int, c_int]),
+    "mer_seq_bias": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int,
+                             c_void_p, c_void_p, c_ll, c_void_p]),
     "mer_bias_corr_scratch_bytes": (c_ll, [c_int]),
     "mer_bias_corr": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int,
                               c_void_p, c_void_p, c_void_p]),

@@ -45,51 +45,46 @@ struct HsMap {
   float* at(int l) const { return base + (long long)(ring ? (l % ring) : l) * stride; }
 };
 
-// passes == 5: ONE f16 MFMA pass + the weight-rounding residual applied through the batch's MEAN activation:
-//   c[n] = bias[n] + mean_rows(A)[k] * (W - f16(W))[n, k]     (mer_bias_corr: sampled column means + a GEMV on the `lo` plane)
-//   C = epi(A * f16(W)^T + c)
-// `cw` carries the scratch of the two helper kernels; without it (or without a `lo` plane) 5 degrades to 4 / 2.
-struct CorrArena {       // one forward's mer_bias_corr scratch: a zeroed accumulator set ("site") per corrected GEMM
-  char* base;            // nsites * stride bytes, cleared by ONE memset at the start of the forward; NULL = not available
-  long long stride;      // mer_bias_corr_scratch_bytes(Kmax)
-  int nsites, next;
-  float* cvec;           // [Nmax] fp32: the corrected bias of the GEMM that is about to run
+// passes == 5: ONE f16 MFMA pass + the weight-rounding residual applied through each SEQUENCE's mean activation:
+//   tab[s, n] = bias[n] + mean_{sampled rows of sequence s}(A)[k] * (W - f16(W))[n, k]     (mer_seq_bias: two small launches)
+//   C[m, :] = epi(A[m, :] * f16(W)^T + tab[m / T, :])
+// A clip's features depend on that clip alone (round 3's batch-mean bias made them depend on the batch mates).  `cw` carries the
+// scratch and the sequence structure of the A plane; without it (or without a `lo` plane) 5 degrades to 4 / 2.
+struct CorrArena {       // one forward's mer_seq_bias scratch, reused by every corrected GEMM (same stream: launches are ordered)
+  char* mean16;          // [nseq, kmax] 16-bit mean plane; NULL = not available
+  float* table;          // [nseq, nmax] fp32: the correction rows of the GEMM that is about to run
+  int nseq, kmax;
+  long long nmax;
 };
 struct CorrWs {
   CorrArena* arena;
-  int seg_rows;          // rows per sequence (the sample is taken per sequence; 0: the plane has no sequence structure) ...
+  int seg_rows;          // rows per sequence of the A plane (1: every row is its own sequence; 0: no sequence structure -> no table) ...
   const int* valid;      // ... ragged batches: device int32 [nseq] valid rows of each (NULL: every row counts)
 };
-static void corr_plan(Arena& ar, CorrArena& ca, bool on, int kmax, long long nmax, int nsites) {
-  ca.stride = mer_bias_corr_scratch_bytes(kmax);
-  ca.nsites = nsites;
-  ca.next = 0;
-  ca.base = on ? (char*)ar.take(ca.stride * nsites) : nullptr;
-  ca.cvec = on ? (float*)ar.take(nmax * 4) : nullptr;
-}
-static int corr_begin(hipStream_t st, CorrArena& ca) {   // dry-run arenas have base == NULL
-  ca.next = 0;
-  if (!ca.base) return MER_OK;
-  MER_REQUIRE(hipMemsetAsync(ca.base, 0, (size_t)(ca.stride * ca.nsites), st) == hipSuccess, MER_ELAUNCH, "bias-correction scratch: memset failed");
-  return MER_OK;
+static void corr_plan(Arena& ar, CorrArena& ca, bool on, int kmax, long long nmax, int nseq) {
+  ca.nseq = nseq; ca.kmax = kmax; ca.nmax = (nmax + 3) / 4 * 4;
+  ca.mean16 = on ? (char*)ar.take(mer_seq_bias_scratch_bytes(nseq, kmax)) : nullptr;
+  ca.table = on ? (float*)ar.take((long long)nseq * ca.nmax * 4) : nullptr;
 }
 
 // mer_gemm16 with the passes == 5 preamble; `g` is complete except for the pass code handling
 static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
   if (g.passes == 5) {
     CorrArena* ca = cw ? cw->arena : nullptr;
-    const bool ok = ca && ca->base && ca->next < ca->nsites && mer_bias_corr_scratch_bytes(g.K) <= ca->stride && g.w_lo &&
+    const int nseq = (cw && cw->seg_rows > 0) ? (int)((g.M + cw->seg_rows - 1) / cw->seg_rows) : 0;
+    const bool ok = ca && ca->mean16 && nseq > 0 && nseq <= ca->nseq && g.K <= ca->kmax && g.N <= ca->nmax && g.w_lo &&
                     g.N % 8 == 0 && g.K % 8 == 0 && g.nbatch <= 1;
     if (!ok) {
       g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
     } else {
-      int rc = mer_bias_corr(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->seg_rows, cw->valid,
-                             g.w_lo, g.ldw, g.bias, g.N, ca->base + ca->stride * ca->next, ca->cvec, (mer_stream_t)st);
-      ++ca->next;
+      int rc = mer_seq_bias(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->seg_rows, cw->valid,
+                            g.w_lo, g.ldw, g.bias, g.N, ca->mean16, ca->table, g.N, (mer_stream_t)st);
       if (rc != MER_OK) return rc;
       g.passes = 1;
       g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
-      g.bias = ca->cvec;
+      g.bias = ca->table;
+      g.bias_seg_rows = cw->seg_rows;
+      g.bias_ld = g.N;
     }
   }
   return mer_gemm16(&g, (mer_stream_t)st);
@@ -103,7 +98,7 @@ static int gemm(hipStream_t st, int dtype, int passes, int M, int N, int K, P16 
   g.M = M; g.N = N; g.K = K; g.dtype = dtype;
   g.a_hi = a.hi; g.a_lo = a.lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.w_mx = w.mx; g.ldw = K;
-  g.w_hi_blk = w.hi_blk; g.w_lo_blk = w.lo_blk; g.w_hi_blkp = w.hi_blkp;
+  g.w_hi_blk = w.hi_blk; g.w_lo_blk = w.lo_blk; g.w_hi_blkp = w.hi_blkp; g.w_hi_blkq = w.hi_blkq;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
   g.c32 = c32; g.ldc32 = ldc32; g.c16_hi = c16.hi; g.c16_lo = c16.lo; g.ldc16 = ldc16;
   g.nbatch = 1; g.nb_inner = 1; g.passes = passes; g.tile = 0;
@@ -123,7 +118,7 @@ struct TfBufs {
   float* ffn32;    // SwiGLU: fp32 [M, 2F] output of weights_in awaiting the gate
   float* gate;     // WavLM: [B, H, T] gate of the current layer
   float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
-  CorrArena corr;  // passes == 5: mer_bias_corr scratch (the encoder's other GEMMs share it)
+  CorrArena corr;  // passes == 5: mer_seq_bias scratch (the encoder's other GEMMs share it)
 };
 
 // ViT whose caller only reads the [CLS] row of the last block (CLIP get_image_features): that block computes K and V for every
@@ -145,7 +140,7 @@ static void cls_plan(Arena& ar, const mer_tf_config& c, long long nseq, ClsBufs&
 }
 
 // extra_sites / extra_k / extra_n: corrected GEMMs outside the blocks that share the arena (conv stack, patch embedding)
-static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b, int extra_sites = 0, int extra_k = 0, long long extra_n = 0) {
+static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, int nseq, TfBufs& b, bool extra_on = false, int extra_k = 0, long long extra_n = 0) {
   const bool lo = c.passes == 3;
   const long long D = c.hidden, F = c.ffn;
   b.t32 = (float*)ar.take(M * D * 4);
@@ -162,7 +157,7 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, TfBufs& b, i
   wide = extra_n > wide ? extra_n : wide;
   int kmax = (int)(F > D ? F : D);
   kmax = extra_k > kmax ? extra_k : kmax;
-  corr_plan(ar, b.corr, c.passes == 5 || extra_sites > 0, kmax, wide, 4 * c.layers + 4 + extra_sites);
+  corr_plan(ar, b.corr, c.passes == 5 || extra_on, kmax, wide, nseq);
 }
 
 // Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
@@ -176,7 +171,9 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
   const int ps2 = (sel && (c.mx_skip & 4)) ? 1 : ps;       // fc2 without the correction
   // passes == 5: the correction goes through the batch's mean token (run_gemm() above); a sequence = T rows, kv_len = its valid rows
   const CorrWs cwv = {&b.corr, T, kv_len};
-  const CorrWs* mc = (ps == 5 && b.corr.base) ? &cwv : nullptr;
+  const CorrWs* mc = (ps == 5 && b.corr.mean16) ? &cwv : nullptr;
+  const CorrWs cw1 = {&b.corr, 1, nullptr};                  // CLS-only block: one row per sequence (its "mean" is the row itself)
+  const CorrWs* mc1 = mc ? &cw1 : nullptr;
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
   for (int l = 0; l < c.layers; ++l) {
@@ -193,18 +190,18 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                            (w.wqkv.mx && tiles) ? (const char*)w.wqkv.mx + (long long)(D / 256) * (D / 32) * 5120 : nullptr,
                            (w.wqkv.hi_blk && tiles) ? (const char*)w.wqkv.hi_blk + woff : nullptr,
                            (w.wqkv.lo_blk && tiles) ? (const char*)w.wqkv.lo_blk + woff : nullptr,
-                           (w.wqkv.hi_blkp && tiles) ? (const char*)w.wqkv.hi_blkp + woff : nullptr};
+                           (w.wqkv.hi_blkp && tiles) ? (const char*)w.wqkv.hi_blkp + woff : nullptr, nullptr};
       const P16 ckv = {(char*)b.qkv16.hi + (long long)D * 2, nullptr};
       MER_TRY(gemm(st, dt, ps, M, 2 * D, D, b.cur16, D, wkv, w.bqkv + D, MER_ACT_NONE, nullptr, 0, nullptr, 0, ckv, 3 * D, mc));
       // ... Q for the CLS rows (row n of the A operand = token 0 of sequence n: lda = T * D)
-      const mer_w16 wq = {w.wqkv.hi, w.wqkv.lo, nullptr, nullptr, nullptr, nullptr};
-      MER_TRY(gemm(st, dt, ps, Bseq, D, D, b.cur16, (long long)T * D, wq, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, cls->q16, D, mc));
+      const mer_w16 wq = {w.wqkv.hi, w.wqkv.lo, nullptr, nullptr, nullptr, nullptr, nullptr};
+      MER_TRY(gemm(st, dt, ps, Bseq, D, D, b.cur16, (long long)T * D, wq, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, cls->q16, D, mc1));
       MER_TRY(mer_attention_cls(cls->q16.hi, D, (char*)b.qkv16.hi + (long long)D * 2, (char*)b.qkv16.hi + (long long)2 * D * 2, 3 * D,
                                 cls->ctx16.hi, cls->ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, (mer_stream_t)st));
-      MER_TRY(gemm(st, dt, ps, Bseq, D, D, cls->ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, (long long)T * D, cls->t32, D, none, 0, mc));
+      MER_TRY(gemm(st, dt, ps, Bseq, D, D, cls->ctx16, D, w.wo, w.bo, MER_ACT_NONE, x, (long long)T * D, cls->t32, D, none, 0, mc1));
       MER_TRY(mer_layernorm(cls->t32, D, w.ln2_g, w.ln2_b, c.ln_eps, Bseq, D, MER_ACT_NONE, nullptr, 0, cls->h16.hi, cls->h16.lo, D, dt, st));
-      MER_TRY(gemm(st, dt, ps1, Bseq, F, D, cls->h16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, cls->f16, F, mc));
-      MER_TRY(gemm(st, dt, ps2, Bseq, D, F, cls->f16, F, w.w2, w.b2, MER_ACT_NONE, cls->t32, D, cls->y32, D, none, 0, mc));
+      MER_TRY(gemm(st, dt, ps1, Bseq, F, D, cls->h16, D, w.w1, w.b1, c.act, nullptr, 0, nullptr, 0, cls->f16, F, mc1));
+      MER_TRY(gemm(st, dt, ps2, Bseq, D, F, cls->f16, F, w.w2, w.b2, MER_ACT_NONE, cls->t32, D, cls->y32, D, none, 0, mc1));
       continue;
     }
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
@@ -212,7 +209,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx != nullptr) {
       // Q | K columns: one f16 pass (weight rounding there only perturbs softmax logits: no measurable effect on the features);
       // V columns: MX-corrected.  The MX plane is stored per 256-column tile, so the V block starts at tile 2D/256.
-      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr, w.wqkv.hi_blkp};
+      const mer_w16 wqk = {w.wqkv.hi, nullptr, nullptr, w.wqkv.hi_blk, nullptr, w.wqkv.hi_blkp, nullptr};
       MER_TRY(gemm(st, dt, 1, M, 2 * D, D, b.cur16, D, wqk, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D));
       const long long woff = (long long)2 * D * D * 2;   // bytes into the 16-bit planes
       const mer_w16 wv = {(const char*)w.wqkv.hi + woff, w.wqkv.lo ? (const char*)w.wqkv.lo + woff : nullptr,
@@ -220,7 +217,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                           // the pre-blocked planes are stored per 256-row tile as well: tile 2D/256 starts woff bytes in
                           w.wqkv.hi_blk ? (const char*)w.wqkv.hi_blk + woff : nullptr,
                           w.wqkv.lo_blk ? (const char*)w.wqkv.lo_blk + woff : nullptr,
-                          w.wqkv.hi_blkp ? (const char*)w.wqkv.hi_blkp + woff : nullptr};
+                          w.wqkv.hi_blkp ? (const char*)w.wqkv.hi_blkp + woff : nullptr, nullptr};
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
       MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, mc));
     } else
@@ -368,7 +365,7 @@ static long long hubert_plan(const mer_hubert* h, Arena& ar, int B, int L, bool 
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
   int kmax = (int)C;
   for (int i = 1; i < c.n_conv; ++i) kmax = c.conv_kernel[i] * (int)C > kmax ? c.conv_kernel[i] * (int)C : kmax;
-  tf_plan(ar, c.tf, M, p.tf, c.conv_passes == 5 ? c.n_conv + 1 : 0, kmax, C > D ? C : D);
+  tf_plan(ar, c.tf, M, B, p.tf, c.conv_passes == 5, kmax, C > D ? C : D);
   return ar.off;
 }
 
@@ -420,8 +417,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   // mean, the bias is an absolute offset they cannot absorb and the projection's LayerNorm magnifies it (1e-2 on loud / quiet clips,
   // DESIGN.md §4, test_hubert_loud_and_quiet_passages).  "mean" runs the conv stack with conv_passes == 4 (per-row MX correction) and
   // keeps the batch-mean bias behind LayerNorms.  In a ragged batch only the output frames that come from a clip's own samples count.
-  MER_TRY(corr_begin(st, p.tf.corr));
-  const bool corr_on = cps == 5 && p.tf.corr.base;
+  const bool corr_on = cps == 5 && p.tf.corr.mean16;
 
   // ragged batch: per-row valid frame counts after conv 0 (GroupNorm statistics) and after the stack (positional conv zeros,
   // attention key mask), derived on the device from the rows' sample counts
@@ -453,7 +449,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
     g.a_hi = src.hi; g.a_lo = src.lo; g.lda = (long long)c.conv_stride[i] * C;
     g.a_rows_per_batch = p.T[i]; g.a_batch_stride = (long long)p.T[i - 1] * C;
     g.w_hi = w.conv_w[i].hi; g.w_lo = w.conv_w[i].lo; g.w_mx = w.conv_w[i].mx; g.ldw = g.K;
-    g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk; g.w_hi_blkp = w.conv_w[i].hi_blkp;
+    g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk; g.w_hi_blkp = w.conv_w[i].hi_blkp; g.w_hi_blkq = w.conv_w[i].hi_blkq;
     g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
     const CorrWs ccw = {&p.tf.corr, p.T[i], valid_samples ? p.vlen + (long long)i * B : nullptr};
@@ -478,7 +474,10 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   if (c.feat_proj_layer_norm)
     MER_TRY(mer_layernorm(p.conv_last32, C, w.fp_ln_g, w.fp_ln_b, c.tf.ln_eps, M, C, MER_ACT_NONE, nullptr, 0, p.fp16.hi, p.fp16.lo, C, dt, st));
   const CorrWs pcw = {&p.tf.corr, Tn, tn_len};
-  MER_TRY(gemm(st, dt, cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, corr_on ? &pcw : nullptr));
+  // (behind a LayerNorm: rows of one size, so the per-sequence table applies under "mean" as it does in the blocks; the conv stack above
+  //  reads un-normalised GELU outputs and keeps its per-row MX correction — DESIGN.md §4)
+  const bool fp_tab = (cps == 5 || (c.tf.passes == 5 && c.feat_proj_layer_norm)) && p.tf.corr.mean16;
+  MER_TRY(gemm(st, dt, fp_tab ? 5 : cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, fp_tab ? &pcw : nullptr));
 
   // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
   HsMap hs;
@@ -572,7 +571,11 @@ struct VitPlan {
 };
 
 // CLIP features come from the CLS row alone: the last block runs for those rows only unless the caller wants every token
-static bool vit_cls_only(const mer_vit_config& c) { return c.variant == 0 && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1; }
+// (mer_attention_cls keeps a sequence's scores in registers: T <= 584 tokens; the CLS branch of tf_forward assumes pre-LN blocks)
+static bool vit_cls_only(const mer_vit_config& c) {
+  const long long g = c.image_size / (c.patch_size > 0 ? c.patch_size : 1);
+  return c.variant == 0 && c.tf.pre_ln && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1 && g * g + 1 <= 584;
+}
 
 static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   const mer_vit_config& c = h->cfg;
@@ -584,7 +587,7 @@ static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   p.x = (float*)ar.take(N * (P + 1) * D * 4);
   p.cls16 = take16(ar, (long long)N * D, lo);
   p.feats = (float*)ar.take((long long)N * c.proj_dim * 4);
-  tf_plan(ar, c.tf, N * (P + 1), p.tf, c.tf.passes == 5 ? 4 : 0, (int)cols);
+  tf_plan(ar, c.tf, N * (P + 1), N, p.tf, false, (int)cols);
   if (vit_cls_only(c)) cls_plan(ar, c.tf, N, p.cls);
   return ar.off;
 }
@@ -619,7 +622,6 @@ extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int
   const P16 none = {nullptr, nullptr};
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
-  MER_TRY(corr_begin(st, p.tf.corr));
   const CorrWs pcw = {&p.tf.corr, P, nullptr};
   MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, c.variant == 1 ? w.patch_b : nullptr, MER_ACT_NONE, nullptr, 0,
                p.patch32, D, none, 0, &pcw));
@@ -686,7 +688,7 @@ static long long vmae_plan(const mer_videomae* h, Arena& ar, int B, VmaePlan& p)
   const long long cols = (long long)c.channels * c.tubelet_size * c.patch_size * c.patch_size;
   p.patches = take16(ar, B * NP * cols, c.tf.passes == 3);
   p.x = (float*)ar.take(B * NP * D * 4);
-  tf_plan(ar, c.tf, B * NP, p.tf, c.tf.passes == 5 ? 2 : 0, (int)cols);
+  tf_plan(ar, c.tf, B * NP, B, p.tf, false, (int)cols);
   return ar.off;
 }
 extern "C" long long mer_videomae_workspace_bytes(const mer_videomae* h, int B) {
@@ -715,7 +717,6 @@ extern "C" int mer_videomae_forward(const mer_videomae* h, const float* pixels, 
   // tubelet embedding: Conv3d(stride == kernel, bias) == GEMM over tubelet rows; + fixed sin-cos positions
   MER_TRY(mer_video_patchify(pixels, B, c.num_frames, c.channels, c.image_size, c.image_size, c.patch_size, c.tubelet_size,
                              p.patches.hi, p.patches.lo, dt, st));
-  MER_TRY(corr_begin(st, p.tf.corr));
   const CorrWs pcw = {&p.tf.corr, NP, nullptr};
   MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0, &pcw));
   MER_TRY(mer_add_pos(x, w.pos, (long long)B * NP, NP, D, st));
@@ -765,7 +766,7 @@ static long long bert_plan(const mer_bert* h, Arena& ar, int B, int T, bool want
   const int E = h->cfg.emb_dim;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
   p.emb16 = (E > 0 && E != D) ? take16(ar, M * E, h->cfg.tf.passes == 3) : P16{nullptr, nullptr};
-  tf_plan(ar, h->cfg.tf, M, p.tf);
+  tf_plan(ar, h->cfg.tf, M, B, p.tf);
   return ar.off;
 }
 extern "C" long long mer_bert_workspace_bytes(const mer_bert* h, int B, int T, int want_hidden_states) {
@@ -795,7 +796,6 @@ extern "C" int mer_bert_forward(const mer_bert* h, const int64_t* ids, const int
   HsMap hs;
   hs.stride = M * D;
   if (hidden_states) { hs.base = hidden_states; hs.ring = 0; } else { hs.base = p.ring; hs.ring = 5; }
-  MER_TRY(corr_begin(st, p.tf.corr));
   if (c.emb_dim > 0 && c.emb_dim != D) {   // factorised embeddings: E-wide tables + LayerNorm, then Linear(E -> D) = hidden_states[0]
     MER_TRY(mer_bert_embed(ids, token_type, B, T, c.emb_dim, w.word, w.pos, w.type, c.pos_mode, c.pad_id, w.emb_ln_g, w.emb_ln_b,
                            c.emb_ln_eps, nullptr, p.emb16.hi, p.emb16.lo, dt, st));

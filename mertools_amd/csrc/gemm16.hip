@@ -49,29 +49,31 @@ __global__ void w_block_pack_kernel(const u32x4* w, long long ldw8, int N, int n
   out[idx] = w[n * ldw8 + kt * 4 + (pc ^ swz_of<4>(r))];
 }
 
-// row-permuted variant for the persistent kernel: block row r holds plane row (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3)
-__global__ void w_block_pack_p_kernel(const u32x4* w, long long ldw8, int N, int nk, long long total, u32x4* out) {
+// row-permuted variants for the persistent kernel (gemm16p_impl.h: p_perm_row): block row r of every 128-row group holds the plane
+// row that makes a lane's eight accumulators of an output row consecutive columns (layout 0: 8 li + nt; layout 1: two runs of four)
+__global__ void w_block_pack_p_kernel(const u32x4* w, long long ldw8, int N, int nk, long long total, int layout, u32x4* out) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int pc = (int)(idx & 3), r = (int)((idx >> 2) & 255);
   const long long blk = idx >> 10;
   const int kt = (int)(blk % nk);
   const long long tn = blk / nk;
-  long long n = tn * 256 + (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);
+  long long n = tn * 256 + p_perm_row(r, layout);
   n = n < N ? n : N - 1;
   out[idx] = w[n * ldw8 + kt * 4 + (pc ^ swz_of<4>(r))];
 }
 }  // namespace mer
 
-extern "C" int mer_w_block_pack_p(const void* w, long long ldw, int N, int K, void* out, mer_stream_t stream) {
+extern "C" int mer_w_block_pack_p(const void* w, long long ldw, int N, int K, int layout, void* out, mer_stream_t stream) {
   using namespace mer;
   MER_REQUIRE(w && out, MER_EINVAL, "mer_w_block_pack_p: null pointer");
+  MER_REQUIRE(layout == 0 || layout == 1, MER_EINVAL, "mer_w_block_pack_p: layout must be 0 (16-bit outputs) or 1 (fp32 outputs)");
   MER_REQUIRE(N > 0 && N % 256 == 0 && K > 0 && K % 32 == 0 && ldw % 8 == 0, MER_ESHAPE,
               "mer_w_block_pack_p: N must be a multiple of 256, K of 32 and ldw of 8 (N=%d K=%d ldw=%lld)", N, K, ldw);
   MER_REQUIRE((((uintptr_t)w | (uintptr_t)out) & 15) == 0, MER_EINVAL, "mer_w_block_pack_p: planes must be 16-byte aligned");
   const long long total = (long long)(N / 256) * (K / 32) * 1024;
   hipLaunchKernelGGL(w_block_pack_p_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const u32x4*)w, ldw / 8, N, K / 32, total, (u32x4*)out);
+                     (const u32x4*)w, ldw / 8, N, K / 32, total, layout, (u32x4*)out);
   return check_launch("w_block_pack_p");
 }
 
@@ -179,12 +181,16 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
                                       a->c16_hi && a->N % 8 == 0 && (a->nbatch <= 1)),
               MER_ESHAPE, "mer_gemm16: head-major output needs M %% T == 0, N %% (64*H) == 0, a 16-bit output and no batching");
   MER_REQUIRE(!a->c16_lo || a->c16_hi, MER_EINVAL, "mer_gemm16: c16_lo without c16_hi");
+  MER_REQUIRE(a->bias_seg_rows >= 0 && (a->bias_seg_rows == 0 || !a->bias || (a->nbatch <= 1 && a->bias_ld >= a->N && a->bias_ld % 4 == 0 &&
+                                                                             (((uintptr_t)a->bias) & 15) == 0)),
+              MER_ESHAPE, "mer_gemm16: a bias table (bias_seg_rows > 0) needs nbatch <= 1, bias_ld >= N, bias_ld %% 4 == 0 and 16-byte alignment");
   const int nbatch = a->nbatch > 0 ? a->nbatch : 1;
   Gemm16Params p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.a_hi = a->a_hi; p.a_lo = a->a_lo; p.lda = a->lda; p.a_rpb = a->a_rows_per_batch; p.a_bstride = a->a_batch_stride;
   p.w_hi = a->w_hi; p.w_lo = a->w_lo; p.ldw = a->ldw; p.w_mx = a->w_mx; p.w_blk = 0;
   p.bias = a->bias; p.act = a->act;
+  p.bias_T = a->bias ? a->bias_seg_rows : 0; p.bias_ld = a->bias_ld;
   p.residual = a->residual; p.ldr = a->ldr;
   p.c32 = a->c32; p.ldc32 = a->ldc32;
   p.c16_hi = a->c16_hi; p.c16_lo = a->c16_lo; p.ldc16 = a->ldc16;
@@ -206,7 +212,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
              (!a->bias || ((((uintptr_t)a->bias) & 15) == 0 && a->bias_si % 4 == 0))) ? 1 : 0;   // its static bias is one 16-byte load per lane
   // packed-pair epilogue: 16-bit output only (no fp32 copy, residual or lo plane), row-major, every column group of 8 in range
   p.pk_epi = (!g_gemm_generic_epi && vec && a->c16_hi && !a->c16_lo && !a->c32 && !a->residual && a->headmajor_T == 0 &&
-              a->act != MER_ACT_RELU) ? 1 : 0;
+              a->act != MER_ACT_RELU && p.bias_T == 0) ? 1 : 0;   // (a bias table is per row: the packed form adds the bias per column)
   MER_REQUIRE((((uintptr_t)a->a_hi | (uintptr_t)a->w_hi | (uintptr_t)a->a_lo | (uintptr_t)a->w_lo | (uintptr_t)a->w_mx) & 15) == 0, MER_EINVAL,
               "mer_gemm16: operand planes must be 16-byte aligned");
   int tile = a->tile;
@@ -219,6 +225,9 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
     const long long t256 = cdiv(a->M, 256) * cdiv(a->N, 256);
     const bool few_narrow = t256 <= 96 && a->N <= 1024 && a->passes != 4;
     tile = (a->N <= 64) ? 2 : ((a->M >= 1024 && a->N >= 192 && !few_narrow) ? 3 : 1);
+    // an MX-corrected GEMM keeps the MX kernel however few rows it has: its 2-pass stand-in is different arithmetic, and a clip's
+    // features would depend on whether its batch reached 1024 rows (HuBERT's last conv layers at batch 1 .. 4: 249 .. 996 rows)
+    if (a->passes == 4 && a->w_mx && a->N >= 192 && a->dtype == MER_DT_F16 && a->K % 128 == 0 && nbatch == 1) tile = 3;
   }
   hipStream_t st = (hipStream_t)stream;
   int passes = a->passes;
@@ -243,21 +252,23 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
     p.w_lo = a->w_lo_blk;
     p.w_blk = 1;
   }
-  // the persistent 256x256 kernel (gemm16p_impl.h): one pass, its own row-permuted pre-blocked plane, whole 256-column tiles, a K loop
-  // long enough for its counted waits (8 slabs), one 16-bit plane OR fp32 (+ residual) out, every plane within 32-bit byte offsets
-  if (a->w_hi_blkp && tile == 3 && passes == 1 && g_gemm_persist && g_gemm_glds == 1 && !g_gemm_generic_epi && nbatch == 1 &&
+  // the persistent 256x256 kernel (gemm16p_impl.h): one pass, its own row-permuted pre-blocked plane (layout A for a 16-bit output,
+  // layout B for an fp32 one), whole 256-column tiles, a K loop long enough for its counted waits (8 slabs), one 16-bit plane OR fp32
+  // (+ residual, then without activation) out, every plane within 32-bit byte offsets
+  const void* wp = a->c16_hi ? a->w_hi_blkp : a->w_hi_blkq;
+  if (wp && tile == 3 && passes == 1 && g_gemm_persist && g_gemm_glds == 1 && !g_gemm_generic_epi && nbatch == 1 &&
       a->N % 256 == 0 && a->K % 32 == 0 && a->K >= 256 && a->headmajor_T == 0 && !a->c16_lo && (!a->c16_hi != !a->c32) &&
-      (a->c16_hi ? !a->residual : true)) {
+      (a->c16_hi ? !a->residual : true) && (p.bias_T == 0 || p.bias_T >= 40)) {
     const long long a_last = a->a_rows_per_batch > 0
         ? (long long)((a->M - 1) / a->a_rows_per_batch) * a->a_batch_stride + (long long)((a->M - 1) % a->a_rows_per_batch) * a->lda
         : (long long)(a->M - 1) * a->lda;
-    const bool act_ok = a->c16_hi ? (a->act != MER_ACT_RELU) : (a->act == MER_ACT_NONE || a->act == MER_ACT_GELU);
-    bool al = (((uintptr_t)a->w_hi_blkp | (uintptr_t)a->bias) & 15) == 0;
-    if (a->c16_hi) al = al && a->ldc16 % 4 == 0 && (((uintptr_t)a->c16_hi) & 7) == 0 && 256ll * a->ldc16 * 2 < (1ll << 31);
+    const bool act_ok = a->c16_hi ? (a->act != MER_ACT_RELU) : (a->act == MER_ACT_NONE || (a->act == MER_ACT_GELU && !a->residual));
+    bool al = (((uintptr_t)wp | (uintptr_t)a->bias) & 15) == 0;
+    if (a->c16_hi) al = al && a->ldc16 % 8 == 0 && (((uintptr_t)a->c16_hi) & 15) == 0 && 256ll * a->ldc16 * 2 < (1ll << 31);
     if (a->c32) al = al && a->ldc32 % 4 == 0 && (((uintptr_t)a->c32) & 15) == 0 && 256ll * a->ldc32 * 4 < (1ll << 31);
     if (a->residual) al = al && a->ldr % 4 == 0 && (((uintptr_t)a->residual) & 15) == 0 && 256ll * a->ldr * 4 < (1ll << 31);
     if (act_ok && al && (a_last + a->K) * 2 < (1ll << 32)) {
-      p.w_hi = a->w_hi_blkp;
+      p.w_hi = wp;
       p.w_lo = nullptr;
       p.w_blk = 2;
       if (a->dtype == MER_DT_F16) return dispatch_p<f16>(p, st);

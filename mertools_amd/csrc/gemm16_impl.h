@@ -40,6 +40,7 @@ struct Gemm16Params {
   const void* w_mx;   // MX kernel: packed fp4 + E8M0 correction plane (mer_mx_pack)
   int w_blk;          // w_hi / w_lo are pre-blocked planes (mer_w_block_pack): [n-tile of 256][32-deep k-slab][the 16 KB LDS image]
   const float* bias; int act;
+  int bias_T; long long bias_ld;   // bias_T > 0: `bias` is a table [ceil(M / bias_T), bias_ld], output row m takes row m / bias_T (mer_seq_bias)
   const float* residual; long long ldr;
   float* c32; long long ldc32;
   void* c16_hi; void* c16_lo; long long ldc16;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
   const float* bias = p.bias ? p.bias + (long long)zi * p.bias_si : nullptr;
   // the static bias of this lane's 8 columns, as two vector registers (a float[8] that is later re-read as vectors ends up in scratch)
   f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
+  if (bias && p.bias_T == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bv0[j] = col + j < p.N ? bias[col + j] : 0.f;
@@ -420,7 +421,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           const f32x4 a0 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL);
           const f32x4 a1 = *reinterpret_cast<const f32x4*>(ct + lr * CLD + c8 * CPL + 4);
           float v[CPL];
-          const f32x4 b0 = bv0, b1 = bv1;
+          f32x4 b0 = bv0, b1 = bv1;
+          if (p.bias_T > 0) {   // per-sequence correction table: this row's row of it (bias_ld % 4 == 0, 16-byte aligned: host-checked)
+            const float* br = p.bias + (long long)(row / p.bias_T) * p.bias_ld + col;
+            b0 = *reinterpret_cast<const f32x4*>(br);
+            b1 = *reinterpret_cast<const f32x4*>(br + 4);
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             v[j] = act_apply(a0[j] + b0[j], ACT);
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
           if (row >= p.M || !col_ok) continue;
           for (int j = 0; j < CPL; ++j) {
             if (col + j >= p.N) break;
-            const float bsc = !bias ? 0.f : bias[col + j];
+            const float bsc = !bias ? 0.f : (p.bias_T > 0 ? p.bias[(long long)(row / p.bias_T) * p.bias_ld + col + j] : bias[col + j]);
             float x = act_apply(ct[lr * CLD + c8 * CPL + j] + bsc, ACT);
             if (res) x += res[(long long)row * p.ldr + col + j];
             if (c32) c32[(long long)row * p.ldc32 + col + j] = x;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
     const int col4 = n0 + wn * SN + c4 * 4;
     const bool ok4 = col4 < p.N;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (bias && ok4) b4 = *reinterpret_cast<const f32x4*>(bias + col4);   // (vec: N % 8 == 0; bias is 16-byte aligned: checked on the host)
+    if (bias && ok4 && p.bias_T == 0) b4 = *reinterpret_cast<const f32x4*>(bias + col4);   // (vec: N % 8 == 0; bias is 16-byte aligned: checked on the host)
 #pragma unroll
     for (int ch = 0; ch < SM / EROWS; ++ch) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -577,7 +583,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(const Gemm16Params
         if (row < p.M && ok4) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ct + (it * RIT + rs) * CLD + c4 * 4);
         f32x4 v;
-        const f32x4 bb = b4;
+        f32x4 bb = b4;
+        if (p.bias_T > 0) bb = *reinterpret_cast<const f32x4*>(p.bias + (long long)(row / p.bias_T) * p.bias_ld + col4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply(a[j] + bb[j], ACT);
         if (res) v += rr[it];

@@ -24,6 +24,11 @@ struct RowLN {
   template <typename Affine>
   static __device__ __forceinline__ void run_with(f32x4 (&v)[NV], int lane, int nv4, int D, Affine affine,
                                                   float eps, int act, float* o32, T* ohi, T* olo) {
+    // Every product / sum below is spelled out (fmaf where a fused operation is meant) and contraction is off: hipcc otherwise
+    // fuses differently in the two kernels that inline this function, their fp32 outputs differ in the last bit, the 16-bit planes
+    // round differently — and a clip's features depended on whether its batch was large enough for the multi-row kernel
+    // (tests/studies/batch_rows_ops_gpu.py: the one operator that was not batch-size invariant).
+#pragma clang fp contract(off)
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
@@ -35,7 +40,7 @@ struct RowLN {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float d = v[j][e] - mean;
-          q += d * d;
+          q = fmaf(d, d, q);
         }
       }
     }
@@ -48,7 +53,7 @@ struct RowLN {
         f32x4 g, b, y;
         affine(idx, g, b);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = act_apply((v[j][e] - mean) * rstd * g[e] + b[e], act);
+        for (int e = 0; e < 4; ++e) y[e] = act_apply(fmaf((v[j][e] - mean) * rstd, g[e], b[e]), act);
         if (o32) *reinterpret_cast<f32x4*>(o32 + idx * 4) = y;
         if (ohi) {
           typename T16<T>::v4 h, l;
@@ -424,6 +429,162 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
                                           act, out32, ld32, (bf16*)out16_hi, (bf16*)out16_lo, ld16));
   }
   return check_launch("layernorm");
+}
+
+namespace mer {
+// ---- per-SEQUENCE weight-residual correction (precision "mean" since round 4) ----
+// The batch-mean bias above made a clip's features depend on its batch mates (and on how the batch was split over GPUs).  Here
+// every sequence (clip / frame / sentence) gets its own correction row:
+//     tab[s, n] = bias[n] + mean_{t in sample(s)}(A[s T + t, :]) . w_lo[n, :]
+// and the one-pass GEMM that follows adds row (m / T) of the table instead of a bias vector (mer_gemm16: bias_seg_rows).  The sample
+// of a sequence — tokens s/2, s/2 + s, ... (s = the largest power of two with at least 16 samples; the offset keeps the [CLS] / BOS
+// row out, whose weight would otherwise be 1 / #samples instead of 1 / T) below its valid length — depends on T and on the clip
+// alone, so its features no longer depend on what else is in the batch, bit for bit.
+//   seqmean16_kernel   workgroup = (64-column slice, sequence): exact 64-bit fixed-point column sums of the sampled rows (any order
+//                      gives the same bits), written as the 16-bit mean plane [nseq, K] — no atomics, one owner per element
+//   seqbias_kernel     the [nseq, K] x [N, K]^T table on the 16x16x32 MFMA, fragments straight from global memory (both operands
+//                      are a few MB and L2-resident; a wave = 64 sequences x 16 columns, 4 waves = 64 columns per workgroup)
+__host__ __device__ inline int seq_sample_stride(int T) {
+  int s = 1;
+  while (s * 2 * 16 <= T) s *= 2;
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seqmean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int seg_rows,
+                                                        const int* valid_rows, T* mean16, long long ldm) {
+  // workgroup = (512-column slice, sequence); wave w takes sample rows w, w + 4, ...; a wave-load = one row x 1 KiB (whole lines)
+  typedef typename T16<T>::v8 v8;
+  __shared__ long long red[4][512];
+  __shared__ int rcnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 512 + lane * 8;
+  const int seq = blockIdx.y;
+  const bool cin = col < K;
+  const int stride = seq_sample_stride(seg_rows);
+  int valid = seg_rows;
+  if (valid_rows) valid = valid_rows[seq] < valid ? valid_rows[seq] : valid;
+  if ((long long)seq * seg_rows + valid > M) valid = M - seq * seg_rows;     // last, partial sequence of the plane
+  long long s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0;
+  int n = 0;
+#pragma unroll 4
+  for (int i = wave; ; i += 4) {
+    const int t = (stride >> 1) + i * stride;
+    if (t >= valid) break;
+    ++n;
+    if (cin) {
+      const int r = seq * seg_rows + t;
+      const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
+      const v8 x = *reinterpret_cast<const v8*>(a + off + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fminf(fmaxf(T16<T>::to_f32(x[j]), -131000.f), 131000.f);
+        s[j] += (long long)__float2int_rn(v * CM_FIX);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = s[j];
+  if (lane == 0) rcnt[wave] = n;
+  __syncthreads();
+  const int total = (rcnt[0] + rcnt[1]) + (rcnt[2] + rcnt[3]);
+  // (a sequence shorter than stride / 2 rows has no sample: its correction row is the plain bias)
+  const double inv = total > 0 ? 1.0 / ((double)total * (double)CM_FIX) : 0.0;
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const long long t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);       // integer sums: any order gives the same bits
+    const int cc = blockIdx.x * 512 + c;
+    if (cc < K) mean16[(long long)seq * ldm + cc] = T16<T>::from_f32((float)((double)t * inv));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seqbias_kernel(const T* mean16, long long ldm, int nseq, int K, const T* w_lo, long long ldw,
+                                                      const float* bias, int N, float* tab, long long ldt) {
+  // workgroup = 64 sequences x 16 columns; its 4 waves split K (a 768-deep dot product is 24 dependent L2 round trips for one
+  // wave: this launch is latency, not bandwidth), 4 k-steps of loads in flight per wave, partial tiles summed in wave order through
+  // LDS (a fixed order: the row of a sequence does not depend on the batch around it)
+  typedef typename T16<T>::v8 v8;
+  __shared__ float red[4][64][20];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * 16, s0 = blockIdx.y * 64;
+  const int n = n0 + li < N ? n0 + li : N - 1;
+  const int ksteps = (K + 31) / 32, per = (ksteps + 3) / 4;
+  const int k_lo = wave * per * 32, k_hi = (wave + 1) * per * 32 < K ? (wave + 1) * per * 32 : K;
+  const T* wr = w_lo + (long long)n * ldw + lg * 8;
+  const T* mr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int sq = s0 + i * 16 + li;
+    mr[i] = mean16 + (long long)(sq < nseq ? sq : nseq - 1) * ldm + lg * 8;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const v8 z = {};
+  for (int k0 = k_lo; k0 < k_hi; k0 += 128) {
+    v8 wf[4], mf[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * 32;
+      const bool kin = k < k_hi && k + lg * 8 < K;     // K % 8 == 0: a lane's 8 elements are in or out together
+      wf[u] = kin ? *reinterpret_cast<const v8*>(wr + k) : z;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mf[u][i] = kin ? *reinterpret_cast<const v8*>(mr[i] + k) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = T16<T>::mfma(mf[u][i], wf[u], acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][i * 16 + lg * 4 + r][li] = acc[i][r];
+  __syncthreads();
+  const int sl = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+  const int sq = s0 + sl;
+  if (sq < nseq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = n0 + c4 + j;
+      if (c < N) tab[(long long)sq * ldt + c] = ((red[0][sl][c4 + j] + red[1][sl][c4 + j]) + (red[2][sl][c4 + j] + red[3][sl][c4 + j])) + (bias ? bias[c] : 0.f);
+    }
+  }
+}
+
+}  // namespace mer
+
+extern "C" long long mer_seq_bias_scratch_bytes(int nseq, int K) {
+  if (nseq <= 0 || K <= 0) return 0;
+  return ((long long)nseq * K * 2 + 255) / 256 * 256;   // the 16-bit mean plane [nseq, K]
+}
+
+extern "C" int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
+                            int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
+                            void* scratch, float* table, long long ldt, mer_stream_t stream) {
+  using namespace mer;
+  MER_REQUIRE(a && w_lo && scratch && table && M > 0 && K > 0 && N > 0 && seg_rows > 0, MER_EINVAL, "mer_seq_bias: bad argument");
+  MER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && a_batch_stride % 8 == 0 && ((((uintptr_t)a | (uintptr_t)w_lo | (uintptr_t)scratch) & 15) == 0), MER_ESHAPE,
+              "mer_seq_bias: K, lda, ldw, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
+  MER_REQUIRE(ldt >= N, MER_ESHAPE, "mer_seq_bias: ldt < N");
+  MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_seq_bias: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int nseq = (int)cdiv(M, seg_rows);
+  MER_REQUIRE(nseq <= 65535, MER_EUNSUPPORTED, "mer_seq_bias: %d sequences > 65535", nseq);
+  dim3 g1((unsigned)cdiv(K, 512), (unsigned)nseq), g2((unsigned)cdiv(N, 16), (unsigned)cdiv(nseq, 64));
+  const int samples = (seg_rows + seq_sample_stride(seg_rows) - 1) / seq_sample_stride(seg_rows);
+  ProfScope prof("bias_corr", 2.0 * nseq * (double)N * K, (double)nseq * samples * K * 2 + (double)N * K * 2 + (double)nseq * N * 4, st);
+  if (dtype == MER_DT_F16) {
+    hipLaunchKernelGGL((seqmean16_kernel<f16>), g1, dim3(256), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (f16*)scratch, (long long)K);
+    hipLaunchKernelGGL((seqbias_kernel<f16>), g2, dim3(256), 0, st, (const f16*)scratch, (long long)K, nseq, K, (const f16*)w_lo, ldw, bias, N, table, ldt);
+  } else {
+    hipLaunchKernelGGL((seqmean16_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (bf16*)scratch, (long long)K);
+    hipLaunchKernelGGL((seqbias_kernel<bf16>), g2, dim3(256), 0, st, (const bf16*)scratch, (long long)K, nseq, K, (const bf16*)w_lo, ldw, bias, N, table, ldt);
+  }
+  return check_launch("seq_bias");
 }
 
 extern "C" long long mer_bias_corr_scratch_bytes(int K) {

@@ -86,7 +86,9 @@ class _Holder:
         self.keep.append(d)
         return d.data_ptr()
 
-    def w16(self, t, lo, mx=False):
+    def w16(self, t, lo, mx=False, out="f16"):
+        """out: what the GEMM reading this weight writes — "f16" (one 16-bit plane: QKV, fc1, conv stack), "f32" (fp32 (+ residual): attention
+        output, fc2, projections) or "both": selects the row permutation of the persistent kernel's pre-blocked plane."""
         t = t.contiguous()
         hi, lo_t = split16_host(t, self.dtype, lo)
         hi = hi.contiguous().to(self.device)
@@ -98,6 +100,7 @@ class _Holder:
         w.hi_blk = None
         w.lo_blk = None
         w.hi_blkp = None
+        w.hi_blkq = None
         if lo:
             lo_t = lo_t.contiguous().to(self.device)
             self.keep.append(lo_t)
@@ -109,11 +112,16 @@ class _Holder:
             with torch.cuda.device(self.device):
                 hb = w_block_pack(hi)
                 lb = w_block_pack(lo_t) if lo and hb is not None else None
-                hp = w_block_pack_p(hi) if _WBLKP else None   # the persistent one-pass kernel's plane (rows permuted per 64)
+                # the persistent one-pass kernel's planes (rows permuted per 128: layout 0 for 16-bit outputs, 1 for fp32 outputs)
+                hp = w_block_pack_p(hi, 0) if _WBLKP and out in ("f16", "both") else None
+                hq = w_block_pack_p(hi, 1) if _WBLKP and out in ("f32", "both") else None
                 torch.cuda.current_stream().synchronize()   # the forwards may run on other streams
             if hp is not None:
                 self.keep.append(hp)
                 w.hi_blkp = hp.data_ptr()
+            if hq is not None:
+                self.keep.append(hq)
+                w.hi_blkq = hq.data_ptr()
             if hb is not None:
                 self.keep.append(hb)
                 w.hi_blk = hb.data_ptr()
@@ -137,12 +145,12 @@ def _tf_layer(hold, lo, wq, bq, wk, bk, wv, bv, wo, bo, ln1, w1, b1, w2, b2, ln2
     L = TfLayer()
     L.wqkv = hold.w16(torch.cat([wq, wk, wv], 0), lo, mx)
     L.bqkv = hold.f32(torch.cat([bq if bq is not None else z, bk if bk is not None else z, bv if bv is not None else z], 0))
-    L.wo = hold.w16(wo, lo, mx)
+    L.wo = hold.w16(wo, lo, mx, out="f32")
     L.bo = hold.f32(bo)
     L.ln1_g, L.ln1_b = hold.f32(ln1[0]), hold.f32(ln1[1])
     L.w1 = hold.w16(w1, lo, mx)
     L.b1 = hold.f32(b1)
-    L.w2 = hold.w16(w2, lo, mx)
+    L.w2 = hold.w16(w2, lo, mx, out="f32")
     L.b2 = hold.f32(b2)
     L.ln2_g, L.ln2_b = hold.f32(ln2[0]), hold.f32(ln2[1])
     return L
@@ -225,7 +233,12 @@ class _HipModule:
         cache = self.__dict__.setdefault("_int_cache", {})
         hit = cache.get(key)
         if hit is None:
-            if len(cache) >= 256:   # (entries other streams may still be reading stay alive through their tensors' references in flight)
+            if len(cache) >= 256:
+                # the kernels read these tables through raw pointers, so a tensor reference does not keep a table alive for a stream
+                # that still has launches queued: drain the device before the memory goes back to the allocator (once per 256
+                # distinct tables: ragged audio batches make a new one each)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
                 cache.clear()
                 self.__dict__.get("_int_pins", {}).clear()
             host = torch.tensor(key, dtype=torch.int32)
@@ -322,10 +335,14 @@ class HipHubertModel(_HipModule):
                 w.conv_b[i] = hold.f32(sd[fe + f"{i}.conv.bias"])
             if i >= 1:  # [Cout, Cin, k] -> [Cout, k*Cin] (column kk*Cin + ci == one contiguous im2col row)
                 wt = sd[fe + f"{i}.conv.weight"]
-                w.conv_w[i] = hold.w16(wt.permute(0, 2, 1).reshape(Cc, -1), clo, cmx)
+                # what the conv GEMM writes (mer_hubert_forward): 16-bit planes for the next conv; fp32 for a LayerNorm behind it
+                # ("layer" front end: every conv; "group": the last one, whose output the feature projection's LayerNorm reads)
+                last = i == n_conv - 1
+                to32 = (not cfg.feat_norm_group) or (last and cfg.feat_proj_layer_norm)
+                w.conv_w[i] = hold.w16(wt.permute(0, 2, 1).reshape(Cc, -1), clo, cmx, out="f32" if to32 else "f16")
         if cfg.feat_proj_layer_norm:
             w.fp_ln_g, w.fp_ln_b = hold.f32(sd["feature_projection.layer_norm.weight"]), hold.f32(sd["feature_projection.layer_norm.bias"])
-        w.fp_w = hold.w16(sd["feature_projection.projection.weight"], clo, cmx)
+        w.fp_w = hold.w16(sd["feature_projection.projection.weight"], clo, cmx, out="f32")
         w.fp_b = hold.f32(sd["feature_projection.projection.bias"])
         # positional conv: fold weight-norm (dim=2), then [D, Dg, K] -> [G, Dg, K*Dg] with column kk*Dg + ci
         p = "encoder.pos_conv_embed.conv."
@@ -502,7 +519,7 @@ class HipCLIPModel(_HipModule):
         pad = (-pw.shape[1]) % 8   # CLIP-L/14: 588 -> 592 zero columns (16-byte rows for the MFMA GEMM)
         if pad:
             pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
-        w.patch_w = hold.w16(pw, lo, tmx)
+        w.patch_w = hold.w16(pw, lo, tmx, out="f32")
         w.cls = hold.f32(sd[v + "embeddings.class_embedding"])
         w.pos = hold.f32(sd[v + "embeddings.position_embedding.weight"])
         w.pre_ln_g, w.pre_ln_b = hold.f32(sd[v + "pre_layrnorm.weight"]), hold.f32(sd[v + "pre_layrnorm.bias"])
@@ -589,7 +606,7 @@ class HipDinov2Model(_HipModule):
         pad = (-pw.shape[1]) % 8   # patch 14: 588 -> 592 zero columns
         if pad:
             pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
-        w.patch_w = hold.w16(pw, lo, tmx)
+        w.patch_w = hold.w16(pw, lo, tmx, out="f32")
         w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
         w.cls = hold.f32(sd["embeddings.cls_token"].reshape(D))
         w.pos = hold.f32(self.interpolate_pos_encoding(sd["embeddings.position_embeddings"], input_size // Pz))
@@ -695,7 +712,7 @@ class HipData2VecVisionModel(HipDinov2Model):
         pad = (-pw.shape[1]) % 8
         if pad:
             pw = torch.cat([pw, torch.zeros(pw.shape[0], pad)], 1)
-        w.patch_w = hold.w16(pw, lo, tmx)
+        w.patch_w = hold.w16(pw, lo, tmx, out="f32")
         w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
         w.cls = hold.f32(sd["embeddings.cls_token"].reshape(D))
         pos = sd.get("embeddings.position_embeddings")
@@ -788,7 +805,7 @@ class HipVideoMAEModel(_HipModule):
         cfg.final_ln = int("layernorm.weight" in sd)
         self.num_patches = (config.image_size // config.patch_size) ** 2 * (config.num_frames // config.tubelet_size)
         w = VideoMAEWeights()
-        w.patch_w = hold.w16(sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1), lo, tmx)
+        w.patch_w = hold.w16(sd["embeddings.patch_embeddings.projection.weight"].reshape(D, -1), lo, tmx, out="f32")
         w.patch_b = hold.f32(sd["embeddings.patch_embeddings.projection.bias"])
         w.pos = hold.f32(sinusoid_table(self.num_patches, D))
         if cfg.final_ln:

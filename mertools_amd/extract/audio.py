@@ -293,8 +293,11 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
             for i, it in enumerate(items):   # straight into the pinned staging block: one host copy per clip
                 dst[i] = it['raw']
             dev_block = up.up(block)
-            up.ready(dev_block)
-            rows = ops.wave_normalize(dev_block, do_normalize)
+            # the kernel launches on the CURRENT device's stream (ops.stream()) while Uploader.ready() orders the stream of
+            # model.device: make them the same device (a model on cuda:1 driven while cuda:0 is current)
+            with torch.cuda.device(model.device):
+                up.ready(dev_block)
+                rows = ops.wave_normalize(dev_block, do_normalize)
         flush(items, rows)
 
     def flush(items, rows=None):

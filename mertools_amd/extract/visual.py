@@ -109,7 +109,7 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             # resize) travel as ONE block on the upload stream and are resized / normalised by one launch each — no per-video H2D copy,
             # kernel launch or device allocation on this thread
             from .. import ops
-            with span("stage"):
+            with span("stage"), torch.cuda.device(model.device):   # (launch on the model's device, whichever is current)
                 block = up.gather([p for _, p in pending])
                 up.ready(block)
                 if tuple(block.shape[1:3]) != (size, size):
@@ -159,10 +159,11 @@ def extract(model, face_dir, save_dir, feature_level='UTTERANCE', vids=None, fra
             return p.to(model.device)
         from .. import ops
         p = p.to(model.device)
-        if tuple(p.shape[1:3]) != (size, size):
-            from .resize import resize_crop_u8
-            p = resize_crop_u8(p, size)
-        return ops.image_normalize_u8(p, CLIP_MEAN, CLIP_STD, bgr=True)
+        with torch.cuda.device(model.device):
+            if tuple(p.shape[1:3]) != (size, size):
+                from .resize import resize_crop_u8
+                p = resize_crop_u8(p, size)
+            return ops.image_normalize_u8(p, CLIP_MEAN, CLIP_STD, bgr=True)
 
     with writer(model.device, async_save) as out:
         for vid, kind, px in prefetch_map(host_stage, vids, workers, chunk=2):

@@ -57,7 +57,7 @@ def split16_host(x, dtype="f16", lo=True):
 
 def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=None, out32=False, out16=False,
            out16_lo=False, passes=1, dtype=None, tile=0, M=None, lda=None, a_rows_per_batch=0, a_batch_stride=0,
-           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, w_hi_blkp=None):
+           headmajor=None, w_mx=None, w_hi_blk=None, w_lo_blk=None, w_hi_blkp=None, w_hi_blkq=None, bias_seg_rows=0):
     """C = epilogue(A @ W^T) — plain (non-batched) form used by the tests. A [M,K], W [N,K]."""
     dtype = dt_code(dtype if dtype is not None else a_hi.dtype)
     N, K = w_hi.shape
@@ -70,8 +70,10 @@ def gemm16(a_hi, w_hi, *, a_lo=None, w_lo=None, bias=None, act=None, residual=No
     g.a_rows_per_batch, g.a_batch_stride = a_rows_per_batch, a_batch_stride
     g.w_hi, g.w_lo, g.ldw = _p(w_hi), _p(w_lo), w_hi.stride(0)
     g.w_mx = _p(w_mx)
-    g.w_hi_blk, g.w_lo_blk, g.w_hi_blkp = _p(w_hi_blk), _p(w_lo_blk), _p(w_hi_blkp)
+    g.w_hi_blk, g.w_lo_blk, g.w_hi_blkp, g.w_hi_blkq = _p(w_hi_blk), _p(w_lo_blk), _p(w_hi_blkp), _p(w_hi_blkq)
     g.bias, g.act = _p(bias), ACT[act]
+    if bias_seg_rows:   # `bias` is a per-sequence table [ceil(M / bias_seg_rows), N] (mer_seq_bias)
+        g.bias_seg_rows, g.bias_ld = int(bias_seg_rows), bias.stride(0)
     g.residual, g.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     dev = a_hi.device
     c32 = torch.empty((M, N), dtype=torch.float32, device=dev) if out32 else None
@@ -112,16 +114,31 @@ def w_block_pack(w16):
     return out
 
 
-def w_block_pack_p(w16):
-    """Device 16-bit plane [N, K] -> the row-permuted pre-blocked copy the PERSISTENT 256x256 one-pass kernel reads
-    (mer_w_block_pack_p: block row 16 q + i holds plane row 4 i + q of every 64-row group, so that a lane's four accumulators of an
-    output row are four consecutive columns and the epilogue stores whole lines from registers).  None when N % 256 or K % 32 != 0."""
+def w_block_pack_p(w16, layout):
+    """Device 16-bit plane [N, K] -> a row-permuted pre-blocked copy for the PERSISTENT 256x256 one-pass kernel
+    (mer_w_block_pack_p): layout 0 for GEMMs whose output is one 16-bit plane (a lane's eight accumulators of an output row become
+    eight consecutive columns: one 16-byte store), layout 1 for fp32 outputs (two runs of four columns: two 16-byte stores / residual
+    loads) — the epilogue stores whole lines from registers.  None when N % 256 or K % 32 != 0."""
     assert w16.is_cuda and w16.dim() == 2 and w16.element_size() == 2 and w16.stride(1) == 1
     N, K = w16.shape
     if N % 256 != 0 or K % 32 != 0 or w16.stride(0) % 8 != 0:
         return None
     out = torch.empty(N * K * 2, dtype=torch.uint8, device=w16.device)
-    _lib.check(_lib.lib().mer_w_block_pack_p(w16.data_ptr(), w16.stride(0), N, K, out.data_ptr(), stream()), "mer_w_block_pack_p")
+    _lib.check(_lib.lib().mer_w_block_pack_p(w16.data_ptr(), w16.stride(0), N, K, int(layout), out.data_ptr(), stream()), "mer_w_block_pack_p")
+    return out
+
+
+def seq_bias(a16, w_lo, seg_rows, bias=None, valid_rows=None, M=None):
+    """table[s, n] = bias[n] + mean_{sampled rows of sequence s}(a16)[k] * w_lo[n, k] (mer_seq_bias): the per-sequence weight-residual
+    correction of a one-pass GEMM; pass the result as gemm16(bias=table, bias_seg_rows=seg_rows)."""
+    assert a16.is_cuda and a16.dim() == 2 and a16.stride(1) == 1 and w_lo.dim() == 2 and w_lo.stride(1) == 1
+    M = M if M is not None else a16.shape[0]
+    K, N = a16.shape[1], w_lo.shape[0]
+    nseq = (M + seg_rows - 1) // seg_rows
+    scratch = torch.empty(_lib.lib().mer_seq_bias_scratch_bytes(nseq, K), dtype=torch.uint8, device=a16.device)
+    out = torch.empty((nseq, N), dtype=torch.float32, device=a16.device)
+    _lib.check(_lib.lib().mer_seq_bias(a16.data_ptr(), dt_code(a16.dtype), a16.stride(0), 0, 0, M, K, int(seg_rows), _p(valid_rows),
+                                       w_lo.data_ptr(), w_lo.stride(0), _p(bias), N, scratch.data_ptr(), out.data_ptr(), N, stream()), "mer_seq_bias")
     return out
 
 

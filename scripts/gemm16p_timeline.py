@@ -4,8 +4,6 @@ import sys
 
 import numpy as np
 
-SLOTS = ["tile start", "mid kt0", "mid kt1", "mid kt2", "mid kt3", "mid kt4", "mid kt5", "mid kt6", "mid kt7", "K loop done", "ring issued",
-         "epilogue done", "past X'", "g1 epi start", "g1 epi end", ""]
 
 
 def main(path):
@@ -23,8 +21,7 @@ def main(path):
             steady = ok
         d = lambda i, j: np.median((t[:, :, j] - t[:, :, i])[steady])
         rows = [("tile start -> mid kt0", 0, 1)] + [(f"mid kt{k} -> mid kt{k + 1}", 1 + k, 2 + k) for k in range(7)]
-        rows += [("mid kt7 -> K loop done", 8, 9), ("K loop done -> ring issued", 9, 10), ("ring issued -> epilogue done", 10, 11),
-                 ("epilogue done -> past X'", 11, 12)]
+        rows += [("mid kt7 -> K loop done", 8, 9), ("K loop done -> boundary slab issued", 9, 10), ("boundary slab -> epilogue done", 10, 11)]
         if g == 1:
             rows = rows[:9] + [("mid kt7 -> K loop done", 8, 9), ("in-loop epilogue (13 -> 14)", 13, 14)]
         for name, i, j in rows:

@@ -1,0 +1,15 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r4c7; mkdir -p "$O"
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "seq_bias or bias_table" > "$O/gemm_tests.log" 2>&1; echo "seq_bias tests rc=$?"; grep -E "passed|failed|^FAILED|AssertionError" "$O/gemm_tests.log" | cut -c1-300 | tail -8
+timeout 300 python tests/studies/hubert_batch_split_gpu.py mean > "$O/hubert_batch_split.txt" 2>&1; tail -13 "$O/hubert_batch_split.txt" | head -4
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sustained --no-large --e2e 0 > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
+python - "$O/bench.json" <<'P'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1])); r = d["roofline"]
+    print(d["value"], d["ms_per_step"], d["parity"], r["kernel"], r["achieved"], r["frac"], r["whole_step_tflops"]); print(r["other_kernels"])
+except Exception as e:
+    print("bench parse failed", e); print(open(sys.argv[1].replace(".json", ".err")).read()[-2500:])
+P

@@ -85,7 +85,7 @@ static void run_shape(const Shape& s, int warm, int reps) {
   void* wlo_blk = wlo ? dev_alloc((size_t)mer_w_block_bytes(s.N, s.K), 0) : nullptr;
   void* wblkp = (s.N % 256 == 0 && s.K % 32 == 0) ? dev_alloc((size_t)s.N * s.K * 2, 0) : nullptr;   // the persistent kernel's plane
   MER(mer_w_block_pack(w, s.K, s.N, s.K, wblk, nullptr));
-  if (wblkp) MER(mer_w_block_pack_p(w, s.K, s.N, s.K, wblkp, nullptr));
+  if (wblkp) MER(mer_w_block_pack_p(w, s.K, s.N, s.K, s.out16 ? 0 : 1, wblkp, nullptr));
   if (wlo) MER(mer_w_block_pack(wlo, s.K, s.N, s.K, wlo_blk, nullptr));
   void* wmx = nullptr;
   if (s.passes == 4) {
@@ -116,7 +116,7 @@ static void run_shape(const Shape& s, int warm, int reps) {
            s.name, s.M, s.N, s.K, s.passes, variant, us, flops / us * 1e-6);
     fflush(stdout);
   };
-  g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk; g.w_hi_blkp = wblkp;
+  g.w_hi_blk = wblk; g.w_lo_blk = wlo_blk; g.w_hi_blkp = s.out16 ? wblkp : nullptr; g.w_hi_blkq = s.out16 ? nullptr : wblkp;
   // interleaved A/B in one process (same clocks, same box): the tile kernel (gemm16_kernel) against the persistent one, twice each
   for (int round = 0; round < 2; ++round) {
     MER(mer_set_option("gemm_persist", 0));

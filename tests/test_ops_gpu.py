@@ -682,21 +682,24 @@ def test_attention_cls(dev, dtype, B, T, H, lens):
 
 
 def test_w_block_pack_p_layout(dev):
-    """mer_w_block_pack_p: block row 16 q + i of every 64-row group holds plane row 4 i + q (the persistent kernel's lanes then own
-    4 consecutive output columns); k-slab blocking and chunk swizzle as mer_w_block_pack."""
+    """mer_w_block_pack_p: block row 16 q + i of every 128-row group holds plane row 8 i + q (layout 0: a lane's eight accumulators
+    are eight consecutive columns) or 64 (q / 4) + 4 i + q % 4 (layout 1: two runs of four); k-slab blocking and chunk swizzle as
+    mer_w_block_pack."""
     ops = _ops()
     N, K = 512, 96
     w = torch.arange(N * K, dtype=torch.int32).to(torch.int16).view(N, K).to(dev)
-    out = ops.w_block_pack_p(w.view(torch.float16)).view(torch.int16).cpu().view(2, K // 32, 256, 4, 8)
     wc = w.cpu()
-    for tn in range(2):
-        for kt in range(K // 32):
-            for r in (0, 1, 15, 16, 17, 47, 63, 64, 100, 255):
-                n = tn * 256 + (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3)
-                for pc in range(4):
-                    lc = pc ^ ((-(r >> 2)) & 3)
-                    assert torch.equal(out[tn, kt, r, pc], wc[n, kt * 32 + lc * 8: kt * 32 + lc * 8 + 8]), (tn, kt, r, pc)
-    assert ops.w_block_pack_p(w.view(torch.float16)[:300]) is None      # N % 256 != 0: no persistent plane
+    for layout in (0, 1):
+        out = ops.w_block_pack_p(w.view(torch.float16), layout).view(torch.int16).cpu().view(2, K // 32, 256, 4, 8)
+        for tn in range(2):
+            for kt in range(K // 32):
+                for r in (0, 1, 15, 16, 17, 47, 63, 64, 100, 127, 128, 200, 255):
+                    i, q = r & 15, (r >> 4) & 7
+                    n = tn * 256 + (r & ~127) + (8 * i + q if layout == 0 else 64 * (q // 4) + 4 * i + q % 4)
+                    for pc in range(4):
+                        lc = pc ^ ((-(r >> 2)) & 3)
+                        assert torch.equal(out[tn, kt, r, pc], wc[n, kt * 32 + lc * 8: kt * 32 + lc * 8 + 8]), (layout, tn, kt, r, pc)
+    assert ops.w_block_pack_p(w.view(torch.float16)[:300], 0) is None      # N % 256 != 0: no persistent plane
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -716,8 +719,8 @@ def test_gemm16_persistent_equals_tile_kernel(dev, M, N, K, dtype):
     w = _rand((N, K), 92) * 0.05
     ah, _ = ops.split16(a.to(dev), dtype, lo=False)
     wh = ops.split16_host(w, dtype)[0].to(dev)
-    hb, hp = ops.w_block_pack(wh), ops.w_block_pack_p(wh)
-    assert hp is not None
+    hb, hp, hq = ops.w_block_pack(wh), ops.w_block_pack_p(wh, 0), ops.w_block_pack_p(wh, 1)
+    assert hp is not None and hq is not None
     bias, res = _rand((N,), 93).to(dev), _rand((M, N), 94).to(dev)
     cases = [dict(out16=True, act=act, bias=bias) for act in (None, "gelu", "quick_gelu", "gelu_new")]
     cases += [dict(out16=True, act=None, bias=None)]
@@ -727,11 +730,11 @@ def test_gemm16_persistent_equals_tile_kernel(dev, M, N, K, dtype):
         kw = dict(kw, passes=1, tile=3, dtype=dtype)
         try:
             lib.mer_set_option(b"gemm_persist", 0)
-            r32, r16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, **kw)
+            r32, r16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq, **kw)
         finally:
             lib.mer_set_option(b"gemm_persist", 1)
         for rep in range(3):
-            c32, c16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, **kw)
+            c32, c16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq, **kw)
             torch.cuda.synchronize()
             what = f"persistent gemm16 {kw.get('act')} out16={kw.get('out16', False)} res={'residual' in kw} rep {rep}"
             if r16 is not None:
@@ -743,7 +746,7 @@ def test_gemm16_persistent_equals_tile_kernel(dev, M, N, K, dtype):
     g = ops.GemmArgs()
     g.M, g.N, g.K, g.dtype = M, N, K, ops.dt_code(dtype)
     g.a_hi, g.lda, g.w_hi, g.ldw = ah.data_ptr(), K, wh.data_ptr(), K
-    g.w_hi_blk, g.w_hi_blkp = hb.data_ptr(), hp.data_ptr()
+    g.w_hi_blk, g.w_hi_blkp, g.w_hi_blkq = hb.data_ptr(), hp.data_ptr(), hq.data_ptr()
     g.bias, g.act, g.residual, g.ldr, g.c32, g.ldc32 = bias.data_ptr(), ops.ACT[None], inplace.data_ptr(), N, inplace.data_ptr(), N
     g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, 1, 3
     ops.gemm16_raw(g)
@@ -766,7 +769,7 @@ def test_gemm16_persistent_conv_rows(dev):
     w = _rand((C, k * C), 96) * 0.03
     xh, _ = ops.split16(x.to(dev), "f16", lo=False)
     wh = ops.split16_host(w, "f16")[0].to(dev)
-    hb, hp = ops.w_block_pack(wh), ops.w_block_pack_p(wh)
+    hb, hp = ops.w_block_pack(wh), ops.w_block_pack_p(wh, 0)
     kw = dict(act="gelu", out16=True, passes=1, tile=3, M=B * Tout, lda=s * C, a_rows_per_batch=Tout, a_batch_stride=Tin * C)
     try:
         lib.mer_set_option(b"gemm_persist", 0)
@@ -778,3 +781,78 @@ def test_gemm16_persistent_conv_rows(dev):
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
     win = x.view(B, Tin, C).unfold(1, k, s).permute(0, 1, 3, 2).reshape(B * Tout, k * C)    # [B, Tout, C, k] -> (kk, ci) order
     assert_close(out.float().cpu(), F.gelu(win.double() @ w.double().T).float(), 2e-3, "persistent conv GEMM vs fp64")
+
+
+@pytest.mark.parametrize("T,nseq,K,N", [(197, 40, 768, 2304), (64, 64, 768, 768), (249, 9, 3072, 768), (1568, 3, 1024, 512), (1, 70, 768, 3072), (7, 11, 96, 200)])
+def test_seq_bias(dev, T, nseq, K, N):
+    """mer_seq_bias: table[s, n] = bias[n] + mean_{rows h, h + st, ... < valid[s]}(A[s T + ., :]) . w_lo[n, :], st the largest power
+    of two leaving >= 16 samples, h = st / 2; the 16-bit mean plane is the exact sample mean rounded once.  Against the same
+    sample in fp64; a sequence's row must not depend on its batch mates (bit for bit: the same clips in another batch order)."""
+    ops = _ops()
+    M = T * nseq - (T // 3 if T > 3 else 0)          # last sequence partial
+    a = (_rand((T * nseq, K), 101) * 0.7 + 0.3)[:M]
+    wlo = _rand((N, K), 102) * 1e-4
+    bias = _rand((N,), 103)
+    g = torch.Generator().manual_seed(104)
+    valid = torch.randint(max(T // 2, 1), T + 1, (nseq,), generator=g, dtype=torch.int32)
+    ah = a.to(dev).half()
+    wl = wlo.to(dev).half()
+    st = 1
+    while st * 2 * 16 <= T:
+        st *= 2
+    for use_valid in (False, True):
+        tab = ops.seq_bias(ah, wl, T, bias=bias.to(dev), valid_rows=valid.to(dev) if use_valid else None)
+        torch.cuda.synchronize()
+        ref = torch.empty((nseq, N), dtype=torch.float64)
+        for s in range(nseq):
+            lim = min(int(valid[s]) if use_valid else T, M - s * T)
+            rows = [s * T + t for t in range(st // 2, lim, st)]
+            mean = ah[rows].cpu().double().mean(0).half().double() if rows else torch.zeros(K, dtype=torch.float64)
+            ref[s] = mean @ wl.cpu().double().T + bias.double()
+        assert_close(tab.cpu(), ref.float(), 2e-6, f"seq_bias T={T} valid={use_valid}")
+    # batch-mate independence: sequences 0 .. 3 alone == their rows of the full table
+    if nseq >= 4 and M >= 4 * T:
+        full = ops.seq_bias(ah, wl, T, bias=bias.to(dev))
+        part = ops.seq_bias(ah[:4 * T].contiguous(), wl, T, bias=bias.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(full[:4], part)
+
+
+@pytest.mark.parametrize("T,M", [(197, 9000), (64, 9000), (249, 9000), (40, 9000), (1568, 6000), (249, 70000), (64, 90000)])
+def test_gemm16_bias_table(dev, T, M):
+    """mer_gemm16 with a per-sequence bias table (bias_seg_rows): output row m takes row m / T of the table.  The persistent
+    kernel (rows of the table staged in LDS, selected per output row), the 256x256 / 128x128 tile kernels (generic and fp32
+    epilogues) and fp64 agree — bit for bit between the kernels — for 16-bit, fp32 and fp32 + residual outputs, ragged M."""
+    from mertools_amd import _lib
+    ops = _ops()
+    lib = _lib.lib()
+    K, N = 768, 768     # (M = 70000 / 90000: 822 / 1056 tiles, three or four per workgroup — the table rows of the NEXT tile are staged under this one)
+    nseq = (M + T - 1) // T
+    a = _rand((M, K), 111)
+    w = _rand((N, K), 112) * 0.05
+    tab = _rand((nseq, N), 113).to(dev)
+    res = _rand((M, N), 114).to(dev)
+    ah, _ = ops.split16(a.to(dev), "f16", lo=False)
+    wh = ops.split16_host(w, "f16")[0].to(dev)
+    hb, hp, hq = ops.w_block_pack(wh), ops.w_block_pack_p(wh, 0), ops.w_block_pack_p(wh, 1)
+    rowseq = (torch.arange(M) // T)
+    z = a.double() @ w.double().T + tab.cpu().double()[rowseq]
+    outs = {}
+    for name, persist, tile in (("persistent", 1, 3), ("tile256", 0, 3)) + ((("tile128", 0, 1),) if M < 20000 else ()):
+        try:
+            lib.mer_set_option(b"gemm_persist", persist)
+            kw = dict(bias=tab, bias_seg_rows=T, passes=1, tile=tile, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq)
+            _, c16, _ = ops.gemm16(ah, wh, act="gelu", out16=True, **kw)
+            c32, _, _ = ops.gemm16(ah, wh, out32=True, **kw)
+            r32, _, _ = ops.gemm16(ah, wh, out32=True, residual=res, **kw)
+        finally:
+            lib.mer_set_option(b"gemm_persist", 1)
+        torch.cuda.synchronize()
+        outs[name] = (c16, c32, r32)
+    for name in [n for n in ("tile256", "tile128") if n in outs]:
+        for i, what in enumerate(("16-bit gelu", "fp32", "fp32 + residual")):
+            assert torch.equal(outs["persistent"][i].view(torch.int16 if i == 0 else torch.int32),
+                               outs[name][i].view(torch.int16 if i == 0 else torch.int32)), f"bias table T={T}: persistent vs {name}, {what}"
+    assert_close(outs["persistent"][0].float().cpu(), F.gelu(z).float(), 2e-3, f"bias table T={T}, 16-bit gelu vs fp64")
+    assert_close(outs["persistent"][1].cpu(), z.float(), 1e-3, f"bias table T={T}, fp32 vs fp64")
+    assert_close(outs["persistent"][2].cpu(), (z + res.cpu().double()).float(), 1e-3, f"bias table T={T}, fp32 + residual vs fp64")
