@@ -182,13 +182,20 @@ def cpu_baseline():
 
 
 def kernel_source_sha(root=ROOT):
-    """sha256[:16] of the GEMM kernel template (csrc/gemm16_impl.h; gemm16.hip only holds the C ABI and the option table) — the stamp
-    scripts/pmc_summarize.py writes into a PMC collection."""
+    """sha256[:16] over every source of the HIP library (mertools_amd/csrc/*.{h,hip,cpp}, sorted by name) — the stamp scripts/pmc_summarize.py,
+    scripts/pmc_mfma_summarize.py and scripts/stamp_kernel_stats.py write into a profile: a collection is only quoted for the tree it was taken on."""
+    import glob
     import hashlib
-    return hashlib.sha256(open(os.path.join(root, "mertools_amd", "csrc", "gemm16_impl.h"), "rb").read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "mertools_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
-PMC_KERNEL_PREFIX = {"gemm16": "gemm16<f16,256,256,32,2,4,1,1,", "gemm16_mx": "gemm16<f16,256,256,32,4,2,1,1,", "gemm16_w2": "gemm16<f16,256,256,32,2,4,1,2,"}
+# (the one-pass launches of the step: the persistent family gemm16p_kernel<f16, EPI, ACT> — the summarisers pool its instantiations under "gemm16p")
+PMC_KERNEL_PREFIX = {"gemm16": "gemm16p", "gemm16_mx": "gemm16<f16,256,256,32,4,2,1,1,", "gemm16_w2": "gemm16<f16,256,256,32,2,4,1,2,"}
 
 
 def pmc_traffic(kernel, algorithmic_bytes_per_launch, root=ROOT):

@@ -136,11 +136,12 @@ int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch,
  * sample of a sequence is rows h, h + s, h + 2 s, ... below its valid length (valid_rows[s], or seg_rows), s the largest power of two
  * that leaves at least 16 samples, h = s / 2; sums are exact 64-bit fixed-point integers, one owner per element (no atomics): the row
  * of a sequence depends on that sequence alone, bit for bit — whatever else is in the batch.  The one-pass GEMM that follows takes the
- * table through mer_gemm16_args.bias / bias_seg_rows / bias_ld.  scratch: device, mer_seq_bias_scratch_bytes(nseq, K) bytes, 16-byte
+ * table through mer_gemm16_args.bias / bias_seg_rows / bias_ld.  Columns below n_first (a multiple of 16) get the plain bias (the
+ * Q | K columns of a fused QKV weight need no correction).  scratch: device, mer_seq_bias_scratch_bytes(nseq, K) bytes, 16-byte
  * aligned (the 16-bit mean plane); table: device fp32 [nseq, ldt].  Two small launches on `stream`. */
 long long mer_seq_bias_scratch_bytes(int nseq, int K);
 int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
-                 int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
+                 int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N, int n_first,
                  void* scratch, float* table, long long ldt, mer_stream_t stream);
 
 /* Pre-blocked weight plane: a DEVICE 16-bit plane w [N, K] (row stride ldw, K % 32 == 0) is re-laid as

@@ -60,6 +60,7 @@ struct CorrWs {
   CorrArena* arena;
   int seg_rows;          // rows per sequence of the A plane (1: every row is its own sequence; 0: no sequence structure -> no table) ...
   const int* valid;      // ... ragged batches: device int32 [nseq] valid rows of each (NULL: every row counts)
+  int n_first;           // output columns below this take the plain bias (fused QKV: the Q | K columns)
 };
 static void corr_plan(Arena& ar, CorrArena& ca, bool on, int kmax, long long nmax, int nseq) {
   ca.nseq = nseq; ca.kmax = kmax; ca.nmax = (nmax + 3) / 4 * 4;
@@ -78,7 +79,7 @@ static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
       g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
     } else {
       int rc = mer_seq_bias(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->seg_rows, cw->valid,
-                            g.w_lo, g.ldw, g.bias, g.N, ca->mean16, ca->table, g.N, (mer_stream_t)st);
+                            g.w_lo, g.ldw, g.bias, g.N, cw->n_first, ca->mean16, ca->table, g.N, (mer_stream_t)st);
       if (rc != MER_OK) return rc;
       g.passes = 1;
       g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
@@ -170,10 +171,14 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
   const int ps1 = (sel && (c.mx_skip & 2)) ? 1 : ps;       // fc1 without the correction
   const int ps2 = (sel && (c.mx_skip & 4)) ? 1 : ps;       // fc2 without the correction
   // passes == 5: the correction goes through the batch's mean token (run_gemm() above); a sequence = T rows, kv_len = its valid rows
-  const CorrWs cwv = {&b.corr, T, kv_len};
+  const CorrWs cwv = {&b.corr, T, kv_len, 0};
+  const CorrWs cwqkv = {&b.corr, T, kv_len, (c.mx_skip & 1) && (2 * D) % 16 == 0 ? 2 * D : 0};   // Q | K uncorrected (mx_skip bit 0)
   const CorrWs* mc = (ps == 5 && b.corr.mean16) ? &cwv : nullptr;
-  const CorrWs cw1 = {&b.corr, 1, nullptr};                  // CLS-only block: one row per sequence (its "mean" is the row itself)
+  const CorrWs cw1 = {&b.corr, 1, nullptr, 0};                  // CLS-only block: one row per sequence (its "mean" is the row itself)
   const CorrWs* mc1 = mc ? &cw1 : nullptr;
+  const CorrWs* mcq = mc ? &cwqkv : nullptr;
+  const CorrWs cwkv = {&b.corr, T, kv_len, (c.mx_skip & 1) && D % 16 == 0 ? D : 0};          // CLS-only block's K | V GEMM: K uncorrected
+  const CorrWs* mckv = mc ? &cwkv : nullptr;
   const float scale = 1.0f / sqrtf((float)(D / H));
   const P16 none = {nullptr, nullptr};
   for (int l = 0; l < c.layers; ++l) {
@@ -192,7 +197,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                            (w.wqkv.lo_blk && tiles) ? (const char*)w.wqkv.lo_blk + woff : nullptr,
                            (w.wqkv.hi_blkp && tiles) ? (const char*)w.wqkv.hi_blkp + woff : nullptr, nullptr};
       const P16 ckv = {(char*)b.qkv16.hi + (long long)D * 2, nullptr};
-      MER_TRY(gemm(st, dt, ps, M, 2 * D, D, b.cur16, D, wkv, w.bqkv + D, MER_ACT_NONE, nullptr, 0, nullptr, 0, ckv, 3 * D, mc));
+      MER_TRY(gemm(st, dt, ps, M, 2 * D, D, b.cur16, D, wkv, w.bqkv + D, MER_ACT_NONE, nullptr, 0, nullptr, 0, ckv, 3 * D, mckv));
       // ... Q for the CLS rows (row n of the A operand = token 0 of sequence n: lda = T * D)
       const mer_w16 wq = {w.wqkv.hi, w.wqkv.lo, nullptr, nullptr, nullptr, nullptr, nullptr};
       MER_TRY(gemm(st, dt, ps, Bseq, D, D, b.cur16, (long long)T * D, wq, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, cls->q16, D, mc1));
@@ -221,7 +226,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
       MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, mc));
     } else
-    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D, mc));
+    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D, mcq));
     const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
     if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
       const float* gate = nullptr;
@@ -452,7 +457,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
     g.w_hi_blk = w.conv_w[i].hi_blk; g.w_lo_blk = w.conv_w[i].lo_blk; g.w_hi_blkp = w.conv_w[i].hi_blkp; g.w_hi_blkq = w.conv_w[i].hi_blkq;
     g.bias = c.conv_bias ? w.conv_b[i] : nullptr;
     g.nbatch = 1; g.nb_inner = 1; g.passes = cps;
-    const CorrWs ccw = {&p.tf.corr, p.T[i], valid_samples ? p.vlen + (long long)i * B : nullptr};
+    const CorrWs ccw = {&p.tf.corr, p.T[i], valid_samples ? p.vlen + (long long)i * B : nullptr, 0};
     const CorrWs* cw = corr_on ? &ccw : nullptr;
     if (c.feat_norm_group) {
       g.act = MER_ACT_GELU;
@@ -473,7 +478,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   // feature projection: LayerNorm(C) -> Linear(C -> D)   (HF:hubert/modeling_hubert.py:216-231)
   if (c.feat_proj_layer_norm)
     MER_TRY(mer_layernorm(p.conv_last32, C, w.fp_ln_g, w.fp_ln_b, c.tf.ln_eps, M, C, MER_ACT_NONE, nullptr, 0, p.fp16.hi, p.fp16.lo, C, dt, st));
-  const CorrWs pcw = {&p.tf.corr, Tn, tn_len};
+  const CorrWs pcw = {&p.tf.corr, Tn, tn_len, 0};
   // (behind a LayerNorm: rows of one size, so the per-sequence table applies under "mean" as it does in the blocks; the conv stack above
   //  reads un-normalised GELU outputs and keeps its per-row MX correction — DESIGN.md §4)
   const bool fp_tab = (cps == 5 || (c.tf.passes == 5 && c.feat_proj_layer_norm)) && p.tf.corr.mean16;
@@ -622,7 +627,7 @@ extern "C" int mer_vit_forward_tokens(const mer_vit* h, const float* pixels, int
   const P16 none = {nullptr, nullptr};
   // patch embedding: Conv2d(stride == kernel, no bias) == GEMM over patch rows   (HF:clip/modeling_clip.py:138-217)
   MER_TRY(mer_vit_patchify(pixels, N, c.channels, c.image_size, c.image_size, c.patch_size, p.patches.hi, p.patches.lo, dt, st));
-  const CorrWs pcw = {&p.tf.corr, P, nullptr};
+  const CorrWs pcw = {&p.tf.corr, P, nullptr, 0};
   MER_TRY(gemm(st, dt, ps, N * P, D, cols, p.patches, cols, w.patch_w, c.variant == 1 ? w.patch_b : nullptr, MER_ACT_NONE, nullptr, 0,
                p.patch32, D, none, 0, &pcw));
   // [CLS] + position embeddings (+ pre_layrnorm for CLIP; DINOv2 has no embedding LayerNorm: gamma == NULL stores the plain sum)
@@ -717,7 +722,7 @@ extern "C" int mer_videomae_forward(const mer_videomae* h, const float* pixels, 
   // tubelet embedding: Conv3d(stride == kernel, bias) == GEMM over tubelet rows; + fixed sin-cos positions
   MER_TRY(mer_video_patchify(pixels, B, c.num_frames, c.channels, c.image_size, c.image_size, c.patch_size, c.tubelet_size,
                              p.patches.hi, p.patches.lo, dt, st));
-  const CorrWs pcw = {&p.tf.corr, NP, nullptr};
+  const CorrWs pcw = {&p.tf.corr, NP, nullptr, 0};
   MER_TRY(gemm(st, dt, ps, B * NP, D, cols, p.patches, cols, w.patch_w, w.patch_b, MER_ACT_NONE, nullptr, 0, x, D, none, 0, &pcw));
   MER_TRY(mer_add_pos(x, w.pos, (long long)B * NP, NP, D, st));
   HsMap hs;

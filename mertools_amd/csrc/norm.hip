@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void seqmean16_kernel(const T* a, long long ld
 
 template <typename T>
 __global__ __launch_bounds__(256) void seqbias_kernel(const T* mean16, long long ldm, int nseq, int K, const T* w_lo, long long ldw,
-                                                      const float* bias, int N, float* tab, long long ldt) {
+                                                      const float* bias, int N, int n_first, float* tab, long long ldt) {
   // workgroup = 64 sequences x 16 columns; its 4 waves split K (a 768-deep dot product is 24 dependent L2 round trips for one
   // wave: this launch is latency, not bandwidth), 4 k-steps of loads in flight per wave, partial tiles summed in wave order through
   // LDS (a fixed order: the row of a sequence does not depend on the batch around it)
@@ -512,7 +512,9 @@ __global__ __launch_bounds__(256) void seqbias_kernel(const T* mean16, long long
   const int n0 = blockIdx.x * 16, s0 = blockIdx.y * 64;
   const int n = n0 + li < N ? n0 + li : N - 1;
   const int ksteps = (K + 31) / 32, per = (ksteps + 3) / 4;
-  const int k_lo = wave * per * 32, k_hi = (wave + 1) * per * 32 < K ? (wave + 1) * per * 32 : K;
+  // columns below n_first take the plain bias (the Q | K columns of a fused QKV weight: their rounding only perturbs softmax logits)
+  const bool plain = n0 + 16 <= n_first;
+  const int k_lo = wave * per * 32, k_hi = plain ? 0 : ((wave + 1) * per * 32 < K ? (wave + 1) * per * 32 : K);
   const T* wr = w_lo + (long long)n * ldw + lg * 8;
   const T* mr[4];
 #pragma unroll
@@ -563,10 +565,10 @@ extern "C" long long mer_seq_bias_scratch_bytes(int nseq, int K) {
 }
 
 extern "C" int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
-                            int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
+                            int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N, int n_first,
                             void* scratch, float* table, long long ldt, mer_stream_t stream) {
   using namespace mer;
-  MER_REQUIRE(a && w_lo && scratch && table && M > 0 && K > 0 && N > 0 && seg_rows > 0, MER_EINVAL, "mer_seq_bias: bad argument");
+  MER_REQUIRE(a && w_lo && scratch && table && M > 0 && K > 0 && N > 0 && seg_rows > 0 && n_first >= 0 && n_first % 16 == 0, MER_EINVAL, "mer_seq_bias: bad argument");
   MER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && a_batch_stride % 8 == 0 && ((((uintptr_t)a | (uintptr_t)w_lo | (uintptr_t)scratch) & 15) == 0), MER_ESHAPE,
               "mer_seq_bias: K, lda, ldw, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
   MER_REQUIRE(ldt >= N, MER_ESHAPE, "mer_seq_bias: ldt < N");
@@ -576,13 +578,13 @@ extern "C" int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_
   MER_REQUIRE(nseq <= 65535, MER_EUNSUPPORTED, "mer_seq_bias: %d sequences > 65535", nseq);
   dim3 g1((unsigned)cdiv(K, 512), (unsigned)nseq), g2((unsigned)cdiv(N, 16), (unsigned)cdiv(nseq, 64));
   const int samples = (seg_rows + seq_sample_stride(seg_rows) - 1) / seq_sample_stride(seg_rows);
-  ProfScope prof("bias_corr", 2.0 * nseq * (double)N * K, (double)nseq * samples * K * 2 + (double)N * K * 2 + (double)nseq * N * 4, st);
+  ProfScope prof("bias_corr", 2.0 * nseq * (double)(N - n_first) * K, (double)nseq * samples * K * 2 + (double)N * K * 2 + (double)nseq * N * 4, st);
   if (dtype == MER_DT_F16) {
     hipLaunchKernelGGL((seqmean16_kernel<f16>), g1, dim3(256), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (f16*)scratch, (long long)K);
-    hipLaunchKernelGGL((seqbias_kernel<f16>), g2, dim3(256), 0, st, (const f16*)scratch, (long long)K, nseq, K, (const f16*)w_lo, ldw, bias, N, table, ldt);
+    hipLaunchKernelGGL((seqbias_kernel<f16>), g2, dim3(256), 0, st, (const f16*)scratch, (long long)K, nseq, K, (const f16*)w_lo, ldw, bias, N, n_first, table, ldt);
   } else {
     hipLaunchKernelGGL((seqmean16_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (bf16*)scratch, (long long)K);
-    hipLaunchKernelGGL((seqbias_kernel<bf16>), g2, dim3(256), 0, st, (const bf16*)scratch, (long long)K, nseq, K, (const bf16*)w_lo, ldw, bias, N, table, ldt);
+    hipLaunchKernelGGL((seqbias_kernel<bf16>), g2, dim3(256), 0, st, (const bf16*)scratch, (long long)K, nseq, K, (const bf16*)w_lo, ldw, bias, N, n_first, table, ldt);
   }
   return check_launch("seq_bias");
 }

@@ -128,7 +128,7 @@ def w_block_pack_p(w16, layout):
     return out
 
 
-def seq_bias(a16, w_lo, seg_rows, bias=None, valid_rows=None, M=None):
+def seq_bias(a16, w_lo, seg_rows, bias=None, valid_rows=None, M=None, n_first=0):
     """table[s, n] = bias[n] + mean_{sampled rows of sequence s}(a16)[k] * w_lo[n, k] (mer_seq_bias): the per-sequence weight-residual
     correction of a one-pass GEMM; pass the result as gemm16(bias=table, bias_seg_rows=seg_rows)."""
     assert a16.is_cuda and a16.dim() == 2 and a16.stride(1) == 1 and w_lo.dim() == 2 and w_lo.stride(1) == 1
@@ -138,7 +138,7 @@ def seq_bias(a16, w_lo, seg_rows, bias=None, valid_rows=None, M=None):
     scratch = torch.empty(_lib.lib().mer_seq_bias_scratch_bytes(nseq, K), dtype=torch.uint8, device=a16.device)
     out = torch.empty((nseq, N), dtype=torch.float32, device=a16.device)
     _lib.check(_lib.lib().mer_seq_bias(a16.data_ptr(), dt_code(a16.dtype), a16.stride(0), 0, 0, M, K, int(seg_rows), _p(valid_rows),
-                                       w_lo.data_ptr(), w_lo.stride(0), _p(bias), N, scratch.data_ptr(), out.data_ptr(), N, stream()), "mer_seq_bias")
+                                       w_lo.data_ptr(), w_lo.stride(0), _p(bias), N, int(n_first), scratch.data_ptr(), out.data_ptr(), N, stream()), "mer_seq_bias")
     return out
 
 

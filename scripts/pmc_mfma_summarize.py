@@ -22,7 +22,9 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row["Kernel_Name"]
-            if "gemm16_kernel" in name:
+            if "gemm16p_kernel" in name:   # the persistent one-pass family: every <dtype, EPI, ACT> instantiation pooled
+                short = "gemm16p"
+            elif "gemm16_kernel" in name:
                 targs = name.split("gemm16_kernelI")[1].split("EEvNS")[0]
                 short = "gemm16<" + ",".join([("f16" if targs.startswith("DF16_") else "bf16")] + re.findall(r"L[ib](\d+)E", targs)) + ">"
             else:
@@ -38,6 +40,11 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE",
     out[k] = dict(launches=n, counters_per_launch={c: round(x, 1) for c, x in mean.items()},
                   mfma_busy=round(busy / (act / XCDS * SIMDS), 4) if act else None)
     print(f"{k[:64]:64s} {n:8d} {out[k]['mfma_busy'] if out[k]['mfma_busy'] is not None else float('nan'):9.4f} {mean.get('SQ_INSTS_MFMA', 0):18.0f} {act:12.0f}")
-csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mertools_amd", "csrc")
-out["_source_sha"] = hashlib.sha256(open(os.path.join(csrc, "gemm16_impl.h"), "rb").read()).hexdigest()[:16]
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in sorted(glob.glob(os.path.join(_root, "mertools_amd", "csrc", "*"))):   # every source of the library: the stamp bench.py checks
+    if _f.endswith((".h", ".hip", ".cpp")):
+        _h.update(os.path.basename(_f).encode())
+        _h.update(open(_f, "rb").read())
+out["_source_sha"] = _h.hexdigest()[:16]
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)

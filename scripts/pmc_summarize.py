@@ -18,7 +18,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row["Kernel_Name"]
-                if "gemm16_kernel" in name:   # keep every template argument: <dtype,BM,BN,BK,WM,WN,AP,WP,GLDS,NS,MX[,STAMP]>
+                if "gemm16p_kernel" in name:   # the persistent one-pass family: every <dtype, EPI, ACT> instantiation pooled
+                    short = "gemm16p"
+                elif "gemm16_kernel" in name:   # keep every template argument: <dtype,BM,BN,BK,WM,WN,AP,WP,GLDS,NS,MX[,STAMP]>
                     import re
                     targs = name.split("gemm16_kernelI")[1].split("EEvNS")[0]
                     short = "gemm16<" + ",".join([("f16" if targs.startswith("DF16_") else "bf16")] + re.findall(r"L[ib](\d+)E", targs)) + ">"
@@ -33,11 +35,14 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0])
     wmb = sum(wr) / max(len(wr), 1) * 1024 / 1e6
     out[k] = dict(launches=len(fe) or len(wr), fetch_mb=fmb, fetch_mb_x2=2 * fmb, write_mb=wmb)
     print(f"{k[:70]:70s} {len(fe) or len(wr):8d} {fmb:16.2f} {2 * fmb:12.2f} {wmb:16.2f}")
-# stamp the kernel sources the counters belong to: bench.py only quotes a traffic figure whose stamp matches the library it runs
+# stamp the library sources the counters belong to: bench.py only quotes a traffic figure whose stamp matches the tree it runs
+import glob as _g
 import hashlib
-csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mertools_amd", "csrc")
-h = hashlib.sha256()
-for f in ("gemm16_impl.h",):   # the kernel template itself (gemm16.hip only holds the C ABI and the option table)
-    h.update(open(os.path.join(csrc, f), "rb").read())
-out["_source_sha"] = h.hexdigest()[:16]
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in sorted(_g.glob(os.path.join(_root, "mertools_amd", "csrc", "*"))):
+    if _f.endswith((".h", ".hip", ".cpp")):
+        _h.update(os.path.basename(_f).encode())
+        _h.update(open(_f, "rb").read())
+out["_source_sha"] = _h.hexdigest()[:16]
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)

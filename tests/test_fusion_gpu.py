@@ -286,3 +286,63 @@ def test_main_release_graph_loop_equals_eager_loop(dev, tmp_path):
     fg = sorted(strip(f) for f in os.listdir(tmp_path / "graph-trimodal" / "result"))
     fe = sorted(strip(f) for f in os.listdir(tmp_path / "eager-trimodal" / "result"))
     assert fg == fe, (fg, fe)
+
+
+def test_attention_topn_forward_matches_reference(dev):
+    """Attention_TOPN (MER2024/toolkit/models/attention_topn.py:7-89) on the HIP kernels against the reference class's own outputs
+    (tests/golden/fusion_attention_topn.npz: 6 streams, emotion-only head output_dim2 = 0), same weights and inputs."""
+    from mertools_amd.toolkit.models import get_models
+    gold = np.load(os.path.join(G, "fusion_attention_topn.npz"))
+    dims = gold["dims"].tolist()
+    args = argparse.Namespace(model="attention_topn", audio_dim=dims, output_dim1=6, output_dim2=0, dropout=0.0, hidden_dim=64, grad_clip=-1.0,
+                              feat_type="utt")
+    m = get_models(args).to(dev).eval()
+    m.model.load_state_dict({k[len("init_"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("init_")})
+    batch = {f"feat{i}": torch.from_numpy(gold[f"x_feat{i}"]).to(dev) for i in range(len(dims))}
+    with torch.no_grad():
+        f, e, v, il = m(batch)
+    torch.cuda.synchronize()
+    assert_close(f.cpu(), torch.from_numpy(gold["features"]), 2e-6, "attention_topn features")
+    assert_close(e.cpu(), torch.from_numpy(gold["emos_out"]), 2e-6, "attention_topn emos_out")
+    assert tuple(v.shape) == tuple(gold["vals_out"].shape) == (16, 0) and int(il) == int(gold["interloss"])
+
+
+@pytest.mark.parametrize("model", ["attention", "attention_topn"])
+def test_main_release_mer2024(dev, tmp_path, model):
+    """`--dataset MER2024` (north_star: "drops into MERBench / MER2024 unchanged"): emotion-only labels (output_dim2 = 0, no MSE term,
+    model selection on the weighted F1), train / test1 only, the test npz carries the fold-averaged probabilities
+    (MER2024/main-release.py:280-290); with `--model attention` and with `--model attention_topn --fusion_topn 2` (six feature sets)."""
+    from mertools_amd import main_release
+    from mertools_amd.toolkit.data.feat_data_topn import topn_feature_names
+    root = tmp_path / "data" / "mer2024-dataset-process"
+    rng = np.random.RandomState(3)
+    names = {"train": [f"tr_{i:03d}" for i in range(40)], "test1": [f"t1_{i:02d}" for i in range(9)]}
+    emos = ['neutral', 'angry', 'happy', 'sad', 'worried', 'surprise']
+    corp = {f"{split}_corpus": {n: {"emo": emos[rng.randint(6)]} for n in ns} for split, ns in names.items()}
+    os.makedirs(root / "features", exist_ok=True)
+    np.savez_compressed(root / "label-6way.npz", **{k: np.array(v, dtype=object) for k, v in corp.items()})
+    feats = {"audio-UTT": 24, "text-UTT": 16, "video-UTT": 20}
+    feats.update({n: 8 + 4 * i for i, n in enumerate(topn_feature_names(2, "AVT"))})
+    for feat, d in feats.items():
+        os.makedirs(root / "features" / feat, exist_ok=True)
+        for ns in names.values():
+            for n in ns:
+                np.save(root / "features" / feat / f"{n}.npy", rng.randn(d).astype(np.float32))
+    argv = ["--model", model, "--feat_type", "utt", "--dataset", "MER2024", "--epochs", "2", "--batch_size", "16", "--gpu", "0", "--seed", "5",
+            "--data_root", str(tmp_path / "data"), "--save_root", str(tmp_path / "saved")]
+    if model == "attention":
+        argv += ["--audio_feature", "audio-UTT", "--text_feature", "text-UTT", "--video_feature", "video-UTT"]
+    else:
+        argv += ["--fusion_topn", "2", "--fusion_modality", "AVT"]
+    res = main_release.main(argv)
+    assert len(res) == 5
+    for fold in res:
+        assert "eval_emofscore" in fold and "eval_valmse" not in fold and "test1_emoprobs" in fold and "test2_emoprobs" not in fold
+        assert np.isfinite(fold["test1_emoprobs"]).all() and fold["test1_emoprobs"].shape == (9, 6)
+    out = tmp_path / ("saved-trimodal" if model == "attention" else "saved-others-multitop") / "result"
+    saved = sorted(os.listdir(out))
+    assert sum(f.startswith("cv_") for f in saved) == 1 and sum(f.startswith("test1_") for f in saved) == 1, saved
+    t1 = [f for f in saved if f.startswith("test1_")][0]
+    assert "_f1:" in t1 and "_val:" not in t1 and ("fusiontopn:2_modality:AVT" in t1) == (model == "attention_topn")
+    z = np.load(out / t1, allow_pickle=True)
+    assert np.asarray(z["emo_probs"]).shape == (9, 6)

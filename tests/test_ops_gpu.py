@@ -412,19 +412,31 @@ def test_gemm16_mx_corrected(dev, M, N, K, act):
 
 
 def test_gemm16_mx_falls_back_to_two_pass(dev):
-    """Shapes the MX kernel does not cover (K % 128 != 0, small M -> 128-wide tiles) run the f16 2-pass path with w_lo."""
+    """A K the MX kernel does not cover (K % 128 != 0) runs the f16 2-pass path with w_lo.  Few rows are NOT a reason to fall back
+    (round 4: a clip must get the same bits alone and in a batch of 64): 100 rows run the same MX kernel as 4096."""
     ops = _ops()
-    for (M, N, K) in [(600, 256, 136), (100, 768, 768)]:
-        a = _rand((M, K), 41).half()
-        w = _rand((N, K), 42) * 0.05
-        wh, wl = ops.split16_host(w, "f16")
-        packed = ops.mx_pack(w - wh.float())
-        c4, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), w_mx=None if packed is None else packed.to(dev), out32=True, passes=4)
-        c2, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), out32=True, passes=2)
-        torch.cuda.synchronize()
-        assert torch.equal(c4, c2)
+    M, N, K = 600, 256, 136
+    a = _rand((M, K), 41).half()
+    w = _rand((N, K), 42) * 0.05
+    wh, wl = ops.split16_host(w, "f16")
+    packed = ops.mx_pack(w - wh.float())
+    assert packed is None
+    c4, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), w_mx=None, out32=True, passes=4)
+    c2, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), out32=True, passes=2)
+    torch.cuda.synchronize()
+    assert torch.equal(c4, c2)
     with pytest.raises(Exception):
         ops.gemm16(a.to(dev), wh.to(dev), out32=True, passes=4)   # neither plane
+    M, N, K = 4096, 768, 768
+    a = _rand((M, K), 43).half()
+    w = _rand((N, K), 44) * 0.05
+    wh, wl = ops.split16_host(w, "f16")
+    mx = ops.mx_pack(w - wh.float()).to(dev)
+    big, _, _ = ops.gemm16(a.to(dev), wh.to(dev), w_lo=wl.to(dev), w_mx=mx, out32=True, passes=4)
+    for rows in (1, 100, 1000):
+        part, _, _ = ops.gemm16(a[:rows].to(dev), wh.to(dev), w_lo=wl.to(dev), w_mx=mx, out32=True, passes=4)
+        torch.cuda.synchronize()
+        assert torch.equal(part, big[:rows]), rows
 
 
 @pytest.mark.parametrize("B,T,H,gated", [(2, 50, 2, True), (3, 197, 3, False), (2, 249, 4, True), (1, 499, 2, True)])
@@ -810,6 +822,11 @@ def test_seq_bias(dev, T, nseq, K, N):
             mean = ah[rows].cpu().double().mean(0).half().double() if rows else torch.zeros(K, dtype=torch.float64)
             ref[s] = mean @ wl.cpu().double().T + bias.double()
         assert_close(tab.cpu(), ref.float(), 2e-6, f"seq_bias T={T} valid={use_valid}")
+    if N % 32 == 0:      # n_first: columns below it take the plain bias
+        tab = ops.seq_bias(ah, wl, T, bias=bias.to(dev), n_first=N // 2)
+        full = ops.seq_bias(ah, wl, T, bias=bias.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(tab[:, N // 2:], full[:, N // 2:]) and torch.equal(tab[:, :N // 2], bias.to(dev)[None, :N // 2].expand(nseq, -1))
     # batch-mate independence: sequences 0 .. 3 alone == their rows of the full table
     if nseq >= 4 and M >= 4 * T:
         full = ops.seq_bias(ah, wl, T, bias=bias.to(dev))
