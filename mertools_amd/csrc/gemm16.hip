@@ -7,6 +7,7 @@ namespace mer {
 int g_gemm_skip = 0;          // "gemm_dbg_skip": 1 = skip the epilogue's global stores, 2 = skip the whole epilogue (timing decomposition)
 int g_gemm_stamp = 0;         // "gemm_stamp": the instrumented (s_memtime) build of the 8-wave kernels, with mer_set_debug_buffer
 int g_gemm_glds = 1;          // "gemm_glds": 0 = register-staged loader instead of LDS-DMA (A/B and the K % 32 != 0 fallback's twin)
+int g_gemm_tm = 0;            // "gemm_tm": rows per persistent tile / 64: 0 = chosen per shape (p_pick_tm), 3 or 4 = forced
 int g_gemm_persist = 1;       // "gemm_persist": 0 = never take the persistent kernel (A/B against gemm16_kernel on the same planes)
 int g_gemm_generic_epi = 0;   // "gemm_generic_epi": 1 = every launch takes the generic epilogue (the specialised ones must equal it)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel
@@ -29,6 +30,7 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_dbg_skip") == 0) { mer::g_gemm_skip = value; return MER_OK; }
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
   if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
+  if (name && strcmp(name, "gemm_tm") == 0) { mer::g_gemm_tm = value; return MER_OK; }
   if (name && strcmp(name, "gemm_generic_epi") == 0) { mer::g_gemm_generic_epi = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;

@@ -34,11 +34,11 @@ constexpr int P_BIAS = 2 * 8 * 1024;       // bias rows of the tile (256 fp32 ea
 constexpr int P_STAMP = 2 * 12 * 16 * 8;   // timeline stamps (mer_set_debug_buffer): 2 wave groups x 12 tiles x 16 slots, dumped at exit
 constexpr int P_SMEM = P_RING + P_BIAS + P_STAMP;
 
-// counted wait with the epilogue's still-in-flight stores (sx = 0, 16 or 32, wave-uniform) added to the allowance
-template <int N>
+// counted wait with the epilogue's still-in-flight stores (sx = 0, 4 TM or 8 TM, wave-uniform) added to the allowance
+template <int N, int TM>
 __device__ __forceinline__ void wait_vmcnt_plus(int sx) {
-  if (sx == 32) wait_vmcnt<N + 32>();
-  else if (sx == 16) wait_vmcnt<N + 16>();
+  if (sx == 8 * TM) wait_vmcnt<N + 8 * TM>();
+  else if (sx == 4 * TM) wait_vmcnt<N + 4 * TM>();
   else wait_vmcnt<N>();
 }
 
@@ -70,16 +70,20 @@ __host__ __device__ inline int p_perm_row(int r, int layout) {
   return (r & ~127) + (layout == 0 ? 8 * li + nt : 64 * (nt >> 2) + 4 * li + (nt & 3));
 }
 
-template <typename T, int EPI, int ACT>
+// TM = 4: 256 x 256 tiles (a wave: 64 x 128).  TM = 3: 192 x 256 tiles (a wave: 48 x 128) for planes whose 256-row tile count fills
+// the last round of workgroups badly (63 row tiles x 9 column tiles on 256 CUs = 2.2 rounds, paid as 3): the same slab stream — the
+// ring still carries 256 A rows per slab, the last 64 of them (the next row tile's, or a clamped repeat of row M - 1) unread — the
+// same k order per output element, hence the same bits.
+template <typename T, int EPI, int ACT, int TM>
 __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   typedef typename T16<T>::v8 v8;
-  constexpr int TM = 4, TN = 8;
+  constexpr int TN = 8, TROWS = 64 * TM, WROWS = 16 * TM;
   constexpr int STAGE = 32768, A_PLANE = 16384;
   __shared__ __attribute__((aligned(16))) char smem[P_SMEM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves of 64 x 128
+  const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves of (16 TM) x 128
   const int li = lane & 15, lg = lane >> 4;
   const bool g1 = wave >= 4;
   const int nk = p.K >> 5;
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     if (!p.bias) return;
     int srow = 0, nrow = 1;
     if (p.bias_T > 0) {
-      const int last = tm_ * 256 + 255 < p.M ? tm_ * 256 + 255 : p.M - 1;
-      srow = (tm_ * 256) / p.bias_T;
+      const int last = tm_ * TROWS + TROWS - 1 < p.M ? tm_ * TROWS + TROWS - 1 : p.M - 1;
+      srow = (tm_ * TROWS) / p.bias_T;
       nrow = last / p.bias_T - srow + 1;
     }
     if (wave < nrow)
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   v8 af[TM], wf[TN];
   // (row >> 2) & 3 == (li >> 2) for every fragment row of this lane: one swizzle term, fragments 1 KiB apart
   const int fsw = ((lg ^ ((-(li >> 2)) & 3)) << 4);
-  const int a_f0 = (wm * 64 + li) * 64 + fsw;
+  const int a_f0 = (wm * WROWS + li) * 64 + fsw;
   const int w_f0 = A_PLANE + (wn * 128 + li) * 64 + fsw;
   auto load_frags = [&](int stage) __attribute__((always_inline)) {
     const char* base = smem + stage * STAGE;
@@ -174,9 +178,9 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   // operations exactly, the asm stores between them only make its waits a little stronger than necessary.
   auto epilogue = [&](int tm_, int tn_, int par) __attribute__((always_inline)) -> int {
     if ((p.dbg_skip & 3) == 2) return 0;
-    const int m0 = tm_ * 256 + wm * 64, n0 = tn_ * 256 + wn * 128;
+    const int m0 = tm_ * TROWS + wm * WROWS, n0 = tn_ * 256 + wn * 128;
     const bool st = (p.dbg_skip & 3) != 1;
-    const bool interior = tm_ * 256 + 256 <= p.M;   // (N % 256 == 0: no column edge)
+    const bool interior = tm_ * TROWS + TROWS <= p.M;   // (N % 256 == 0: no column edge)
     const char* bs = smem + P_RING + par * 8192 + wn * 512;    // this wave's 128 columns of the slot's row 0
     int row = (int)opaque((unsigned)(m0 + 4 * lg));
     // per-sequence table: slot row of output row `row` = row / T - (256 tm_) / T, tracked incrementally (T >= 40 > a step of <= 13 rows)
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     if (p.bias_T > 0) {
       bq = row / p.bias_T;
       brem = row - bq * p.bias_T;
-      bq -= (tm_ * 256) / p.bias_T;
+      bq -= (tm_ * TROWS) / p.bias_T;
     }
     auto bias_step = [&](int d) __attribute__((always_inline)) {
       brem += d;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
         vo += 12 * rstep;
         row += 16;
       }
-      return (st && interior) ? 16 : 0;
+      return (st && interior) ? 4 * TM : 0;
     } else {
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
       const char* bl = bs + li * 16;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
           vo += 12 * cstep;
           row += 16;
         }
-        return (st && interior) ? 32 : 0;
+        return (st && interior) ? 8 * TM : 0;
       } else {
         // The residual may BE the output (the pre-LN stream is updated in place); source order is kept (asm volatile + "memory")
         // and vmcnt retires in order, so a load issued behind a store waits for that store's acknowledgement too.  The tile's 8
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
           if (half) { vo += 16 * cstep; row += 16; }
           if (j + 4 < 2 * TM) issue(j + 4);
         }
-        return (st && interior) ? 32 : 0;
+        return (st && interior) ? 8 * TM : 0;
       }
     }
   };
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   int tm, tn;
   tile_of(L, tm, tn);
   unsigned ao[2], aon[2] = {0u, 0u};   // A offsets of the current / the next tile
-  a_offsets(tm * 256, ao);
+  a_offsets(tm * TROWS, ao);
   glds_bias(tm, tn, 0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) glds_slab(ao, tn, s, s);
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     int ntm = 0, ntn = 0;
     if (has_next) {
       tile_of(Ln, ntm, ntn);
-      a_offsets(ntm * 256, aon);
+      a_offsets(ntm * TROWS, aon);
     }
     stamp(0);
 #pragma clang loop unroll(disable)   // (also keeps hipcc from peeling the first three iterations: three more copies of the loop body)
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
       // this wave's share of the stream's next slab has landed; two younger slabs — and, early in a tile, the stores — stay in
       // flight (the next tile's bias row rides one slot ahead of its slab 0: two waits per tile are one request stricter than needed)
       if (has_next || kt + 3 < nk) {
-        if (kt < 3) wait_vmcnt_plus<8>(sx);
+        if (kt < 3) wait_vmcnt_plus<8, TM>(sx);
         else wait_vmcnt<8>();
       } else wait_vmcnt<0>();               // last tile's tail: nothing younger is issued any more
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -396,30 +400,30 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
 
 int device_cu_count();
 
-template <typename T, int EPI>
+template <typename T, int EPI, int TM>
 static int launch_p_act(const Gemm16Params& p, dim3 grid, hipStream_t st) {
   dim3 block(512, 1, 1);
   if constexpr (EPI == 0) {
     switch (p.act) {
-      case MER_ACT_GELU: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_GELU>), grid, block, 0, st, p); break;
-      case MER_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_QUICK_GELU>), grid, block, 0, st, p); break;
-      case MER_ACT_GELU_TANH: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_GELU_TANH>), grid, block, 0, st, p); break;
-      default: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_NONE>), grid, block, 0, st, p); break;
+      case MER_ACT_GELU: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_GELU, TM>), grid, block, 0, st, p); break;
+      case MER_ACT_QUICK_GELU: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_QUICK_GELU, TM>), grid, block, 0, st, p); break;
+      case MER_ACT_GELU_TANH: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_GELU_TANH, TM>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_NONE, TM>), grid, block, 0, st, p); break;
     }
   } else if constexpr (EPI == 1) {
-    if (p.act == MER_ACT_GELU) hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_GELU>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_NONE>), grid, block, 0, st, p);
+    if (p.act == MER_ACT_GELU) hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_GELU, TM>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_NONE, TM>), grid, block, 0, st, p);
   } else {
-    hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_NONE>), grid, block, 0, st, p);   // (residual: no activation — checked by mer_gemm16)
+    hipLaunchKernelGGL((gemm16p_kernel<T, EPI, MER_ACT_NONE, TM>), grid, block, 0, st, p);   // (residual: no activation — checked by mer_gemm16)
   }
   return check_launch("gemm16p");
 }
 
-// eligibility was checked by mer_gemm16 (gemm16.hip)
-template <typename T>
+// eligibility was checked by mer_gemm16 (gemm16.hip); TM by dispatch_p (gemm16.hip: p_pick_tm)
+template <typename T, int TM>
 int dispatch_p_impl(const Gemm16Params& p0, hipStream_t st) {
   Gemm16Params p = p0;
-  p.tiles_m = (int)cdiv(p.M, 256);
+  p.tiles_m = (int)cdiv(p.M, 64 * TM);
   p.tiles_n = p.N / 256;
   const int nblk = p.tiles_m * p.tiles_n;
   const int cus = device_cu_count();
@@ -427,9 +431,29 @@ int dispatch_p_impl(const Gemm16Params& p0, hipStream_t st) {
   const double mn = (double)p.M * p.N;
   ProfScope prof("gemm16", 2.0 * mn * p.K,
                  2.0 * (double)p.M * p.K + 2.0 * (double)p.N * p.K + mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.residual ? 4 : 0)), st);
-  if (p.c16_hi) return launch_p_act<T, 0>(p, grid, st);
-  if (p.residual) return launch_p_act<T, 2>(p, grid, st);
-  return launch_p_act<T, 1>(p, grid, st);
+  if (p.c16_hi) return launch_p_act<T, 0, TM>(p, grid, st);
+  if (p.residual) return launch_p_act<T, 2, TM>(p, grid, st);
+  return launch_p_act<T, 1, TM>(p, grid, st);
+}
+
+template <typename T, int TM> int dispatch_p_tm(const Gemm16Params& p, hipStream_t st);
+
+// Rows per tile for an M x N plane on `cus` workgroups: a 192-row tile does 3/4 of the work of a 256-row one at a higher cost per
+// flop — the load phase of a slab (4 LDS-DMA pieces + 11 fragment reads per wave) does not shrink with the 24 instead of 32 MFMAs
+// it hides behind: 0.86-0.89 of the 256-row tile's TFLOP/s on CLIP's full-machine shapes (profiles/r04_gemm16_tile_rows_ab.txt) —
+// and pays when it saves a round of workgroups (HuBERT b64: 63 x 9 tiles = 2.2 rounds -> 83 x 9 = 2.9 rounds of 3/4 the length).
+inline int p_pick_tm(long long M, int N, int cus) {
+  const long long t4 = cdiv(M, 256) * (N / 256), t3 = cdiv(M, 192) * (N / 256);
+  const double c4 = (double)cdiv(t4, cus), c3 = (double)cdiv(t3, cus) * 0.75 * 1.15;
+  return c3 < 0.97 * c4 ? 3 : 4;
+}
+
+extern int g_gemm_tm;   // "gemm_tm": 0 = p_pick_tm, 3 / 4 = forced (tests, A/B)
+
+template <typename T>
+int dispatch_p_pick(const Gemm16Params& p, hipStream_t st) {
+  const int tm = g_gemm_tm == 3 || g_gemm_tm == 4 ? g_gemm_tm : p_pick_tm(p.M, p.N, device_cu_count());
+  return tm == 3 ? dispatch_p_tm<T, 3>(p, st) : dispatch_p_tm<T, 4>(p, st);
 }
 
 template <typename T> int dispatch_p(const Gemm16Params& p, hipStream_t st);

@@ -440,10 +440,11 @@ namespace mer {
 // of a sequence — tokens s/2, s/2 + s, ... (s = the largest power of two with at least 16 samples; the offset keeps the [CLS] / BOS
 // row out, whose weight would otherwise be 1 / #samples instead of 1 / T) below its valid length — depends on T and on the clip
 // alone, so its features no longer depend on what else is in the batch, bit for bit.
-//   seqmean16_kernel   workgroup = (64-column slice, sequence): exact 64-bit fixed-point column sums of the sampled rows (any order
+//   seqmean16_kernel   workgroup = (512-column slice, sequence): exact 64-bit fixed-point column sums of the sampled rows (any order
 //                      gives the same bits), written as the 16-bit mean plane [nseq, K] — no atomics, one owner per element
 //   seqbias_kernel     the [nseq, K] x [N, K]^T table on the 16x16x32 MFMA, fragments straight from global memory (both operands
-//                      are a few MB and L2-resident; a wave = 64 sequences x 16 columns, 4 waves = 64 columns per workgroup)
+//                      are a few MB); workgroup = 64 sequences x 16 columns, its 16 waves split K
+// Both launches are latency, not bandwidth: every load a wave needs is in flight before the first is consumed.
 __host__ __device__ inline int seq_sample_stride(int T) {
   int s = 1;
   while (s * 2 * 16 <= T) s *= 2;
@@ -451,109 +452,119 @@ __host__ __device__ inline int seq_sample_stride(int T) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void seqmean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int seg_rows,
+__global__ __launch_bounds__(512) void seqmean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int seg_rows,
                                                         const int* valid_rows, T* mean16, long long ldm) {
-  // workgroup = (512-column slice, sequence); wave w takes sample rows w, w + 4, ...; a wave-load = one row x 1 KiB (whole lines)
+  // workgroup = (512-column slice, sequence), 8 waves; wave w takes sample rows w, w + 8, w + 16, w + 24 (a sequence has at most 31
+  // samples) and issues its (up to four) row loads back to back before it touches the data: the launch is one memory round trip,
+  // not one per row.  A wave-load = one row x 1 KiB (whole lines).
   typedef typename T16<T>::v8 v8;
-  __shared__ long long red[4][512];
-  __shared__ int rcnt[4];
+  __shared__ long long red[8][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 512 + lane * 8;
   const int seq = blockIdx.y;
   const bool cin = col < K;
-  const int stride = seq_sample_stride(seg_rows);
+  const int stride = seq_sample_stride(seg_rows), half = stride >> 1;
   int valid = seg_rows;
   if (valid_rows) valid = valid_rows[seq] < valid ? valid_rows[seq] : valid;
   if ((long long)seq * seg_rows + valid > M) valid = M - seq * seg_rows;     // last, partial sequence of the plane
+  const int total = valid > half ? (valid - half + stride - 1) / stride : 0;   // samples half, half + stride, ... below valid
+  v8 x[4];
+  const v8 z = {};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = wave + 8 * u;
+    x[u] = z;
+    if (cin && i < total) {
+      const int r = seq * seg_rows + half + i * stride;
+      const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
+      x[u] = *reinterpret_cast<const v8*>(a + off + col);
+    }
+  }
   long long s[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0;
-  int n = 0;
-#pragma unroll 4
-  for (int i = wave; ; i += 4) {
-    const int t = (stride >> 1) + i * stride;
-    if (t >= valid) break;
-    ++n;
-    if (cin) {
-      const int r = seq * seg_rows + t;
-      const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
-      const v8 x = *reinterpret_cast<const v8*>(a + off + col);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = fminf(fmaxf(T16<T>::to_f32(x[j]), -131000.f), 131000.f);
-        s[j] += (long long)__float2int_rn(v * CM_FIX);
-      }
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // (a slot without a sample holds zeros: adds nothing)
+      const float v = fminf(fmaxf(T16<T>::to_f32(x[u][j]), -131000.f), 131000.f);
+      s[j] += (long long)__float2int_rn(v * CM_FIX);
     }
-  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = s[j];
-  if (lane == 0) rcnt[wave] = n;
   __syncthreads();
-  const int total = (rcnt[0] + rcnt[1]) + (rcnt[2] + rcnt[3]);
   // (a sequence shorter than stride / 2 rows has no sample: its correction row is the plain bias)
   const double inv = total > 0 ? 1.0 / ((double)total * (double)CM_FIX) : 0.0;
-  for (int c = threadIdx.x; c < 512; c += 256) {
-    const long long t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);       // integer sums: any order gives the same bits
-    const int cc = blockIdx.x * 512 + c;
-    if (cc < K) mean16[(long long)seq * ldm + cc] = T16<T>::from_f32((float)((double)t * inv));
-  }
+  const int c = threadIdx.x;
+  long long t = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) t += red[w][c];       // integer sums: any order gives the same bits
+  const int cc = blockIdx.x * 512 + c;
+  if (cc < K) mean16[(long long)seq * ldm + cc] = T16<T>::from_f32((float)((double)t * inv));
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void seqbias_kernel(const T* mean16, long long ldm, int nseq, int K, const T* w_lo, long long ldw,
-                                                      const float* bias, int N, int n_first, float* tab, long long ldt) {
-  // workgroup = 64 sequences x 16 columns; its 4 waves split K (a 768-deep dot product is 24 dependent L2 round trips for one
-  // wave: this launch is latency, not bandwidth), 4 k-steps of loads in flight per wave, partial tiles summed in wave order through
-  // LDS (a fixed order: the row of a sequence does not depend on the batch around it)
+__global__ __launch_bounds__(1024) void seqbias_kernel(const T* mean16, long long ldm, int nseq, int K, const T* w_lo, long long ldw,
+                                                       const float* bias, int N, int n_first, float* tab, long long ldt) {
+  // workgroup = 64 sequences x 16 columns; its 16 waves split K (a 3072-deep dot product is 96 dependent L2 / HBM round trips for
+  // one wave: this launch is latency, not bandwidth), up to 4 k-steps of loads in flight per wave, partial tiles summed in a fixed
+  // tree through LDS (the row of a sequence does not depend on the batch around it: 16-row blocks beyond nseq are skipped, which
+  // changes nothing for the rows that exist)
   typedef typename T16<T>::v8 v8;
-  __shared__ float red[4][64][20];
+  __shared__ float red[16][64][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.x * 16, s0 = blockIdx.y * 64;
   const int n = n0 + li < N ? n0 + li : N - 1;
-  const int ksteps = (K + 31) / 32, per = (ksteps + 3) / 4;
+  const int ksteps = (K + 31) / 32, per = (ksteps + 15) / 16;
   // columns below n_first take the plain bias (the Q | K columns of a fused QKV weight: their rounding only perturbs softmax logits)
   const bool plain = n0 + 16 <= n_first;
-  const int k_lo = wave * per * 32, k_hi = plain ? 0 : ((wave + 1) * per * 32 < K ? (wave + 1) * per * 32 : K);
-  const T* wr = w_lo + (long long)n * ldw + lg * 8;
-  const T* mr[4];
+  const int mts = nseq - s0 >= 64 ? 4 : (nseq - s0 + 15) / 16;
+  if (!plain) {
+    const int k_lo = wave * per * 32, k_hi = (wave + 1) * per * 32 < K ? (wave + 1) * per * 32 : K;
+    const T* wr = w_lo + (long long)n * ldw + lg * 8;
+    const T* mr[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int sq = s0 + i * 16 + li;
-    mr[i] = mean16 + (long long)(sq < nseq ? sq : nseq - 1) * ldm + lg * 8;
-  }
-  f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) {
+      const int sq = s0 + i * 16 + li;
+      mr[i] = mean16 + (long long)(sq < nseq ? sq : nseq - 1) * ldm + lg * 8;
+    }
+    f32x4 acc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const v8 z = {};
-  for (int k0 = k_lo; k0 < k_hi; k0 += 128) {
-    v8 wf[4], mf[4][4];
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const v8 z = {};
+    for (int k0 = k_lo; k0 < k_hi; k0 += 128) {
+      v8 wf[4], mf[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + u * 32;
-      const bool kin = k < k_hi && k + lg * 8 < K;     // K % 8 == 0: a lane's 8 elements are in or out together
-      wf[u] = kin ? *reinterpret_cast<const v8*>(wr + k) : z;
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * 32;
+        const bool kin = k < k_hi && k + lg * 8 < K;     // K % 8 == 0: a lane's 8 elements are in or out together
+        wf[u] = kin ? *reinterpret_cast<const v8*>(wr + k) : z;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mf[u][i] = kin ? *reinterpret_cast<const v8*>(mr[i] + k) : z;
+        for (int i = 0; i < 4; ++i) mf[u][i] = (kin && i < mts) ? *reinterpret_cast<const v8*>(mr[i] + k) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = T16<T>::mfma(mf[u][i], wf[u], acc[i]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = T16<T>::mfma(mf[u][i], wf[u], acc[i]);
+      for (int r = 0; r < 4; ++r) red[wave][i * 16 + lg * 4 + r][li] = acc[i][r];
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][i * 16 + lg * 4 + r][li] = acc[i][r];
   __syncthreads();
-  const int sl = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
-  const int sq = s0 + sl;
-  if (sq < nseq) {
+  const int sl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+  const int sq = s0 + sl, c = n0 + cl;
+  if (sq < nseq && c < N) {
+    float p[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = n0 + c4 + j;
-      if (c < N) tab[(long long)sq * ldt + c] = ((red[0][sl][c4 + j] + red[1][sl][c4 + j]) + (red[2][sl][c4 + j] + red[3][sl][c4 + j])) + (bias ? bias[c] : 0.f);
-    }
+    for (int w = 0; w < 16; ++w) p[w] = plain ? 0.f : red[w][sl][cl];
+#pragma unroll
+    for (int d = 1; d < 16; d *= 2)
+#pragma unroll
+      for (int w = 0; w < 16; w += 2 * d) p[w] += p[w + d];
+    tab[(long long)sq * ldt + c] = p[0] + (bias ? bias[c] : 0.f);
   }
 }
 
@@ -580,11 +591,11 @@ extern "C" int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_
   const int samples = (seg_rows + seq_sample_stride(seg_rows) - 1) / seq_sample_stride(seg_rows);
   ProfScope prof("bias_corr", 2.0 * nseq * (double)(N - n_first) * K, (double)nseq * samples * K * 2 + (double)N * K * 2 + (double)nseq * N * 4, st);
   if (dtype == MER_DT_F16) {
-    hipLaunchKernelGGL((seqmean16_kernel<f16>), g1, dim3(256), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (f16*)scratch, (long long)K);
-    hipLaunchKernelGGL((seqbias_kernel<f16>), g2, dim3(256), 0, st, (const f16*)scratch, (long long)K, nseq, K, (const f16*)w_lo, ldw, bias, N, n_first, table, ldt);
+    hipLaunchKernelGGL((seqmean16_kernel<f16>), g1, dim3(512), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (f16*)scratch, (long long)K);
+    hipLaunchKernelGGL((seqbias_kernel<f16>), g2, dim3(1024), 0, st, (const f16*)scratch, (long long)K, nseq, K, (const f16*)w_lo, ldw, bias, N, n_first, table, ldt);
   } else {
-    hipLaunchKernelGGL((seqmean16_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (bf16*)scratch, (long long)K);
-    hipLaunchKernelGGL((seqbias_kernel<bf16>), g2, dim3(256), 0, st, (const bf16*)scratch, (long long)K, nseq, K, (const bf16*)w_lo, ldw, bias, N, n_first, table, ldt);
+    hipLaunchKernelGGL((seqmean16_kernel<bf16>), g1, dim3(512), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (bf16*)scratch, (long long)K);
+    hipLaunchKernelGGL((seqbias_kernel<bf16>), g2, dim3(1024), 0, st, (const bf16*)scratch, (long long)K, nseq, K, (const bf16*)w_lo, ldw, bias, N, n_first, table, ldt);
   }
   return check_launch("seq_bias");
 }

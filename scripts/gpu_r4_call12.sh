@@ -1,0 +1,32 @@
+#!/bin/bash
+# 192-row persistent tiles: bit-identity tests, per-shape A/B, audio lines
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r4c12; mkdir -p "$O"
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_ops_gpu.py -k "persistent or bias_table or seq_bias" -m gpu -q --no-header -p no:cacheprovider > "$O/tests.log" 2>&1; echo "tests rc=$?"; grep -E "passed|failed|^FAILED|^ERROR|Error" "$O/tests.log" | tail -8
+for set in hubert hubert32 roberta clip; do
+  MER_TM_AB=1 timeout 200 scripts/probes/gemm16_bench.bin 20 20 $set > "$O/ab_$set.jsonl" 2>&1; echo "ab $set rc=$?"
+done
+python - "$O" <<'P'
+import json, sys, glob, collections
+for f in sorted(glob.glob(sys.argv[1] + "/ab_*.jsonl")):
+    rows = collections.OrderedDict()
+    for l in open(f):
+        try: d = json.loads(l)
+        except Exception: continue
+        if "variant" in d: rows.setdefault(d["shape"], collections.OrderedDict()).setdefault(d["variant"][:28], []).append(d["TFLOPs"])
+    for sh, v in rows.items():
+        print(f"{sh[:44]:44s} " + "  ".join(f"{k[:26]}: {'/'.join(str(int(x)) for x in xs)}" for k, xs in v.items() if not k.startswith("4 rot")))
+P
+for cfg in "a 32" "a 64" "avt 64"; do set -- $cfg
+  timeout 200 python bench.py --modalities $1 --batch $2 --steps 20 --warmup 5 --no-cpu-baseline --no-sustained --no-large --no-parity --e2e 0 > "$O/bench_$1_b$2.json" 2>> "$O/bench.err"; echo "bench $1 b$2 rc=$?"
+done
+python - "$O" <<'P'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/bench*.json")):
+    try:
+        d = json.load(open(f)); r = d["roofline"]
+        print(f.split("/")[-1], d["value"], d["ms_per_step"], r["kernel"], r["achieved"], r["frac"], r["whole_step_tflops"], {k: v["ms_share"] for k, v in r["other_kernels"].items()})
+    except Exception as e:
+        print(f, "parse failed", e)
+P

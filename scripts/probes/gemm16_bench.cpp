@@ -123,6 +123,11 @@ static void run_shape(const Shape& s, int warm, int reps) {
     report("tile kernel (gemm16_kernel), pre-blocked W", time_gemm(g, warm, reps));
     MER(mer_set_option("gemm_persist", 1));
     if (wblkp && s.passes == 1) report("persistent kernel (gemm16p_kernel)", time_gemm(g, warm, reps));
+    if (wblkp && s.passes == 1 && getenv("MER_TM_AB")) {   // 256-row against 192-row tiles on the same planes (the default picks per shape)
+      MER(mer_set_option("gemm_tm", 4)); report("persistent, 256-row tiles", time_gemm(g, warm, reps));
+      MER(mer_set_option("gemm_tm", 3)); report("persistent, 192-row tiles", time_gemm(g, warm, reps));
+      MER(mer_set_option("gemm_tm", 0));
+    }
   }
   if (const char* sd = getenv("MER_STAMP")) if (wblkp && s.passes == 1) {   // s_memtime timeline of the persistent kernel (gemm16p_impl.h: stamp slots)
     const size_t nb = 256 * 384 * 8;

@@ -745,26 +745,35 @@ def test_gemm16_persistent_equals_tile_kernel(dev, M, N, K, dtype):
             r32, r16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq, **kw)
         finally:
             lib.mer_set_option(b"gemm_persist", 1)
-        for rep in range(3):
-            c32, c16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq, **kw)
-            torch.cuda.synchronize()
+        for rep in range(6):
+            try:     # both tile heights (256 rows, 192 rows: gemm16p_impl.h TM), three launches each
+                lib.mer_set_option(b"gemm_tm", 4 if rep < 3 else 3)
+                c32, c16, _ = ops.gemm16(ah, wh, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq, **kw)
+                torch.cuda.synchronize()
+            finally:
+                lib.mer_set_option(b"gemm_tm", 0)
             what = f"persistent gemm16 {kw.get('act')} out16={kw.get('out16', False)} res={'residual' in kw} rep {rep}"
             if r16 is not None:
                 assert torch.equal(c16.view(torch.int16), r16.view(torch.int16)), what
             if r32 is not None:
                 assert torch.equal(c32, r32), what
     # in-place residual (the pre-LN residual stream: residual == c32)
-    inplace = res.clone()
-    g = ops.GemmArgs()
-    g.M, g.N, g.K, g.dtype = M, N, K, ops.dt_code(dtype)
-    g.a_hi, g.lda, g.w_hi, g.ldw = ah.data_ptr(), K, wh.data_ptr(), K
-    g.w_hi_blk, g.w_hi_blkp, g.w_hi_blkq = hb.data_ptr(), hp.data_ptr(), hq.data_ptr()
-    g.bias, g.act, g.residual, g.ldr, g.c32, g.ldc32 = bias.data_ptr(), ops.ACT[None], inplace.data_ptr(), N, inplace.data_ptr(), N
-    g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, 1, 3
-    ops.gemm16_raw(g)
     ref32, _, _ = ops.gemm16(ah, wh, w_hi_blk=hb, bias=bias, residual=res, out32=True, passes=1, tile=3, dtype=dtype)
-    torch.cuda.synchronize()
-    assert torch.equal(inplace, ref32), "persistent gemm16, residual updated in place"
+    for tm in (4, 3):
+        inplace = res.clone()
+        g = ops.GemmArgs()
+        g.M, g.N, g.K, g.dtype = M, N, K, ops.dt_code(dtype)
+        g.a_hi, g.lda, g.w_hi, g.ldw = ah.data_ptr(), K, wh.data_ptr(), K
+        g.w_hi_blk, g.w_hi_blkp, g.w_hi_blkq = hb.data_ptr(), hp.data_ptr(), hq.data_ptr()
+        g.bias, g.act, g.residual, g.ldr, g.c32, g.ldc32 = bias.data_ptr(), ops.ACT[None], inplace.data_ptr(), N, inplace.data_ptr(), N
+        g.nbatch, g.nb_inner, g.passes, g.tile = 1, 1, 1, 3
+        try:
+            lib.mer_set_option(b"gemm_tm", tm)
+            ops.gemm16_raw(g)
+            torch.cuda.synchronize()
+        finally:
+            lib.mer_set_option(b"gemm_tm", 0)
+        assert torch.equal(inplace, ref32), f"persistent gemm16 ({64 * tm}-row tile), residual updated in place"
     true = a.double() @ w.double().T + bias.cpu().double() + res.cpu().double()
     assert_close(ref32.cpu(), true.float(), 1e-3 if dtype == "f16" else 8e-3, "persistent gemm16 vs fp64")
 
@@ -855,18 +864,20 @@ def test_gemm16_bias_table(dev, T, M):
     rowseq = (torch.arange(M) // T)
     z = a.double() @ w.double().T + tab.cpu().double()[rowseq]
     outs = {}
-    for name, persist, tile in (("persistent", 1, 3), ("tile256", 0, 3)) + ((("tile128", 0, 1),) if M < 20000 else ()):
+    for name, persist, tile in (("persistent", 1, 3), ("persistent192", 1, 3), ("tile256", 0, 3)) + ((("tile128", 0, 1),) if M < 20000 else ()):
         try:
             lib.mer_set_option(b"gemm_persist", persist)
+            lib.mer_set_option(b"gemm_tm", 3 if name == "persistent192" else 4)
             kw = dict(bias=tab, bias_seg_rows=T, passes=1, tile=tile, w_hi_blk=hb, w_hi_blkp=hp, w_hi_blkq=hq)
             _, c16, _ = ops.gemm16(ah, wh, act="gelu", out16=True, **kw)
             c32, _, _ = ops.gemm16(ah, wh, out32=True, **kw)
             r32, _, _ = ops.gemm16(ah, wh, out32=True, residual=res, **kw)
+            torch.cuda.synchronize()
         finally:
             lib.mer_set_option(b"gemm_persist", 1)
-        torch.cuda.synchronize()
+            lib.mer_set_option(b"gemm_tm", 0)
         outs[name] = (c16, c32, r32)
-    for name in [n for n in ("tile256", "tile128") if n in outs]:
+    for name in [n for n in ("persistent192", "tile256", "tile128") if n in outs]:
         for i, what in enumerate(("16-bit gelu", "fp32", "fp32 + residual")):
             assert torch.equal(outs["persistent"][i].view(torch.int16 if i == 0 else torch.int32),
                                outs[name][i].view(torch.int16 if i == 0 else torch.int32)), f"bias table T={T}: persistent vs {name}, {what}"
