@@ -114,24 +114,10 @@ typedef struct {
 } mer_gemm16_args;
 int mer_gemm16(const mer_gemm16_args* args, mer_stream_t stream);
 
-/* Batch-mean weight-residual correction of a one-pass GEMM (precision "mean"): out[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k],
- * w_lo = the 16-bit plane of W - f16(W) ([N, K], row stride ldw).  mean_rows runs over 2048 .. 4096 evenly spaced rows of the A
- * plane (every row when M < 4096): rows 0, s, 2s, ... of every sequence of seg_rows rows (seg_rows == 0: of the whole plane), s the
- * largest power of two <= M / 2048; rows addressed like mer_gemm16's A operand (a_rows_per_batch / a_batch_stride / lda; <= 0 ->
- * plain row-major).  valid_rows (device int32 [ceil(M / seg_rows)], or NULL): rows t >= valid_rows[sequence] of a sequence are
- * padding and do not count.  Elements are summed as 64-bit fixed-point integers (2^-14 resolution): the result depends only on the
- * SET of sampled rows, not on their order, layout or the amount of padding — bit for bit.  The rounding error of a weight matrix
- * is the same perturbation for every token, so what it does to the features goes almost entirely through the MEAN activation
- * (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass) — i.e. it
- * is a bias, and the GEMM that follows runs passes = 1 with `out` as its bias.  scratch: device, mer_bias_corr_scratch_bytes(K)
- * bytes, 16-byte aligned, ZERO on entry (the accumulators + a row counter; the call leaves them non-zero — clear them before the
- * next use); out: device fp32 [N].  Two small launches on `stream`. */
-long long mer_bias_corr_scratch_bytes(int K);
-int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
-                  int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
-                  void* scratch, float* out, mer_stream_t stream);
-
-/* Per-SEQUENCE weight-residual correction (precision "mean"): table[s, n] = bias[n] + mean_{sampled rows of sequence s}(A)[k] * w_lo[n, k]
+/* Per-SEQUENCE weight-residual correction (precision "mean"): table[s, n] = bias[n] + mean_{sampled rows of sequence s}(A)[k] * w_lo[n, k],
+ * w_lo = the 16-bit plane of W - f16(W) ([N, K], row stride ldw).  The rounding error of a weight matrix is the same perturbation for
+ * every token, so what it does to the features goes almost entirely through the mean activation of the sequence
+ * (tests/studies/mean_correction.py) — i.e. it is a bias, one row per sequence.  Computed
  * for the ceil(M / seg_rows) sequences of seg_rows consecutive rows of the A plane (rows addressed like mer_gemm16's A operand).  The
  * sample of a sequence is rows h, h + s, h + 2 s, ... below its valid length (valid_rows[s], or seg_rows), s the largest power of two
  * that leaves at least 16 samples, h = s / 2; sums are exact 64-bit fixed-point integers, one owner per element (no atomics): the row
@@ -343,7 +329,7 @@ typedef struct {
   float ln_eps;
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
   int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split), 4 (MX-corrected, see mer_gemm16) or
-                   * 5 (one pass + the batch-mean weight-residual bias correction, see mer_bias_corr; needs the `lo` planes) */
+                   * 5 (one pass + the per-sequence weight-residual correction table, see mer_seq_bias; needs the `lo` planes) */
   int gated_rel_pos;  /* 1: WavLM — every layer carries gru_* and the forward call must be given the position-bias table */
   int ffn_swiglu;     /* 1: DINOv2-giant SwiGLU feed-forward (HF:dinov2/modeling_dinov2.py Dinov2SwiGLUFFN): w1 = weights_in [2*ffn, D],
                        * h = silu(y[:, :ffn]) * y[:, ffn:], w2 = weights_out [D, ffn]; `ffn` is the post-gate width, `act` is ignored */

@@ -174,9 +174,6 @@ _PROTOS = {
     "mer_seq_bias_scratch_bytes": (c_ll, [c_int, c_int]),
     "mer_seq_bias": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int, c_int,
                              c_void_p, c_void_p, c_ll, c_void_p]),
-    "mer_bias_corr_scratch_bytes": (c_ll, [c_int]),
-    "mer_bias_corr": (c_int, [c_void_p, c_int, c_ll, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_int,
-                              c_void_p, c_void_p, c_void_p]),
     "mer_hubert_forward_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     "mer_hubert_conv0_gn_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,

@@ -152,121 +152,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, lon
   }
 }
 
-// Batch-mean weight-residual correction (precision "mean", passes == 5).  The rounding error of a weight matrix
-// is the same perturbation a (W - f16(W))^T for every token, and nearly all of it acts through the MEAN activation of the batch
-// (tests/studies/mean_correction.py: one mean token per launch recovers the accuracy of the exact second MFMA pass), i.e. it is a
-// bias:  c[n] = bias[n] + mean_rows(A)[k] * w_lo[n, k].  Two tiny kernels in front of the one-pass GEMM.  Both are latency-bound
-// and a CU pulls only ~25-50 GB/s on its own, so both are spread over a few hundred workgroups:
-//   colsum16_kernel    workgroup = (64-column slice of the 16-bit A plane, one of CM_PARTS row groups); a wave-load = 8 sampled rows
-//                      x 128 B (whole lines), every lane's loads independent; rows addressed like mer_gemm16's A operand, padded
-//                      rows of ragged batches skipped.  The workgroup's column sums (fp32, fixed order) are added to the call's
-//                      accumulators as 64-bit FIXED-POINT integers: integer atomics commute, so the result does not depend on
-//                      the order the workgroups arrive in (a float atomic would make the bias — and with it every output of the
-//                      GEMM — vary from run to run in the last bit)
-//   bias_corr_kernel   the mean vector into LDS, then one wave per 2 output columns takes the dot products with the residual
-//                      plane rows (a GEMV over [N, K]); 8 columns per workgroup
-constexpr int CM_ROWS = 2048;    // sampled rows: between CM_ROWS and 2 CM_ROWS of them (every row when M is smaller)
-constexpr int CM_PARTS = 16;     // row groups (workgroups per column slice)
-constexpr float CM_FIX = 16384.0f;   // 2^14: |x| <= 65504 (f16) -> |x * 2^14| < 2^31 per element; sums in 64 bits
-// Every element becomes a fixed-point integer BEFORE it is added, so all sums (lane, wave, workgroup, the global atomics) are exact
-// integer sums: the mean — and with it the bias, and with it every output bit of the GEMM — does not depend on which lane or
-// workgroup a row lands in, i.e. not on the batch's padding or row layout, only on the SET of sampled rows.  (An fp32 partial sum
-// would differ in its last bit between two paddings of the same clips; the 16-bit planes downstream then round differently and the
-// features move by the size of the rounding noise itself.)  Sampling is per sequence — tokens 0, s, 2s, ... of every sequence, s a
-// power of two — so that the sampled set does not change either when rows are padded further.
-template <typename T>
-__global__ __launch_bounds__(256) void colsum16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int stride,
-                                                       int seg_rows, const int* valid_rows, long long* acc, int* cnt) {
-  typedef typename T16<T>::v8 v8;
-  __shared__ long long red[4][64];
-  __shared__ int rcnt[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane >> 3, cg = lane & 7;
-  const int col = blockIdx.x * 64 + cg * 8;
-  const bool cin = col < K;
-  const int per_seq = seg_rows > 0 ? (seg_rows + stride - 1) / stride : 0;
-  const int R = seg_rows > 0 ? ((M + seg_rows - 1) / seg_rows) * per_seq : (M + stride - 1) / stride;   // sample slots
-  long long s[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) s[j] = 0;
-  int n = 0;
-#pragma unroll 4
-  for (int i = (blockIdx.y * 4 + wave) * 8 + sub; i < R; i += CM_PARTS * 32) {
-    int r = i * stride;
-    if (seg_rows > 0) {
-      const int seq = i / per_seq, t = (i - seq * per_seq) * stride;
-      r = seq * seg_rows + t;
-      if (t >= seg_rows || (valid_rows && t >= valid_rows[seq])) continue;
-    }
-    if (r >= M) continue;
-    ++n;
-    if (cin) {
-      const long long off = rpb > 0 ? (long long)(r / rpb) * bstride + (long long)(r % rpb) * lda : (long long)r * lda;
-      const v8 x = *reinterpret_cast<const v8*>(a + off + col);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // saturating: a bf16 plane may hold values beyond the fixed-point range (far outside any activation)
-        const float v = fminf(fmaxf(T16<T>::to_f32(x[j]), -131000.f), 131000.f);
-        s[j] += (long long)__float2int_rn(v * CM_FIX);
-      }
-    }
-  }
-  // the 8 row groups of a wave (lanes cg, cg + 8, ...), then the 4 waves through LDS: integer sums, any order gives the same bits
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    s[j] += __shfl_xor(s[j], 8);
-    s[j] += __shfl_xor(s[j], 16);
-    s[j] += __shfl_xor(s[j], 32);
-  }
-  int nn = cg == 0 ? n : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o);
-  if (sub == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[wave][cg * 8 + j] = s[j];
-  }
-  if (lane == 0) rcnt[wave] = nn;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const long long t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < K) atomicAdd(reinterpret_cast<unsigned long long*>(acc + c), (unsigned long long)t);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cnt, (rcnt[0] + rcnt[1]) + (rcnt[2] + rcnt[3]));
-  }
-}
-
-constexpr int BC_COLS = 8;   // output columns per workgroup (2 per wave)
-template <typename T>
-__global__ __launch_bounds__(256) void bias_corr_kernel(const long long* acc, const int* cnt, int K, const T* w_lo, long long ldw,
-                                                        const float* bias, int N, float* out) {
-  typedef typename T16<T>::v8 v8;
-  extern __shared__ __attribute__((aligned(16))) float mean[];   // [K]
-  const int total = *cnt;
-  const double inv = total > 0 ? 1.0 / ((double)total * (double)CM_FIX) : 0.0;
-  for (int k = threadIdx.x; k < K; k += 256) mean[k] = (float)((double)acc[k] * inv);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float s[BC_COLS / 4];
-#pragma unroll
-  for (int j = 0; j < BC_COLS / 4; ++j) {
-    const int n = blockIdx.x * BC_COLS + wave * (BC_COLS / 4) + j;
-    s[j] = 0.f;
-    if (n >= N) continue;   // wave-uniform
-    const T* wr = w_lo + (long long)n * ldw;
-    for (int k = lane * 8; k < K; k += 512) {
-      const v8 w = *reinterpret_cast<const v8*>(wr + k);
-      const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + k), m1 = *reinterpret_cast<const f32x4*>(mean + k + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s[j] += T16<T>::to_f32(w[e]) * m0[e] + T16<T>::to_f32(w[4 + e]) * m1[e];
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < BC_COLS / 4; ++j) {
-    const int n = blockIdx.x * BC_COLS + wave * (BC_COLS / 4) + j;
-    const float t = wave_sum(s[j]);
-    if (lane == 0 && n < N) out[n] = t + (bias ? bias[n] : 0.f);
-  }
-}
+constexpr float CM_FIX = 16384.0f;   // 2^14: |x| <= 65504 (f16) -> |x * 2^14| < 2^31 per element; sums in 64 bits (mer_seq_bias below)
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* patch, const float* cls, const float* pos,
@@ -433,8 +319,10 @@ extern "C" int mer_layernorm(const float* x, long long ldx, const float* gamma, 
 
 namespace mer {
 // ---- per-SEQUENCE weight-residual correction (precision "mean" since round 4) ----
-// The batch-mean bias above made a clip's features depend on its batch mates (and on how the batch was split over GPUs).  Here
-// every sequence (clip / frame / sentence) gets its own correction row:
+// The rounding error of a weight matrix is the same perturbation a (W - f16(W))^T for every token, and nearly all of it acts through
+// the MEAN activation (tests/studies/mean_correction.py: one mean token recovers the accuracy of the exact second MFMA pass), i.e.
+// it is a bias.  Round 3 took that mean over the whole batch, which made a clip's features depend on its batch mates (and on how the
+// batch was split over GPUs); since round 4 every sequence (clip / frame / sentence) gets its own correction row:
 //     tab[s, n] = bias[n] + mean_{t in sample(s)}(A[s T + t, :]) . w_lo[n, :]
 // and the one-pass GEMM that follows adds row (m / T) of the table instead of a bias vector (mer_gemm16: bias_seg_rows).  The sample
 // of a sequence — tokens s/2, s/2 + s, ... (s = the largest power of two with at least 16 samples; the offset keeps the [CLS] / BOS
@@ -598,44 +486,6 @@ extern "C" int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_
     hipLaunchKernelGGL((seqbias_kernel<bf16>), g2, dim3(1024), 0, st, (const bf16*)scratch, (long long)K, nseq, K, (const bf16*)w_lo, ldw, bias, N, n_first, table, ldt);
   }
   return check_launch("seq_bias");
-}
-
-extern "C" long long mer_bias_corr_scratch_bytes(int K) {
-  if (K <= 0) return 0;
-  return ((long long)K * 8 + 16 + 255) / 256 * 256;   // column-sum accumulators [K] int64 | row count int32
-}
-
-extern "C" int mer_bias_corr(const void* a, int dtype, long long lda, int a_rows_per_batch, long long a_batch_stride, int M, int K,
-                             int seg_rows, const int* valid_rows, const void* w_lo, long long ldw, const float* bias, int N,
-                             void* scratch, float* out, mer_stream_t stream) {
-  using namespace mer;
-  MER_REQUIRE(a && w_lo && scratch && out && M > 0 && K > 0 && N > 0, MER_EINVAL, "mer_bias_corr: bad argument");
-  MER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && a_batch_stride % 8 == 0 && ((((uintptr_t)a | (uintptr_t)w_lo | (uintptr_t)scratch) & 15) == 0), MER_ESHAPE,
-              "mer_bias_corr: K, lda, ldw, a_batch_stride must be multiples of 8 and the planes 16-byte aligned");
-  MER_REQUIRE(K <= 16384, MER_EUNSUPPORTED, "mer_bias_corr: K=%d > 16384", K);
-  MER_REQUIRE(!valid_rows || seg_rows > 0, MER_EINVAL, "mer_bias_corr: valid_rows needs seg_rows");
-  MER_REQUIRE(seg_rows >= 0, MER_EINVAL, "mer_bias_corr: seg_rows < 0");
-  MER_REQUIRE(dtype == MER_DT_F16 || dtype == MER_DT_BF16, MER_EINVAL, "mer_bias_corr: bad dtype");
-  hipStream_t st = (hipStream_t)stream;
-  long long* acc = (long long*)scratch;
-  int* cnt = (int*)(acc + K);
-  // CM_ROWS .. 2 CM_ROWS evenly spaced rows (every row below that; the mean of >= 2048 tokens is far inside what the correction
-  // needs): tokens 0, s, 2s, ... of every sequence, s the largest power of two <= M / CM_ROWS — padding the batch a little further
-  // changes neither s nor the sampled set
-  int stride = 1;
-  while ((long long)stride * 2 * CM_ROWS <= M) stride *= 2;
-  dim3 g1((unsigned)cdiv(K, 64), CM_PARTS), g2((unsigned)cdiv(N, BC_COLS));
-  {
-    ProfScope prof("bias_corr", 2.0 * N * K, (double)cdiv(M, stride) * K * 2 + (double)N * K * 2, st);
-    if (dtype == MER_DT_F16) {
-      hipLaunchKernelGGL((colsum16_kernel<f16>), g1, dim3(256), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, acc, cnt);
-      hipLaunchKernelGGL((bias_corr_kernel<f16>), g2, dim3(256), (size_t)K * 4, st, acc, cnt, K, (const f16*)w_lo, ldw, bias, N, out);
-    } else {
-      hipLaunchKernelGGL((colsum16_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, stride, seg_rows, valid_rows, acc, cnt);
-      hipLaunchKernelGGL((bias_corr_kernel<bf16>), g2, dim3(256), (size_t)K * 4, st, acc, cnt, K, (const bf16*)w_lo, ldw, bias, N, out);
-    }
-  }
-  return check_launch("bias_corr");
 }
 
 extern "C" int mer_vit_assemble(const float* patch, const float* cls, const float* pos, const float* gamma,

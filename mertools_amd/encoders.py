@@ -15,17 +15,19 @@ is no torch compute on the forward path and no CPU fallback.
 
 precision (see DESIGN.md §numerics for the measured parity of each):
     "fast"      every GEMM one fp16 MFMA pass (fp32 accumulate): ~1e-3 on the saved features
-    "mean"      One fp16 pass per GEMM + the weight-rounding residual applied through the batch's MEAN activation:
-                c = bias + mean_rows(a) (w - f16(w))^T (mer_bias_corr: sampled column means + a GEMV on the f16 residual plane, two
-                tiny launches), used as the bias of the one-pass GEMM.  The rounding error of the weights is the same perturbation
-                for every token, so almost all of what reaches the features goes through the mean activation: same parity as
-                "balanced" / "mx" (tests/studies/mean_correction.py).  That argument needs rows of comparable size —
-                true behind a LayerNorm (every GEMM of the transformer blocks, the patch embedding, HuBERT's projection), NOT in
-                HuBERT's conv stack: its inputs are un-normalised GELU outputs, a quiet passage's rows are 20-50x smaller than a
-                loud one's, the batch-mean bias is an absolute offset they cannot absorb, and the feature projection's LayerNorm
-                then magnifies it (1e-2 on speech-like loud / quiet audio, tests/test_round3_cpu.py).  So HuBERT's conv stack runs
-                the "mx" scheme under this preset — a per-row correction — and the batch-mean bias is used behind LayerNorms only.
-    "mean_all"  (study / test only) "mean" with the batch-mean bias in HuBERT's conv stack too: what "mean" was before the
+    "mean"      (default) One fp16 pass per GEMM + the weight-rounding residual applied through each SEQUENCE's mean activation:
+                table[s] = bias + mean_rows(a[sequence s]) (w - f16(w))^T (mer_seq_bias: exact sampled column means per clip / frame /
+                sentence + a small MFMA product on the f16 residual plane, two tiny launches); the one-pass GEMM adds row (m / T) of
+                that table where it would add the bias.  The rounding error of the weights is the same perturbation for every token,
+                so almost all of what reaches the features goes through the mean activation: same parity as "balanced" / "mx"
+                (tests/studies/mean_correction.py) — and, the mean being the sequence's own, a clip's features do not
+                depend on its batch mates (bit for bit: tests/test_parity_hardening_gpu.py).  The argument needs rows of comparable
+                size — true behind a LayerNorm (every GEMM of the transformer blocks, the patch embedding, HuBERT's projection), NOT
+                in HuBERT's conv stack: its inputs are un-normalised GELU outputs, a quiet passage's rows are 20-50x smaller than a
+                loud one's, a mean-token offset is an absolute error they cannot absorb, and the feature projection's LayerNorm then
+                magnifies it (1e-2 on speech-like loud / quiet audio, tests/test_round3_cpu.py).  So HuBERT's conv stack runs the
+                "mx" scheme under this preset — a per-row correction — and the table is used behind LayerNorms only.
+    "mean_all"  (study / test only) "mean" with the mean-token correction in HuBERT's conv stack too: what "mean" was before the
                 quiet-passage case was tested.
     "mx"        One fp16 pass + the weight-rounding residual w - f16(w) as an MX-fp4 plane (e2m1 + E8M0 per 32 k)
                 applied through v_mfma_scale_f32_16x16x128_f8f6f4 against bf8 copies of the activations: removes the

@@ -142,18 +142,6 @@ def seq_bias(a16, w_lo, seg_rows, bias=None, valid_rows=None, M=None, n_first=0)
     return out
 
 
-def bias_corr(a16, w_lo, bias=None, valid_rows=None, seg_rows=0, M=None):
-    """out[n] = bias[n] + mean_rows(a16)[k] * w_lo[n, k] (mer_bias_corr): the batch-mean weight-residual correction of a one-pass GEMM."""
-    assert a16.is_cuda and a16.dim() == 2 and a16.stride(1) == 1 and w_lo.dim() == 2 and w_lo.stride(1) == 1
-    M = M if M is not None else a16.shape[0]
-    K, N = a16.shape[1], w_lo.shape[0]
-    scratch = torch.zeros(_lib.lib().mer_bias_corr_scratch_bytes(K), dtype=torch.uint8, device=a16.device)
-    out = torch.empty(N, dtype=torch.float32, device=a16.device)
-    _lib.check(_lib.lib().mer_bias_corr(a16.data_ptr(), dt_code(a16.dtype), a16.stride(0), 0, 0, M, K, int(seg_rows), _p(valid_rows),
-                                        w_lo.data_ptr(), w_lo.stride(0), _p(bias), N, scratch.data_ptr(), out.data_ptr(), stream()), "mer_bias_corr")
-    return out
-
-
 def gemm16_raw(args: GemmArgs):
     _lib.check(_lib.lib().mer_gemm16(args, stream()), "mer_gemm16")
 

@@ -2,7 +2,7 @@
 // Covers the code paths written after round 1's GPU budget was spent:
 //   1. mer_image_resize_crop_u8 against bytes produced by Pillow on the host (selftest_vectors.h: frames, expected crop,
 //      the host-built window / coefficient tables; bicubic and bilinear);
-//   2. mer_bias_corr (the batch-mean weight-residual correction of the "mean" preset) against the same sum on the host
+//   2. mer_seq_bias (the per-sequence weight-residual correction table of the "mean" preset) against the same sums on the host
 // Prints one JSON line per check; exit code = number of failed checks.
 // Build (scripts/probes/build_probes.sh): hipcc abi_selftest.cpp -I../../include -L../../mertools_amd -lmer_hip -Wl,-rpath,...
 #include <hip/hip_runtime.h>
@@ -54,10 +54,11 @@ static int check_resize() {
 static unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
 static _Float16 rnd16(unsigned& s, float scale) { return (_Float16)(((int)(lcg(s) >> 8) % 2001 - 1000) * 0.001f * scale); }
 
-// mer_bias_corr through the C ABI: out[n] = bias[n] + mean(sampled rows of A)[k] * w_lo[n, k] against the same sum on the host
-static int check_bias_corr(int M) {
-  const int K = 768, N = 520;
-  unsigned seed = 777u + M;
+// mer_seq_bias through the C ABI: table[s, n] = bias[n] + mean(sampled rows of sequence s)[k] * w_lo[n, k] (the sample: rows
+// st / 2, st / 2 + st, ... of the sequence, st the largest power of two that leaves >= 16 of them) against the same sum on the host
+static int check_seq_bias(int T, int nseq) {
+  const int K = 768, N = 528, M = T * nseq - T / 3;   // the last sequence is partial
+  unsigned seed = 777u + T;
   std::vector<_Float16> a((size_t)M * K), wl((size_t)N * K);
   std::vector<float> bias(N);
   for (auto& v : a) v = rnd16(seed, 1.0f) + (_Float16)0.25f;
@@ -67,37 +68,38 @@ static int check_bias_corr(int M) {
   float* dbias = to_dev(bias.data(), bias.size());
   void* scratch;
   float* dout;
-  const long long sb = mer_bias_corr_scratch_bytes(K);
-  CK(hipMalloc(&scratch, (size_t)sb));
-  CK(hipMemset(scratch, 0, (size_t)sb));
-  CK(hipMalloc(&dout, (size_t)N * 4));
-  MER(mer_bias_corr(da, MER_DT_F16, K, 0, 0, M, K, 0, nullptr, dwl, K, dbias, N, scratch, dout, nullptr));
+  CK(hipMalloc(&scratch, (size_t)mer_seq_bias_scratch_bytes(nseq, K)));
+  CK(hipMalloc(&dout, (size_t)nseq * N * 4));
+  MER(mer_seq_bias(da, MER_DT_F16, K, 0, 0, M, K, T, nullptr, dwl, K, dbias, N, 0, scratch, dout, N, nullptr));
   CK(hipDeviceSynchronize());
-  std::vector<float> out(N);
-  CK(hipMemcpy(out.data(), dout, (size_t)N * 4, hipMemcpyDeviceToHost));
+  std::vector<float> out((size_t)nseq * N);
+  CK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
   int stride = 1;
-  while ((long long)stride * 2 * 2048 <= M) stride *= 2;
-  std::vector<double> mean(K, 0.0);
-  int cnt = 0;
-  for (int r = 0; r < M; r += stride, ++cnt)
-    for (int k = 0; k < K; ++k) mean[k] += (double)a[(size_t)r * K + k];
+  while (stride * 2 * 16 <= T) stride *= 2;
   double worst = 0, scale = 0;
-  for (int n = 0; n < N; ++n) {
-    double ref = bias[n];
-    for (int k = 0; k < K; ++k) ref += mean[k] / cnt * (double)wl[(size_t)n * K + k];
-    worst = fmax(worst, fabs(ref - out[n]));
-    scale = fmax(scale, fabs(ref));
+  for (int q = 0; q < nseq; ++q) {
+    const int valid = (q + 1) * T <= M ? T : M - q * T;
+    std::vector<double> mean(K, 0.0);
+    int cnt = 0;
+    for (int t = stride / 2; t < valid; t += stride, ++cnt)
+      for (int k = 0; k < K; ++k) mean[k] += (double)a[(size_t)(q * T + t) * K + k];
+    for (int n = 0; n < N; ++n) {
+      double ref = bias[n];
+      for (int k = 0; k < K && cnt; ++k) ref += mean[k] / cnt * (double)wl[(size_t)n * K + k];
+      worst = fmax(worst, fabs(ref - out[(size_t)q * N + n]));
+      scale = fmax(scale, fabs(ref));
+    }
   }
-  const bool ok = worst <= 3e-4 * scale + 1e-7;   // elements enter the sums as 2^-14 fixed-point values
-  printf("{\"check\": \"bias_corr == host sum over the sampled rows\", \"M\": %d, \"max_abs_err\": %.3g, \"ok\": %s}\n", M, worst, ok ? "true" : "false");
+  const bool ok = worst <= 3e-4 * scale + 1e-7;   // the mean plane is rounded to 16 bits once
+  printf("{\"check\": \"seq_bias == host sum over each sequence's sampled rows\", \"T\": %d, \"sequences\": %d, \"max_abs_err\": %.3g, \"ok\": %s}\n", T, nseq, worst, ok ? "true" : "false");
   return ok ? 0 : 1;
 }
 
 int main() {
   printf("{\"library\": \"%s\"}\n", mer_version());
   int fails = check_resize();
-  fails += check_bias_corr(1000);
-  fails += check_bias_corr(30000);
+  fails += check_seq_bias(197, 24);
+  fails += check_seq_bias(64, 70);
   printf("{\"failed_checks\": %d}\n", fails);
   return fails;
 }

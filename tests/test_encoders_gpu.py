@@ -190,7 +190,7 @@ def test_hubert_base_5s(dev):
     feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
     utt = feat.mean(1)
     res = {}
-    for prec in ("fast", "mixed", "balanced", "mx", "balanced3", "accurate"):
+    for prec in ("fast", "mixed", "balanced", "mx", "mean", "balanced3", "accurate"):
         m = HipHubertModel(sd, cfg, device=dev, precision=prec)
         assert m.out_frames(80000) == 249
         hsd, fr, pooled = m.forward_raw(wav.to(dev), hidden_states=True, frames=True, seg_start=[0, 249], seg_len=[249, 249])
@@ -200,7 +200,8 @@ def test_hubert_base_5s(dev):
         _report(f"hubert-base[{prec}]", res[prec])
         del m
     assert res["balanced"]["utt"] <= TOL, res
-    assert res["mx"]["utt"] <= TOL, res     # conv stack on the MX-corrected GEMM (M = B*T_i >= 1024), blocks fall back at B = 2
+    assert res["mx"]["utt"] <= TOL and res["mx"]["frame"] <= TOL, res     # the MX-corrected kernel whatever the row count (round 4)
+    assert res["mean"]["utt"] <= TOL and res["mean"]["frame"] <= TOL, res  # the default preset: one pass + per-sequence correction table
     assert res["accurate"]["utt"] <= X3 and res["accurate"]["frame"] <= TOL and res["accurate"]["hs12"] <= TOL, res
 
 
@@ -235,7 +236,7 @@ def test_roberta_base_64tok(dev):
     ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids))
     feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
     res = {}
-    for prec in ("fast", "balanced", "mx", "accurate"):
+    for prec in ("fast", "balanced", "mx", "mean", "accurate"):
         m = HipBertModel(sd, cfg, device=dev, precision=prec)
         hs, fr, pooled = m.forward_raw(ids.to(dev), lengths=[64] * 4, hidden_states=True, frames=True,
                                        seg_start=[b * 64 + 1 for b in range(4)], seg_len=[62] * 4)
@@ -245,7 +246,8 @@ def test_roberta_base_64tok(dev):
         _report(f"roberta-base[{prec}]", res[prec])
         del m
     assert res["balanced"]["utt"] <= TOL, res
-    assert res["mx"]["utt"] <= TOL, res      # 256 rows: the MX preset falls back to the 2-pass 128x128 kernels here
+    assert res["mx"]["utt"] <= TOL and res["mx"]["frame"] <= TOL, res      # 256 rows: still the MX-corrected kernel (a clip alone == its row of 64)
+    assert res["mean"]["utt"] <= TOL and res["mean"]["frame"] <= TOL, res  # the default preset
     assert res["accurate"]["frame"] <= TOL and res["accurate"]["utt"] <= X3, res
 
 

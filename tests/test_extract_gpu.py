@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 # The drivers are exercised on TINY random-weight models (hidden 128-ish): structure, file layout, batching, raggedness.  The one-plane
 # presets' per-FRAME maximum sits right at 1e-3 there (a max over few, noisy entries: 0.9 .. 1.05e-3 from one rounding realisation to the
-# next); the 1e-3 bar on real-size models — utterance AND frame level, every preset — is asserted in test_encoders_gpu.py.
+# next); the 1e-3 bar on real-size models — utterance AND frame level — is asserted below through the same drivers
+# (test_*_extract_files_base_size, default preset) and, per preset, in test_encoders_gpu.py / test_parity_hardening_gpu.py.
 PRESETS = ["accurate", "mean", "mx"]   # "mean" = the drivers' default preset
 
 
@@ -67,6 +68,63 @@ def test_audio_extract_files(dev, tmp_path, level, precision):
         print(f"audio driver [{precision}, {level}]: worst clip {worst:.2e}")
     finally:
         audio.split_into_batch.__defaults__ = old
+
+
+@pytest.mark.parametrize("level", ["UTTERANCE", "FRAME"])
+def test_audio_extract_files_base_size(dev, tmp_path, level):
+    """The audio driver on HuBERT-base with the default constructor (what extract_audio_huggingface.py:93-110 runs, one clip per
+    forward, fp32): ragged clips share batches, every saved file — utterance AND frame level — within 1e-3 of the oracle's
+    batch-of-one forward of that clip."""
+    from mertools_amd.encoders import HipHubertModel
+    from mertools_amd.extract import audio
+    cfg = W.hubert_config("base")
+    sd = W.hubert_state_dict(cfg, 0)
+    model = HipHubertModel(sd, cfg, device=dev)
+    rng = np.random.RandomState(7)
+    files = []
+    for i, L in enumerate([24000, 41000, 16000, 33123]):
+        p = str(tmp_path / f"clip{i}.wav")
+        _write_wav(p, rng.randn(L) * 0.1)
+        files.append(p)
+    save_dir = str(tmp_path / f"feat-{level[:3]}")
+    audio.extract("hubert-base", files, save_dir, level, 0, model=model)
+    worst = 0.0
+    for i, p in enumerate(files):
+        samples, sr = audio.read_audio(p)
+        iv = audio.split_into_batch(audio.wav2vec2_normalize(samples))
+        hs = R.hubert_hidden_states(sd, vars(cfg), iv)
+        feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).view(-1, cfg.hidden_size).numpy()
+        ref = feat.mean(0) if level == "UTTERANCE" else feat
+        out = np.load(os.path.join(save_dir, f"clip{i}.npy"))
+        assert out.shape == ref.shape and out.dtype == np.float32, (out.shape, ref.shape)
+        e = rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0]
+        worst = max(worst, e)
+        assert e <= TOL, (i, level, e)
+    print(f"audio driver, hubert-base [{model.precision}, {level}]: worst clip {worst:.2e}")
+
+
+def test_visual_extract_files_base_size(dev, tmp_path):
+    """The visual driver on CLIP ViT-B/16, default constructor: per-frame (FRAME) and per-video mean (UTTERANCE) files within 1e-3."""
+    from mertools_amd.encoders import HipCLIPModel
+    from mertools_amd.extract import visual
+    cfg = W.clip_config("base16")
+    sd = W.clip_state_dict(cfg, 0)
+    model = HipCLIPModel(sd, cfg, device=dev)
+    rng = np.random.RandomState(8)
+    counts = {"v0": 3, "v1": 1, "v2": 5}
+    vids = {v: rng.randint(0, 256, (n, 224, 224, 3)).astype(np.uint8) for v, n in counts.items()}
+    vcfg = dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim)
+    for level in ["UTTERANCE", "FRAME"]:
+        save_dir = str(tmp_path / f"clip-{level[:3]}")
+        visual.extract(model, "unused", save_dir, level, vids=sorted(counts), reader=lambda d, v: vids[v], frames_per_batch=8)
+        for vid, n in counts.items():
+            ref = R.clip_image_features(sd, vcfg, visual.clip_preprocess(vids[vid], 224)).numpy()
+            out = np.load(os.path.join(save_dir, f"{vid}.npy"))
+            if level == "UTTERANCE":
+                ref = ref.mean(0) if n > 1 else ref.squeeze()
+            e = rel_err(torch.from_numpy(out), torch.from_numpy(ref).view(out.shape))[0]
+            print(f"visual driver, clip-B/16 [{model.precision}, {level}] {vid}: {e:.2e}")
+            assert e <= TOL, (vid, level, e)
 
 
 @pytest.mark.parametrize("precision", PRESETS)
