@@ -266,6 +266,13 @@ class _HipModule:
             def checked_init(self, state_dict, config, *a, self_check="auto", **k):
                 init(self, state_dict, config, *a, **k)
                 self.escalated = None
+                if "precision" not in self.__dict__:      # the preset this object runs (after an escalation: its accurate twin's)
+                    import inspect
+                    sig = inspect.signature(init)
+                    if "precision" in sig.parameters:
+                        ba = sig.bind(self, state_dict, config, *a, **k)
+                        ba.apply_defaults()
+                        self.precision = ba.arguments["precision"]
                 if type(self) is cls:       # (once, for the most derived class)
                     _self_check(self, state_dict, config, a, k, self_check)
             cls.__init__ = checked_init
