@@ -177,6 +177,13 @@ int mer_attention(const void* q, const void* k, const void* v, long long ld,
                   void* out_hi, void* out_lo, long long ldo,
                   int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
 
+/* The same attention with fp32 q | k | v (the fp32 output of the QKV GEMM) on the exact fp32 MFMA: what the three-pass ("accurate")
+ * preset runs, so that no operand of a block is a single 16-bit plane (HF:hubert/modeling_hubert.py:236-259 in fp32).  q, k, v:
+ * device fp32, row stride ld floats (ld % 4 == 0, 16-byte aligned), head h at column 64 h; out_hi / out_lo: 16-bit hi / lo planes of
+ * the context rows (out_lo may be NULL).  Any T; keys >= kv_len[b] are masked. */
+int mer_attention_f32(const float* q, const float* k, const float* v, long long ld, void* out_hi, void* out_lo,
+                      long long ldo, int B, int T, int H, float scale, const int* kv_len, int dtype, mer_stream_t stream);
+
 /* Same attention on head-major operands: q, k, v are [B][H][T][64] planes (as written by mer_gemm16's head-major
  * output), so every head's K/V tile is one contiguous 128*T-byte stream.  out stays row-major [B*T, ldo]. */
 int mer_attention_hm(const void* q, const void* k, const void* v, void* out_hi, void* out_lo, long long ldo,

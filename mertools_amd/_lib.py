@@ -132,6 +132,8 @@ _PROTOS = {
                               c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     "mer_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
                               c_float, c_void_p, c_int, c_void_p]),
+    "mer_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                                  c_float, c_void_p, c_int, c_void_p]),
     "mer_attention_hm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_float, c_void_p,
                                  c_int, c_void_p]),
     "mer_split16": (c_int, [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),

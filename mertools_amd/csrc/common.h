@@ -46,8 +46,13 @@ template <> struct T16<bf16> {
 };
 
 // hi/lo split of an fp32 value into two 16-bit planes (hi = rn(x), lo = rn(x - hi)).
+// x must be ONE fp32 value for both lines: handed `a * b`, hipcc converts the product to 16 bits twice — v_cvt_pk_f16_f32 of the rounded
+// fp32 product for the hi it stores, v_fma_mixlo_f16 (the exact product, rounded once) for the hi it subtracts — and when the fp32 product
+// sits on a 16-bit rounding tie the two disagree: lo gets the wrong sign, one element in ~10^4 is off by a full 16-bit ulp (found through
+// mer_attention_f32's test; the f16 attention kernels' lo planes had it too).  The empty asm pins the value.
 template <typename T>
 __device__ __forceinline__ void split16(float x, T& hi, T& lo) {
+  asm volatile("" : "+v"(x));
   hi = T16<T>::from_f32(x);
   lo = T16<T>::from_f32(x - T16<T>::to_f32(hi));
 }

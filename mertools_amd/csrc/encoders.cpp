@@ -116,6 +116,7 @@ struct TfBufs {
   float* t32;
   float* h1_32;
   P16 cur16, qkv16, ctx16, h1_16, f16;
+  float* qkv32;    // passes == 3: fp32 q | k | v for mer_attention_f32 (no operand of an "accurate" block is a single 16-bit plane)
   float* ffn32;    // SwiGLU: fp32 [M, 2F] output of weights_in awaiting the gate
   float* gate;     // WavLM: [B, H, T] gate of the current layer
   float* gin32;    // WavLM pre-LN: fp32 copy of the normalised attention input (the gate is computed from it)
@@ -148,6 +149,7 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, int nseq, Tf
   b.h1_32 = c.pre_ln ? nullptr : (float*)ar.take(M * D * 4);
   b.cur16 = take16(ar, M * D, lo);
   b.qkv16 = take16(ar, M * 3 * D, false);
+  b.qkv32 = lo ? (float*)ar.take(M * 3 * D * 4) : nullptr;
   b.ctx16 = take16(ar, M * D, lo);
   b.h1_16 = take16(ar, M * D, lo);
   b.f16 = take16(ar, M * F, lo);
@@ -209,6 +211,9 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
       MER_TRY(gemm(st, dt, ps2, Bseq, D, F, cls->f16, F, w.w2, w.b2, MER_ACT_NONE, cls->t32, D, cls->y32, D, none, 0, mc1));
       continue;
     }
+    const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
+    // three passes: q | k | v stay fp32 and attention runs on the exact fp32 MFMA (not with a score bias: WavLM / BEiT keep the f16 kernel)
+    const bool f32attn = ps == 3 && b.qkv32 != nullptr && !ab;
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
     if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx != nullptr) {
@@ -225,10 +230,13 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
                           w.wqkv.hi_blkp ? (const char*)w.wqkv.hi_blkp + woff : nullptr, nullptr};
       const P16 cv = {(char*)b.qkv16.hi + (long long)2 * D * 2, nullptr};
       MER_TRY(gemm(st, dt, ps, M, D, D, b.cur16, D, wv, w.bqkv + 2 * D, MER_ACT_NONE, nullptr, 0, nullptr, 0, cv, 3 * D, mc));
-    } else
+    } else if (f32attn)
+    MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, b.qkv32, 3 * D, none, 0, mcq));
+    else
     MER_TRY(gemm(st, dt, ps, M, 3 * D, D, b.cur16, D, w.wqkv, w.bqkv, MER_ACT_NONE, nullptr, 0, nullptr, 0, b.qkv16, 3 * D, mcq));
-    const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
-    if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
+    if (f32attn) {
+      MER_TRY(mer_attention_f32(b.qkv32, b.qkv32 + D, b.qkv32 + 2 * D, 3 * D, b.ctx16.hi, b.ctx16.lo, D, Bseq, T, H, scale, kv_len, dt, (mer_stream_t)st));
+    } else if (ab) {   // additive score bias (BEiT) with WavLM's per-layer gate computed from the attention input
       const float* gate = nullptr;
       if (w.gru_w) {
         MER_TRY(mer_wavlm_gate(c.pre_ln ? b.gin32 : x, D, w.gru_w, w.gru_b, w.gru_const, Bseq, T, H, b.gate, (mer_stream_t)st));
@@ -579,7 +587,8 @@ struct VitPlan {
 // (mer_attention_cls keeps a sequence's scores in registers: T <= 584 tokens; the CLS branch of tf_forward assumes pre-LN blocks)
 static bool vit_cls_only(const mer_vit_config& c) {
   const long long g = c.image_size / (c.patch_size > 0 ? c.patch_size : 1);
-  return c.variant == 0 && c.tf.pre_ln && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1 && g * g + 1 <= 584;
+  // (not under the three-pass preset: its blocks run mer_attention_f32 on fp32 q | k | v, the CLS kernel reads 16-bit K / V planes)
+  return c.variant == 0 && c.tf.pre_ln && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1 && g * g + 1 <= 584 && c.tf.passes != 3;
 }
 
 static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {

@@ -159,6 +159,18 @@ def layernorm(x, gamma, beta, eps, *, act=None, out32=True, out16=False, out16_l
     return o32, oh, ol
 
 
+def attention_f32(qkv32, B, T, H, scale, *, kv_len=None, out_lo=True, dtype="f16"):
+    """qkv32: fp32 [B*T, 3*H*64] (q | k | v column blocks) -> ctx hi (+ lo) 16-bit planes [B*T, H*64] on the exact fp32 MFMA
+    (mer_attention_f32: the "accurate" preset's attention)."""
+    D = H * 64
+    assert qkv32.dtype == torch.float32 and qkv32.shape == (B * T, 3 * D) and qkv32.is_contiguous()
+    oh = torch.empty((B * T, D), dtype=torch16(dtype), device=qkv32.device)
+    ol = torch.empty_like(oh) if out_lo else None
+    _lib.check(_lib.lib().mer_attention_f32(qkv32.data_ptr(), qkv32.data_ptr() + D * 4, qkv32.data_ptr() + 2 * D * 4, 3 * D,
+                                            _p(oh), _p(ol), D, B, T, H, float(scale), _p(kv_len), dt_code(dtype), stream()), "mer_attention_f32")
+    return oh, ol
+
+
 def attention(qkv, B, T, H, scale, *, kv_len=None, out_lo=False):
     """qkv: 16-bit [B*T, 3*H*64] (q | k | v column blocks) -> ctx 16-bit [B*T, H*64]."""
     D = H * 64

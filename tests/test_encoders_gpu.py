@@ -1,8 +1,9 @@
 """Encoder-level parity (GPU): the HIP path through the C-ABI against the CPU oracle, same seeded
 weights and inputs.  Tolerance: north_star's 1e-3 relative on the saved feature (max-norm relative:
-max|x-ref| / max|ref|).  The "accurate" preset is held to 4e-4 on the tiny models: its GEMMs are fp32-grade (see
-test_gemm16_three_pass_is_fp32_grade) but activations are rounded to fp16 between operators and attention rounds q/k/v/P to fp16
-once (the D=128 tiny-bert sits at 3.0e-4 on one hidden-state row; the base-size models are one order below)."""
+max|x-ref| / max|ref|).  The "accurate" preset is held to 4e-4 wherever it is parametrised (tiny models, the encoders whose attention
+carries a score bias and therefore keeps the f16 attention kernel) and to 1e-4 FRAME / 2e-5 UTT on the base-size HuBERT / CLIP /
+RoBERTa: three-pass GEMMs (test_gemm16_three_pass_is_fp32_grade), hi + lo activation planes and, since round 4, attention on fp32
+q | k | v (mer_attention_f32)."""
 import os
 
 import pytest
@@ -202,7 +203,8 @@ def test_hubert_base_5s(dev):
     assert res["balanced"]["utt"] <= TOL, res
     assert res["mx"]["utt"] <= TOL and res["mx"]["frame"] <= TOL, res     # the MX-corrected kernel whatever the row count (round 4)
     assert res["mean"]["utt"] <= TOL and res["mean"]["frame"] <= TOL, res  # the default preset: one pass + per-sequence correction table
-    assert res["accurate"]["utt"] <= X3 and res["accurate"]["frame"] <= TOL and res["accurate"]["hs12"] <= TOL, res
+    # three passes + fp32 attention (mer_attention_f32, round 4): no operand of a block is a single 16-bit plane any more
+    assert res["accurate"]["utt"] <= 2e-5 and res["accurate"]["frame"] <= 1e-4 and res["accurate"]["hs12"] <= 1e-4, res
 
 
 def test_clip_base16_8frames(dev):
@@ -224,7 +226,7 @@ def test_clip_base16_8frames(dev):
     assert res["balanced"]["utt"] <= TOL, res
     assert res["mx"]["utt"] <= TOL and res["mx"]["frames"] <= TOL, res   # 1576 rows: every block GEMM runs the MX kernel
     assert res["mean"]["utt"] <= TOL and res["mean"]["frames"] <= TOL, res  # one pass + per-frame mean-token correction
-    assert res["accurate"]["frames"] <= TOL and res["accurate"]["utt"] <= X3, res
+    assert res["accurate"]["frames"] <= 1e-4 and res["accurate"]["utt"] <= 2e-5, res
 
 
 def test_roberta_base_64tok(dev):
@@ -248,7 +250,7 @@ def test_roberta_base_64tok(dev):
     assert res["balanced"]["utt"] <= TOL, res
     assert res["mx"]["utt"] <= TOL and res["mx"]["frame"] <= TOL, res      # 256 rows: still the MX-corrected kernel (a clip alone == its row of 64)
     assert res["mean"]["utt"] <= TOL and res["mean"]["frame"] <= TOL, res  # the default preset
-    assert res["accurate"]["frame"] <= TOL and res["accurate"]["utt"] <= X3, res
+    assert res["accurate"]["frame"] <= 1e-4 and res["accurate"]["utt"] <= 2e-5, res
 
 
 # ---- the kernel selection bench.py times (B = 64): M >= 1024 rows puts every block GEMM on the 256x256 tiles — one-pass
@@ -660,9 +662,9 @@ def test_activation_outliers_post_ln(dev, kind):
     """Post-LN encoders: the re-parametrisation is not exact there (the outlier channels ride the residual stream into the next
     LayerNorm, whose rows they then dominate: hidden states of ~2.5e3 in three channels against ~5e-2 in the others).  RoBERTa-base
     holds the bar with every preset.  HuBERT-base does NOT with one 16-bit activation plane — mx / mean / balanced all land at
-    utt ~4e-3..1e-2 (frame 0.3..1) on the MI355X, printed below — and does with `accurate` (hi + lo activation planes, three MFMA
-    passes): asserted.  What pretrained HuBERT checkpoints' outlier channels actually look like cannot be checked offline; a
-    deployment that sees such channels uses precision="accurate" (DESIGN.md §4)."""
+    utt ~3e-3..5e-3 (frame 0.3..0.4) on the MI355X, printed below — and does with `accurate` (hi + lo activation planes, three MFMA
+    passes, fp32 attention): asserted.  What pretrained HuBERT checkpoints' outlier channels actually look like cannot be checked
+    offline; the default constructor's self-check escalates to "accurate" by itself when it sees them."""
     from mertools_amd.encoders import HipBertModel, HipHubertModel
     from util import rel_err
     if kind == "hubert":
@@ -679,13 +681,14 @@ def test_activation_outliers_post_ln(dev, kind):
         x = W.synth_tokens(B, 64, seed=4322)
         feat = torch.stack(R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), x, torch.ones_like(x)))[[-4, -3, -2, -1]].sum(0)
         utt = feat[:, 1:-1].mean(1)
-    res = {}
+    res, clipwise = {}, {}
     for prec in ("mean", "mx", "balanced", "accurate", "mean_blocks", "mean_conv", None):
         kw = dict(precision=prec, self_check=False) if prec else {}     # None: the default constructor, self-check on
         if kind == "hubert":
             m = HipHubertModel(sd, cfg, device=dev, **kw)
             _, fr, pooled = m.forward_raw(x.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
             ef = rel_err(fr.cpu().view(B, 249, -1), feat)[0]
+            clipwise[prec] = sorted(float((fr.cpu().view(B, 249, -1)[b] - feat[b]).abs().max() / feat.abs().max()) for b in range(B))
         else:
             m = HipBertModel(sd, cfg, device=dev, **kw)
             _, fr, pooled = m.forward_raw(x.to(dev), lengths=[64] * B, frames=True, seg_start=[b * 64 + 1 for b in range(B)], seg_len=[62] * B)
@@ -698,12 +701,16 @@ def test_activation_outliers_post_ln(dev, kind):
         del m
     # Every preset is asserted where it holds the bar.  HuBERT-base (post-LN, outlier channels riding the residual stream): only the
     # three-pass arithmetic does — and the DEFAULT constructor gets there by itself: its load-time self-check sees the outlier LayerNorm
-    # channels, measures 'mean' against 'accurate' on its calibration batch and switches.  UTT then holds 1e-3 with a wide margin;
-    # FRAME is asserted at the 5e-3 this arithmetic reaches on this checkpoint: what is left sits in the outlier channels themselves
-    # (0.3 absolute on values of 2.5e3, tests/studies/outlier_layers_gpu.py), not in the others, and is not understood — DESIGN.md §4.
+    # channels, measures 'mean' against 'accurate' on its calibration batch and switches.  UTT then holds 1e-3 with a wide margin.
+    # FRAME: six of the eight clips sit at ~1e-5; two (the same two in every arithmetic) are frames on which THIS synthetic network is
+    # 10^2 - 10^3 times more sensitive than elsewhere — in fp64, a perturbation of hs[0] of the size of fp32 rounding noise moves exactly
+    # those clips (tests/studies/outlier_conditioning.py) — and reach 4.5e-4 / 3.3e-3 although every operator is exact to 3e-7 of its row
+    # maximum on exact inputs and the model's block equals the fp64 block on the model's own input to 2e-7
+    # (tests/studies/outlier_block_bisect_gpu.py, outlier_block_chain_gpu.py).  Asserted: the worst clip at 5e-3, the typical clip at 1e-4.
     if kind == "hubert":
         assert res["accurate"][0] <= TOL and res["accurate"][1] <= 5e-3, res
         assert res[None][2] and res[None][0] <= TOL and res[None][1] <= 5e-3, res
+        assert clipwise["accurate"][B // 2] <= 1e-4 and clipwise[None][B // 2] <= 1e-4, clipwise     # the median clip
     else:
         for prec in ("mean", "mx", "accurate", None):
             assert res[prec][0] <= TOL and res[prec][1] <= TOL, (kind, res)

@@ -183,6 +183,32 @@ def test_attention(dev, dtype, B, T, H):
     assert_close((oh.float() + ol.float()).cpu(), ref, 6e-3 if dtype == "bf16" else 8e-4, f"attention {dtype}")
 
 
+@pytest.mark.parametrize("B,T,H,lens", [(3, 50, 2, None), (2, 197, 12, None), (2, 249, 3, [249, 100]), (1, 600, 2, None), (4, 16, 1, [16, 1, 7, 15]), (1, 1568, 1, None)])
+def test_attention_f32(dev, B, T, H, lens):
+    """mer_attention_f32 (the "accurate" preset's attention: fp32 q | k | v on the exact fp32 MFMA, hi + lo output planes) against fp64:
+    1e-5, where the f16 kernel holds 8e-4 — any T, ragged key lengths, scores of large dynamic range."""
+    ops = _ops()
+    D = H * 64
+    qkv = _rand((B * T, 3 * D), 16)
+    qkv[:, :D] *= 3.0                       # logits up to +-60: the softmax is sharp on some rows, flat on others
+    q, k, v = [t.view(B, T, H, 64).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    s = q @ k.transpose(2, 3) / 8.0
+    if lens is not None:
+        mask = torch.arange(T)[None, :] >= torch.tensor(lens)[:, None]
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * T, D)
+    kv = torch.tensor(lens, dtype=torch.int32, device=dev) if lens is not None else None
+    oh, ol = ops.attention_f32(qkv.to(dev), B, T, H, 0.125, kv_len=kv)
+    oh1, _ = ops.attention_f32(qkv.to(dev), B, T, H, 0.125, kv_len=kv, out_lo=False)
+    torch.cuda.synchronize()
+    assert torch.equal(oh, oh1)
+    got = (oh.float() + ol.float()).cpu().view(B, T, D)
+    ref = ref.view(B, T, D)
+    for b in range(B):                       # (rows >= the sequence's length are unspecified, as for mer_attention)
+        n = lens[b] if lens is not None else T
+        assert_close(got[b, :n], ref[b, :n].float(), 1e-5, f"attention_f32 B={B} T={T} sequence {b}")
+
+
 @pytest.mark.parametrize("B,T,H,tile", [(3, 50, 2, 1), (2, 197, 4, 3), (1, 600, 2, 3)])
 def test_qkv_headmajor_gemm_and_attention(dev, B, T, H, tile):
     """QKV projection written head-major by the GEMM epilogue + attention reading that layout == the row-major path."""
