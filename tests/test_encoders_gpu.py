@@ -489,14 +489,16 @@ def test_large_trio(dev):
     torch.cuda.synchronize()
     print("large trio: " + "  ".join(f"{k}={v:.2e}" for k, v in res.items()))
     # configs[4] is served with f16 MFMA operands (same MFMA rate as bf16 on gfx950, three more mantissa bits).
-    # bf16 planes stay available: 3-pass bf16 meets the bar for the audio and video encoders; RoBERTa-large does not (1.2e-3: bf16's
-    # 8-bit mantissa in the attention operands) — test_roberta_large_bf16_is_outside_the_bar records that instead of a wider tolerance.
+    # bf16 planes stay available: 3-pass bf16 ("accurate", attention on fp32 q | k | v) meets the bar for all three large encoders
+    # (hubert-large 9e-6, videomae-large 6e-6 above, roberta-large 2e-5 in test_roberta_large_bf16_accurate).
     for k, v in res.items():
         assert v <= TOL, (k, v)
 
 
-@pytest.mark.xfail(reason="bf16 attention operands (8-bit mantissa) put RoBERTa-large at ~1.2e-3 even with 3-pass GEMMs; configs[4] is served in f16", strict=False)
-def test_roberta_large_bf16_is_outside_the_bar(dev):
+def test_roberta_large_bf16_accurate(dev):
+    """north_star names bf16 for the large trio.  Until round 4 this was an expected failure (1.2e-3: the attention kernel's bf16
+    q | k | v | P planes, 8 bits of mantissa); with attention on fp32 operands (mer_attention_f32) the three-pass bf16 preset holds
+    the bar by two orders of magnitude.  (configs[4] is still SERVED with f16 operands under the one-pass preset: DESIGN.md §4.)"""
     from mertools_amd.encoders import HipBertModel
     from util import rel_err
     cfg = W.bert_config("roberta-large")
@@ -506,7 +508,7 @@ def test_roberta_large_bf16_is_outside_the_bar(dev):
     m = HipBertModel(sd, cfg, device=dev, precision="accurate", dtype="bf16")
     e = rel_err(m.extract_utterance(ids.to(dev), [64, 64], 1, -1).cpu(), ref)[0]
     print(f"roberta-large[accurate,bf16]={e:.2e}")
-    assert e <= TOL
+    assert e <= 1e-4
 
 
 # ---- data2vec-audio: 5-layer positional conv stack on the HuBERT engine ----
