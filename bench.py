@@ -70,8 +70,8 @@ def parse():
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
     ap.add_argument("--precision", default="mean", choices=["fast", "balanced", "mx", "mean", "accurate"],
                     help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo f16 planes), mx=1 + MX-fp4 correction of the weight "
-                         "residual, mean (default)=1 + the weight residual applied through the batch's mean activation (a bias: "
-                         "mer_bias_corr; same parity as balanced / mx), accurate=3")
+                         "residual, mean (default)=1 + the weight residual applied through each sequence's mean activation (a per-clip correction row: "
+                         "mer_seq_bias; same parity as balanced / mx), accurate=3 + fp32 attention")
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--split", type=int, default=1, help="run each modality's batch as this many sub-batches on their own HIP streams "
                                                            "(kernels of one sub-batch fill the partial last wave of workgroups of the other)")

@@ -447,7 +447,7 @@ def ln_outliers(sd, channels=3, lo=30.0, hi=100.0, seed=77, compensate=True):
     and beta: the same channels everywhere, as in pretrained checkpoints) are scaled by 30-100x, and — compensate=True — the
     matching input columns of the Linear layers that read the LayerNorm are divided by the same factor.  What pretrained HuBERT /
     RoBERTa checkpoints look like to the kernels: a few massive channels in the 16-bit activation planes against tiny weight columns
-    (the rounding residual of those columns is what the MX block scales and the batch-mean correction have to get right), with the
+    (the rounding residual of those columns is what the MX block scales and the mean-token correction have to get right), with the
     Linear outputs — the attention logits among them — of the unperturbed network; in the post-LN encoders the outlier channels also
     ride the residual stream into the next LayerNorm, as massive activations do.  compensate=False scales gamma only: the attention
     logits then grow by the square of the factor and the softmax turns into an arg-max that no 16-bit Q / K plane can reproduce —
