@@ -1,5 +1,5 @@
 #!/bin/bash
-# phase stagger of the persistent GEMM: A/B per shape, bit-identity tests, headline / visual lines
+# phase stagger of the persistent GEMM (the `gemm_stagger` switch and the probe's MER_STAGGER_AB leg were removed with the experiment: this script is the record of how profiles/r04_gemm16_stagger_ab.txt was taken and no longer runs as is)
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r4c15; mkdir -p "$O"
 export TMPDIR=/tmp
