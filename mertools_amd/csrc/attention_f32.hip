@@ -7,11 +7,13 @@
 // encoder with massive activation channels amplifies it by gamma / sigma ~ 10 per LayerNorm.  Here q | k | v arrive
 // as the fp32 output of the QKV GEMM and every product is an exact fp32 product accumulated in fp32.
 //
-// A wave owns 16 queries of one (batch, head) and walks the keys 16 at a time with an online softmax; nothing is staged in LDS (a
-// head's K and V are 64 KB each at T = 256: L2-resident, re-read by the head's 16 waves).  The MFMA sums over its k index in any
-// order, which is used twice to keep every operand a lane-local value:
-//   S^T = K Q^T  k index = feature d, enumerated as d = 16 (lane >> 4) + step: a lane loads 16 CONTIGUOUS floats of its key's row
-//                (and of its query's row) and feeds them to 16 MFMAs; the result has, for query (lane & 15), keys 4 (lane >> 4) + r;
+// A workgroup = 64 queries of one (batch, head), a wave = 16 of them; the keys are walked 16 at a time with an online softmax.  The
+// K and V rows of a key tile (16 x 64 floats each) are staged ONCE per workgroup into a double-buffered LDS tile (rows padded to 68
+// floats: the fragment reads below are bank-conflict free) — the first version had every wave fetch its fragments from L2 with sixteen
+// 4-byte gathers per tile and ran at 42 TF, bound by the CU's address path, not by the matrix pipe.  The MFMA sums over its k index in
+// any order, which is used twice to keep every operand a lane-local value:
+//   S^T = K Q^T  k index = feature d, enumerated as d = 16 (lane >> 4) + step: a lane reads 16 CONTIGUOUS floats of its key's row
+//                (and holds 16 of its query's row) and feeds them to 16 MFMAs; the result has, for query (lane & 15), keys 4 (lane >> 4) + r;
 //   O^T = V^T P^T  k index = key, enumerated as key = 4 (lane >> 4) + r over the steps r = 0 .. 3: the probabilities a lane just
 //                computed ARE its B operand of step r; the A operand is V[key][16 dt + (lane & 15)].
 // Cost: 32 MFMAs of 32 cycles per 16 x 16 (query, key) tile — ~1/16 of the f16 kernel's matrix rate, a few per cent of an
@@ -26,17 +28,33 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                        long long ld, T* oh, T* ol, long long ldo, int Tn, float scale,
                                                        const int* kv_len) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RS = 68;                              // LDS row stride in floats (64 + 4: see the fragment reads)
+  __shared__ __attribute__((aligned(16))) float Ks[2][16 * RS];
+  __shared__ __attribute__((aligned(16))) float Vs[2][16 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
-  if (q0 >= Tn) return;                       // (no barriers in this kernel: a wave may leave early)
+  const int q0 = (blockIdx.x * 4 + wave) * 16;       // (a wave whose queries are all beyond T still helps staging and keeps the barriers)
   int klen = kv_len ? kv_len[b] : Tn;
   klen = klen < Tn ? klen : Tn;
   const long long row0 = (long long)b * Tn;
   const float* qb = q + row0 * ld + h * 64;
   const float* kb = k + row0 * ld + h * 64;
   const float* vb = v + row0 * ld + h * 64;
+
+  // staging: thread t brings 16 bytes of K and of V: tile row t >> 4, floats 4 (t & 15) .. + 3 — a wave-load = 4 rows x 256 B
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  f32x4 kst, vst;
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+    const int key = k0 + srow;
+    const long long off = (long long)(key < Tn ? key : Tn - 1) * ld + scol;
+    kst = *reinterpret_cast<const f32x4*>(kb + off);
+    vst = key < klen ? *reinterpret_cast<const f32x4*>(vb + off) : f32x4{0.f, 0.f, 0.f, 0.f};   // (a masked key's weight is 0: its row must not be NaN * 0)
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(&Ks[buf][srow * RS + scol]) = kst;
+    *reinterpret_cast<f32x4*>(&Vs[buf][srow * RS + scol]) = vst;
+  };
 
   // this lane's query row (clamped: rows beyond T are computed and not stored), features 16 lg .. 16 lg + 15, pre-scaled
   const int qr = q0 + li < Tn ? q0 + li : Tn - 1;
@@ -51,21 +69,26 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;                // running max / sum of this lane's query (replicated over the four lg lanes)
 
-  for (int k0 = 0; k0 < klen; k0 += 16) {
-    // S^T tile: rows = keys k0 + 4 lg + r, column = query li
-    const int kr = k0 + li < Tn ? k0 + li : Tn - 1;
+  if (klen > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < klen; k0 += 16, buf ^= 1) {
+    const bool more = k0 + 16 < klen;           // (uniform over the workgroup)
+    if (more) fetch(k0 + 16);                   // the next tile's global loads fly under this tile's MFMAs
+    // S^T tile: rows = keys k0 + 4 lg + r, column = query li.  K fragment: row li, floats 16 lg .. + 15 (row stride 68 floats: the
+    // 16 li lanes of a 16-byte read start 4 banks apart, the lg groups 16 floats apart — no two lanes of a pass share a bank)
     f32x4 kf[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kb + (long long)kr * ld + 16 * lg + 4 * j);
-    // V^T operands of this tile: keys k0 + 4 lg + r, features 16 dt + li (loaded early: independent of the softmax)
+    for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(&Ks[buf][li * RS + 16 * lg + 4 * j]);
+    // V^T operands: keys 4 lg + r, features 16 dt + li (4-byte reads: 16 consecutive banks per lg, the four lg groups 16 banks apart)
     float vf[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = k0 + 4 * lg + r;
-      const float* vr = vb + (long long)(key < Tn ? key : Tn - 1) * ld + li;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) vf[r][dt] = key < klen ? vr[16 * dt] : 0.f;   // (a masked key's weight is 0: its row must not be NaN * 0)
-    }
+      for (int dt = 0; dt < 4; ++dt) vf[r][dt] = Vs[buf][(4 * lg + r) * RS + 16 * dt + li];
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, s1 = s;    // two accumulators: consecutive MFMAs are independent (40-cycle dependent latency)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -101,6 +124,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(vf[r][dt], p[r], o[dt]);
+    // the other buffer was last read in the previous iteration, which every wave has left (the barrier below, one iteration ago)
+    if (more) stash(buf ^ 1);
+    __syncthreads();
   }
   // O^T tile dt: rows = features 16 dt + 4 lg + r, column = query li
   if (q0 + li < Tn) {
