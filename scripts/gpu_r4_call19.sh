@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes of the shipped tree (FETCH_SIZE / WRITE_SIZE / SQ counters: each its own rocprofv3 run) + smoke
+# the round's last GPU action: PMC passes of the shipped tree (FETCH_SIZE / WRITE_SIZE / SQ counters: each its own rocprofv3 run), smoke
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 bash scripts/pmc_traffic.sh 2>&1 | grep -E "rc=|gemm16p|layernorm_rows|seqbias|seqmean" | head
