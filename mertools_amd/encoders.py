@@ -264,7 +264,17 @@ class _HipModule:
         if init is not None:
             @functools.wraps(init)
             def checked_init(self, state_dict, config, *a, self_check="auto", **k):
-                init(self, state_dict, config, *a, **k)
+                # (constructors nest — a subclass's __init__ calls its parent's, both wrapped: the OUTERMOST call, whichever class it
+                #  belongs to, runs the self-check once the object is complete; a subclass without an __init__ of its own is covered too)
+                outermost = "_mer_constructing" not in self.__dict__
+                self.__dict__["_mer_constructing"] = True
+                try:
+                    init(self, state_dict, config, *a, **k)
+                finally:
+                    if outermost:
+                        self.__dict__.pop("_mer_constructing", None)
+                if not outermost:
+                    return
                 self.escalated = None
                 if "precision" not in self.__dict__:      # the preset this object runs (after an escalation: its accurate twin's)
                     import inspect
@@ -273,8 +283,7 @@ class _HipModule:
                         ba = sig.bind(self, state_dict, config, *a, **k)
                         ba.apply_defaults()
                         self.precision = ba.arguments["precision"]
-                if type(self) is cls:       # (once, for the most derived class)
-                    _self_check(self, state_dict, config, a, k, self_check)
+                _self_check(self, state_dict, config, a, k, self_check)
             cls.__init__ = checked_init
         fr = cls.__dict__.get("forward_raw")
         if fr is not None:
