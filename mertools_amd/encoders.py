@@ -201,12 +201,23 @@ SELF_CHECK_UTT, SELF_CHECK_FRAME = 1.0e-3, 2.0e-3     # preset vs accurate on th
 
 
 def ln_outlier_ratio(sd):
-    """max over the checkpoint's LayerNorm weight / bias vectors of max|v| / median|v| (1-D tensors whose key names a norm layer)."""
+    """How far the checkpoint's LayerNorm channels stick out: max over the norm layers of max|gamma| / median|gamma| and of
+    max|beta| / max(median|beta|, median|gamma|) (1-D tensors whose key names a norm layer).  A bias vector is measured against the
+    layer's GAIN scale as well as its own median: the median of a pretrained LayerNorm bias sits near zero, and max / median of the
+    bias alone would flag every real checkpoint — what matters is a channel whose affine output is many times the typical
+    channel's, i.e. |beta_c| or |gamma_c| against the typical |gamma|."""
     worst = 1.0
+    gains = {}
+    for k, v in sd.items():
+        if torch.is_tensor(v) and v.dim() == 1 and v.numel() >= 64 and ("norm" in k.lower() or "ln_" in k.lower() or ".ln" in k.lower()):
+            if k.endswith("weight"):
+                gains[k[:-len("weight")]] = float(v.detach().abs().float().median())
     for k, v in sd.items():
         if torch.is_tensor(v) and v.dim() == 1 and v.numel() >= 64 and ("norm" in k.lower() or "ln_" in k.lower() or ".ln" in k.lower()):
             a = v.detach().abs().float()
             med = float(a.median())
+            if k.endswith("bias"):
+                med = max(med, gains.get(k[:-len("bias")], 0.0))
             if med > 0:
                 worst = max(worst, float(a.max()) / med)
     return worst
@@ -390,13 +401,20 @@ class HipHubertModel(_HipModule):
         assert all(c == Cc for c in config.conv_dim), "conv_dim must be uniform"
         D = config.hidden_size
         cfg = HubertConfig()
+        # live HF config objects differ per model type: Data2VecAudioConfig has no `do_stable_layer_norm` (its blocks are post-LN,
+        # HF:data2vec/modeling_data2vec_audio.py), HubertConfig may carry `conv_pos_batch_norm` (a BatchNorm positional conv: not built)
+        stable_ln = bool(getattr(config, "do_stable_layer_norm", False))
+        if getattr(config, "conv_pos_batch_norm", False):
+            raise _lib.MerError("conv_pos_batch_norm=True (BatchNorm positional convolution) is not supported")
+        if getattr(config, "hidden_act", "gelu") != "gelu" or getattr(config, "feat_extract_activation", "gelu") != "gelu":
+            raise _lib.MerError("only GELU activations are supported in the HuBERT / wav2vec2 engine")
         cfg.tf = _tf_config(D, config.num_attention_heads, config.intermediate_size, config.num_hidden_layers,
-                            config.do_stable_layer_norm, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
+                            stable_ln, MER_ACT_GELU, config.layer_norm_eps, dtype, tf_passes)
         cfg.n_conv, cfg.conv_dim = n_conv, Cc
         for i in range(n_conv):
             cfg.conv_kernel[i], cfg.conv_stride[i] = config.conv_kernel[i], config.conv_stride[i]
-        cfg.feat_norm_group = 1 if config.feat_extract_norm == "group" else 0
-        cfg.conv_bias = int(config.conv_bias)
+        cfg.feat_norm_group = 1 if getattr(config, "feat_extract_norm", "layer") == "group" else 0
+        cfg.conv_bias = int(getattr(config, "conv_bias", False))
         cfg.feat_proj_layer_norm = int(getattr(config, "feat_proj_layer_norm", True))
         # data2vec-audio (HF:data2vec/modeling_data2vec_audio.py): num_conv_pos_embeddings is the NUMBER of positional conv
         # layers (5) and conv_pos_kernel_size their kernel (19); HuBERT / wav2vec2: one conv of kernel num_conv_pos_embeddings
@@ -404,7 +422,7 @@ class HipHubertModel(_HipModule):
         cfg.pos_k = config.conv_pos_kernel_size if d2v else config.num_conv_pos_embeddings
         cfg.pos_groups = config.num_conv_pos_embedding_groups
         cfg.pos_layers = config.num_conv_pos_embeddings if d2v else 0
-        cfg.stable_layer_norm = int(config.do_stable_layer_norm)
+        cfg.stable_layer_norm = int(stable_ln)
         cfg.conv_passes = conv_passes
         wavlm = "encoder.layers.0.attention.rel_attn_embed.weight" in sd
         cfg.tf.gated_rel_pos = int(wavlm)
@@ -416,7 +434,7 @@ class HipHubertModel(_HipModule):
             if fe + f"{i}.layer_norm.weight" in sd:
                 w.conv_norm_g[i] = hold.f32(sd[fe + f"{i}.layer_norm.weight"])
                 w.conv_norm_b[i] = hold.f32(sd[fe + f"{i}.layer_norm.bias"])
-            if config.conv_bias:
+            if cfg.conv_bias:
                 w.conv_b[i] = hold.f32(sd[fe + f"{i}.conv.bias"])
             if i >= 1:  # [Cout, Cin, k] -> [Cout, k*Cin] (column kk*Cin + ci == one contiguous im2col row)
                 wt = sd[fe + f"{i}.conv.weight"]
@@ -479,6 +497,10 @@ class HipHubertModel(_HipModule):
 
     @classmethod
     def from_hf(cls, hf_model, **kw):
+        """The drop-in call for a loaded HuggingFace module (AutoModel.from_pretrained(...) at the reference's call sites).  A real
+        checkpoint always gets the load-time comparison against the `accurate` twin (self_check=True; the LayerNorm-ratio gate of
+        "auto" is for hand-built state_dicts): `model.self_check_result` / `model.escalated` say what it found."""
+        kw.setdefault("self_check", True)
         return cls(hf_model.state_dict(), hf_model.config, **kw)
 
     def _probe_features(self):
@@ -641,6 +663,10 @@ class HipCLIPModel(_HipModule):
 
     @classmethod
     def from_hf(cls, hf_model, **kw):
+        """The drop-in call for a loaded HuggingFace module (AutoModel.from_pretrained(...) at the reference's call sites).  A real
+        checkpoint always gets the load-time comparison against the `accurate` twin (self_check=True; the LayerNorm-ratio gate of
+        "auto" is for hand-built state_dicts): `model.self_check_result` / `model.escalated` say what it found."""
+        kw.setdefault("self_check", True)
         return cls(hf_model.state_dict(), hf_model.config, **kw)
 
     def forward_raw(self, pixel_values, *, features=True, seg_start=None, seg_len=None):
@@ -753,7 +779,20 @@ class HipDinov2Model(_HipModule):
 
     @classmethod
     def from_hf(cls, hf_model, **kw):
+        """The drop-in call for a loaded HuggingFace module (AutoModel.from_pretrained(...) at the reference's call sites).  A real
+        checkpoint always gets the load-time comparison against the `accurate` twin (self_check=True; the LayerNorm-ratio gate of
+        "auto" is for hand-built state_dicts): `model.self_check_result` / `model.escalated` say what it found."""
+        kw.setdefault("self_check", True)
         return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def _probe_features(self):
+        """(clip, frame) features of the built-in calibration batch (load-time self-check): 4 frames of blocky noise at ImageNet statistics."""
+        g = torch.Generator().manual_seed(20260926)
+        S, Cn = self._cfg.image_size, self._cfg.channels
+        px = torch.rand((4, Cn, (S + 7) // 8, (S + 7) // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)[:, :, :S, :S]
+        px = (px + 0.1 * torch.rand((4, Cn, S, S), generator=g) - 0.45) / 0.225
+        feats = self.forward_raw(px.contiguous().to(self.device))[0]
+        return feats.mean(0, keepdim=True), feats
 
     def forward_raw(self, pixel_values, *, features=True, tokens=False, seg_start=None, seg_len=None):
         """-> (frame features [N, D] = token sums, last residual stream [N, 1+P, D] or None, pooled [nseg, D] or None)."""
@@ -941,7 +980,21 @@ class HipVideoMAEModel(_HipModule):
 
     @classmethod
     def from_hf(cls, hf_model, **kw):
+        """The drop-in call for a loaded HuggingFace module (AutoModel.from_pretrained(...) at the reference's call sites).  A real
+        checkpoint always gets the load-time comparison against the `accurate` twin (self_check=True; the LayerNorm-ratio gate of
+        "auto" is for hand-built state_dicts): `model.self_check_result` / `model.escalated` say what it found."""
+        kw.setdefault("self_check", True)
         return cls(hf_model.state_dict(), hf_model.config, **kw)
+
+    def _probe_features(self):
+        """(video, token) features of the built-in calibration batch (load-time self-check): one video of blocky noise that drifts over time."""
+        g = torch.Generator().manual_seed(20260926)
+        c = self._cfg
+        S, F, Cn = c.image_size, c.num_frames, c.channels
+        base = torch.rand((1, 1, Cn, (S + 7) // 8, (S + 7) // 8), generator=g).repeat_interleave(8, 3).repeat_interleave(8, 4)[..., :S, :S]
+        px = (base + 0.2 * torch.rand((1, F, Cn, S, S), generator=g) * torch.linspace(0.2, 1.0, F).view(1, F, 1, 1, 1) - 0.5) / 0.225
+        out = self.forward_raw(px.contiguous().to(self.device))[0]
+        return out.mean(1), out[0]
 
     def forward_raw(self, pixel_values, *, hidden=True, seg_start=None, seg_len=None):
         x = pixel_values
@@ -1053,6 +1106,10 @@ class HipBertModel(_HipModule):
 
     @classmethod
     def from_hf(cls, hf_model, **kw):
+        """The drop-in call for a loaded HuggingFace module (AutoModel.from_pretrained(...) at the reference's call sites).  A real
+        checkpoint always gets the load-time comparison against the `accurate` twin (self_check=True; the LayerNorm-ratio gate of
+        "auto" is for hand-built state_dicts): `model.self_check_result` / `model.escalated` say what it found."""
+        kw.setdefault("self_check", True)
         return cls(hf_model.state_dict(), hf_model.config, **kw)
 
     def _probe_features(self):

@@ -351,3 +351,44 @@ def extract_data2vec_vision(model, face_dir, save_dir, feature_level='UTTERANCE'
         pending.append((vid, px))
         nframes += len(px)
     flush()
+
+
+# ---- by name, as the reference's command line does (reference :18-26,83-101) ---------------------------------------
+CLIP_VIT_BASE = 'clip-vit-base-patch32'
+CLIP_VIT_LARGE = 'clip-vit-large-patch14'
+DATA2VEC_VISUAL = 'data2vec-vision-base-ft1k'
+VIDEOMAE_BASE = 'videomae-base'
+VIDEOMAE_LARGE = 'videomae-large'
+DINO2_LARGE = 'dinov2-large'
+DINO2_GIANT = 'dinov2-giant'
+
+# checkpoint architecture (config.model_type, what AutoModel dispatches on) -> (HIP encoder class, driver of that branch)
+_BRANCHES = {'clip': ('HipCLIPModel', 'extract'), 'videomae': ('HipVideoMAEModel', 'extract_videomae'),
+             'dinov2': ('HipDinov2Model', 'extract_dinov2'), 'data2vec-vision': ('HipData2VecVisionModel', 'extract_data2vec_vision'),
+             'beit': ('HipData2VecVisionModel', 'extract_data2vec_vision')}
+
+
+def load_model(model_name, gpu=0, precision="mean", model_dir=None):
+    """`AutoModel.from_pretrained(PATH_TO_PRETRAINED_MODELS/transformers/<model_name>)` (reference :83-91) -> the HIP encoder of the
+    checkpoint's architecture + the name of the driver that runs the reference's branch for it.  The branch follows the checkpoint's
+    `config.model_type` — which is what the reference's name lists amount to (CLIP_VIT_* are CLIP checkpoints, DINO2_* DINOv2 ...) —
+    so a differently named directory holding one of these architectures works too."""
+    from transformers import AutoModel
+    from .. import config, encoders
+    from .._lib import MerError
+    if model_dir is None:
+        model_dir = os.path.join(config.PATH_TO_PRETRAINED_MODELS, f'transformers/{model_name}')
+    hf = AutoModel.from_pretrained(model_dir)
+    kind = getattr(hf.config, 'model_type', None)
+    if kind not in _BRANCHES:
+        raise MerError(f"{model_name}: architecture '{kind}' has no HIP visual branch (supported: {sorted(_BRANCHES)})")
+    cls, driver = _BRANCHES[kind]
+    torch.cuda.set_device(max(gpu, 0))   # reference :99-101
+    return getattr(encoders, cls).from_hf(hf, device=f'cuda:{max(gpu, 0)}', precision=precision), driver
+
+
+def extract_by_name(model_name, face_dir, save_dir, feature_level='UTTERANCE', gpu=0, precision="mean", **kw):
+    """The reference's `python extract_vision_huggingface.py --model_name X --feature_level L --gpu G` for one face directory:
+    loads the checkpoint by name and runs its branch; `kw` goes to that branch's driver (vids, workers, device_preprocess ...)."""
+    model, driver = load_model(model_name, gpu, precision)
+    return globals()[driver](model, face_dir, save_dir, feature_level, **kw)

@@ -163,14 +163,14 @@ def test_videomae_base_16frames(dev):
     px = W.synth_video(1)
     ref = R.videomae_last_hidden_state(sd, vars(cfg), px)
     exp = ref.view(8, 196, -1).mean(1)
-    for prec in ("balanced", "mx", "accurate"):
+    for prec in ("mean", "balanced", "mx", "accurate"):
         m = HipVideoMAEModel(sd, cfg, device=dev, precision=prec)
         out, seg = m(px.to(dev)).last_hidden_state, m.extract_segments(px.to(dev))
         torch.cuda.synchronize()
         e, es = rel_err(out.cpu(), ref)[0], rel_err(seg.cpu(), exp)[0]
         print(f"videomae-base(4 layers)[{prec}]: last_hidden_state={e:.2e} segment-mean={es:.2e}")
         assert out.shape == (1, 1568, 768) and seg.shape == (8, 768)
-        assert es <= TOL and e <= (TOL if prec == "accurate" else 2e-3)
+        assert es <= TOL and e <= TOL    # the saved feature AND the raw last_hidden_state (measured 2-6e-4 with one-plane presets)
         del m
 
 
@@ -512,7 +512,7 @@ def test_roberta_large_bf16_accurate(dev):
 
 
 # ---- data2vec-audio: 5-layer positional conv stack on the HuBERT engine ----
-@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL)])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL), ("mean", TOL)])
 def test_data2vec_audio_tiny(dev, precision, tol):
     from mertools_amd.encoders import HipData2VecAudioModel
     cfg = W.data2vec_audio_config("tiny")
@@ -537,20 +537,22 @@ def test_data2vec_audio_base_5s(dev):
     sd = W.hubert_state_dict(cfg, 0)
     wav = W.synth_audio(2, 80000)
     hs = R.hubert_hidden_states(sd, vars(cfg), wav)
-    utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
-    for prec in ("mx", "accurate"):
+    feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
+    utt = feat.mean(1)
+    T = feat.shape[1]
+    for prec in ("mean", "mx", "accurate"):     # "mean" = the constructors' default, what from_hf() and the drivers give a user
         m = HipData2VecAudioModel(sd, cfg, device=dev, precision=prec)
-        pooled = m.extract_utterance(wav.to(dev))
+        _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[0, T], seg_len=[T, T])
         torch.cuda.synchronize()
-        e = rel_err(pooled.cpu(), utt)[0]
-        print(f"data2vec-audio-base[{prec}]: utt={e:.2e}")
-        assert e <= (TOL if prec == "mx" else X3)
+        e, ef = rel_err(pooled.cpu(), utt)[0], rel_err(fr.cpu().view(2, T, -1), feat)[0]
+        print(f"data2vec-audio-base[{prec}]: utt={e:.2e} frame={ef:.2e}")
+        assert e <= (X3 if prec == "accurate" else TOL) and ef <= (X3 if prec == "accurate" else TOL)
         del m
 
 
 # ---- WavLM: gated relative position bias in every attention ----
 @pytest.mark.parametrize("style", ["base", "large"])
-@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL)])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL), ("mean", TOL)])
 def test_wavlm_tiny(dev, precision, tol, style):
     from mertools_amd.encoders import HipWavLMModel
     over = {} if style == "base" else dict(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
@@ -574,20 +576,22 @@ def test_wavlm_base_5s(dev):
     sd = W.hubert_state_dict(cfg, 0)
     wav = W.synth_audio(2, 80000)
     hs = R.hubert_hidden_states(sd, vars(cfg), wav)
-    utt = torch.stack(hs)[[-4, -3, -2, -1]].sum(0).mean(1)
-    for prec in ("mx", "accurate"):
+    feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
+    utt = feat.mean(1)
+    T = feat.shape[1]
+    for prec in ("mean", "mx", "accurate"):     # "mean" = the constructors' default, what from_hf() and the drivers give a user
         m = HipWavLMModel(sd, cfg, device=dev, precision=prec)
-        pooled = m.extract_utterance(wav.to(dev))
+        _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[0, T], seg_len=[T, T])
         torch.cuda.synchronize()
-        e = rel_err(pooled.cpu(), utt)[0]
-        print(f"wavlm-base[{prec}]: utt={e:.2e}")
-        assert e <= (TOL if prec == "mx" else X3)
+        e, ef = rel_err(pooled.cpu(), utt)[0], rel_err(fr.cpu().view(2, T, -1), feat)[0]
+        print(f"wavlm-base[{prec}]: utt={e:.2e} frame={ef:.2e}")
+        assert e <= (X3 if prec == "accurate" else TOL) and ef <= (X3 if prec == "accurate" else TOL)
         del m
 
 
 # ---- ELECTRA (embedding projection) and ALBERT (shared block, gelu_new) on the BERT engine ----
 @pytest.mark.parametrize("kind", ["electra", "albert"])
-@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL)])
+@pytest.mark.parametrize("precision,tol", [("accurate", X3), ("mx", TOL), ("mean", TOL)])
 def test_electra_albert_tiny(dev, precision, tol, kind):
     from mertools_amd.encoders import HipBertModel
     if kind == "electra":
@@ -617,7 +621,7 @@ def test_clip_large14_frames(dev):
     sd = W.clip_state_dict(cfg, 0)
     px = W.synth_frames(5)
     ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
-    for prec in ("mx", "accurate"):
+    for prec in ("mean", "mx", "accurate"):
         m = HipCLIPModel(sd, cfg, device=dev, precision=prec)
         out = m.get_image_features(px.to(dev))
         torch.cuda.synchronize()

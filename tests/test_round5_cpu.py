@@ -1,0 +1,77 @@
+"""Round-5 host logic (CPU): the load-time self-check's LayerNorm gate, live HF config objects through the constructors' config
+reading (no GPU: the objects are built on device="cpu", nothing is launched), the visual driver's by-name dispatch table."""
+import pytest
+import torch
+
+
+def test_ln_outlier_ratio_measures_bias_against_the_gain_scale():
+    """max / median over a LayerNorm BIAS alone flags every pretrained checkpoint (its median sits near zero).  The gate
+    now measures a bias channel against max(median|beta|, median|gamma|) of its layer."""
+    from mertools_amd.encoders import ln_outlier_ratio
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for l in range(4):
+        sd[f"encoder.layers.{l}.layer_norm.weight"] = 1.0 + 0.1 * torch.randn(768, generator=g)
+        b = 0.02 * torch.randn(768, generator=g)
+        b[::2] *= 1e-3                                   # half of the channels ~0: median|beta| ~ 1e-4, max ~ 0.07
+        sd[f"encoder.layers.{l}.layer_norm.bias"] = b
+    assert float(sd["encoder.layers.0.layer_norm.bias"].abs().max() / sd["encoder.layers.0.layer_norm.bias"].abs().median()) > 50
+    assert ln_outlier_ratio(sd) < 2.0                    # an ordinary checkpoint: no twin is built under self_check="auto"
+    hot = dict(sd)
+    hot["encoder.layers.2.layer_norm.weight"] = sd["encoder.layers.2.layer_norm.weight"].clone()
+    hot["encoder.layers.2.layer_norm.weight"][5] = 40.0
+    assert ln_outlier_ratio(hot) > 30                    # a massive gain channel
+    hot = dict(sd)
+    hot["encoder.layers.1.layer_norm.bias"] = sd["encoder.layers.1.layer_norm.bias"].clone()
+    hot["encoder.layers.1.layer_norm.bias"][7] = -25.0
+    assert ln_outlier_ratio(hot) > 20                    # a massive bias channel, measured against the gains
+
+
+def test_synthetic_outlier_checkpoints_still_trip_the_gate():
+    from mertools_amd import synthetic as W
+    from mertools_amd.encoders import ln_outlier_ratio
+    cfg = W.bert_config("tiny")
+    sd = W.bert_state_dict(cfg, 0)
+    assert ln_outlier_ratio(sd) < 8.0
+    assert ln_outlier_ratio(W.ln_outliers(sd)) > 8.0
+
+
+@pytest.mark.parametrize("kind", ["hubert", "wav2vec2", "wavlm", "data2vec-audio", "clip", "roberta", "bert", "electra", "albert", "videomae",
+                                  "dinov2", "data2vec-vision"])
+def test_live_hf_config_objects_are_read_by_the_constructors(kind):
+    """The constructors read a LIVE HF config (attribute names differ per model type: Data2VecAudioConfig has no
+    do_stable_layer_norm, CLIPConfig nests vision_config, ...).  Built on device="cpu": weight conversion and the C-ABI `create`
+    call run, nothing is launched (the forward itself needs the GPU: tests/test_from_hf_gpu.py)."""
+    tr = pytest.importorskip("transformers")
+    from mertools_amd import encoders as E
+    small = dict(num_hidden_layers=1)
+    table = {
+        "hubert": (E.HipHubertModel, lambda: tr.HubertModel(tr.HubertConfig(**small))),
+        "wav2vec2": (E.HipWav2Vec2Model, lambda: tr.Wav2Vec2Model(tr.Wav2Vec2Config(**small))),
+        "wavlm": (E.HipWavLMModel, lambda: tr.WavLMModel(tr.WavLMConfig(**small))),
+        "data2vec-audio": (E.HipData2VecAudioModel, lambda: tr.Data2VecAudioModel(tr.Data2VecAudioConfig(**small))),
+        "clip": (E.HipCLIPModel, lambda: tr.CLIPModel(tr.CLIPConfig(vision_config=dict(num_hidden_layers=1), text_config=dict(num_hidden_layers=1)))),
+        "roberta": (E.HipBertModel, lambda: tr.RobertaModel(tr.RobertaConfig(vocab_size=500, max_position_embeddings=130, pad_token_id=1, **small))),
+        "bert": (E.HipBertModel, lambda: tr.BertModel(tr.BertConfig(vocab_size=500, **small))),
+        "electra": (E.HipBertModel, lambda: tr.ElectraModel(tr.ElectraConfig(vocab_size=500, **small))),
+        "albert": (E.HipBertModel, lambda: tr.AlbertModel(tr.AlbertConfig(vocab_size=500, hidden_size=768, num_attention_heads=12, intermediate_size=3072, **small))),
+        "videomae": (E.HipVideoMAEModel, lambda: tr.VideoMAEModel(tr.VideoMAEConfig(**small))),
+        "dinov2": (E.HipDinov2Model, lambda: tr.Dinov2Model(tr.Dinov2Config(**small))),
+        "data2vec-vision": (E.HipData2VecVisionModel, lambda: tr.Data2VecVisionModel(tr.Data2VecVisionConfig(use_relative_position_bias=True, **small))),
+    }
+    cls, make = table[kind]
+    m = cls.from_hf(make().eval(), device="cpu")      # self_check=True by default: a no-op without a GPU
+    assert m.precision == "mean" and m.escalated is None
+    with pytest.raises(Exception):                     # and there is no CPU forward path
+        m.forward_raw(torch.zeros(1, 16000) if kind in ("hubert", "wav2vec2", "wavlm", "data2vec-audio") else torch.zeros(1, 4, dtype=torch.long))
+
+
+def test_visual_branches_cover_the_reference_name_list():
+    """extract_vision_huggingface.py:18-26 lists CLIP, data2vec-vision, VideoMAE and DINOv2 checkpoints from HuggingFace: each
+    architecture has a branch (EVA-CLIP is a timm model: out of scope)."""
+    from mertools_amd.extract import visual
+    for kind in ("clip", "data2vec-vision", "videomae", "dinov2"):
+        cls, driver = visual._BRANCHES[kind]
+        assert callable(getattr(visual, driver))
+        from mertools_amd import encoders
+        assert hasattr(getattr(encoders, cls), "from_hf")
