@@ -93,7 +93,9 @@ typedef struct {
   int passes;   /* 1 = a_hi*w_hi; 2 = + a_hi*w_lo (needs w_lo); 3 = + a_lo*w_hi (needs a_lo too);
                  * 4 = a_hi*w_hi + bf8(a_hi)*mxfp4(w - w_hi): the weight residual as an MX-scaled fp4 plane (w_mx, from
                  * mer_mx_pack) through v_mfma_scale_f32_16x16x128_f8f6f4, 1/4 of an f16 pass; f16, 256x256 tile,
-                 * K % 128 == 0, no batching — other shapes run passes=2 with w_lo */
+                 * K % 128 == 0, no batching — other shapes run passes=2 with w_lo;
+                 * 6 = a_hi*w_hi + a_lo*w_hi (needs a_lo, no w_lo): the ACTIVATION split alone — two MFMA passes; the weight residual is
+                 * then applied through a bias table (bias_seg_rows, mer_seq_bias) by the caller */
   int tile;     /* 0 = auto; 1 = 128x128; 2 = 128x64 (narrow N); 3 = 256x256 (8 waves, 1 workgroup/CU) */
   /* headmajor_T > 0: the 16-bit output is written head-major for attention instead of row-major:
    * element (row = b*T + t, col = which*64*H + h*64 + d) goes to c16[which][b][h][t][d] (contiguous [T,64] per head);
@@ -336,13 +338,17 @@ typedef struct {
   float ln_eps;
   int dtype;      /* MER_DT_F16 | MER_DT_BF16 */
   int passes;     /* GEMM passes inside the blocks: 1, 2 (weights split), 3 (both split), 4 (MX-corrected, see mer_gemm16) or
-                   * 5 (one pass + the per-sequence weight-residual correction table, see mer_seq_bias; needs the `lo` planes) */
+                   * 5 (one pass + the per-sequence weight-residual correction table, see mer_seq_bias; needs the `lo` planes) or
+                   * 6 (5 with every GEMM input carried as hi + lo activation planes: a_hi*w_hi + a_lo*w_hi + the table — two MFMA
+                   * passes; the preset for checkpoints whose activations do not fit one 16-bit plane) */
   int gated_rel_pos;  /* 1: WavLM — every layer carries gru_* and the forward call must be given the position-bias table */
   int ffn_swiglu;     /* 1: DINOv2-giant SwiGLU feed-forward (HF:dinov2/modeling_dinov2.py Dinov2SwiGLUFFN): w1 = weights_in [2*ffn, D],
                        * h = silu(y[:, :ffn]) * y[:, ffn:], w2 = weights_out [D, ffn]; `ffn` is the post-gate width, `act` is ignored */
   int mx_skip;        /* passes == 4 / 5: GEMMs that run WITHOUT the weight-residual correction (plain one-pass f16) because
                        * their rounding error does not reach the saved features (tests/studies/mx_selective.py):
                        * bit 0 = the Q and K projections (their error only perturbs softmax logits), bit 1 = FFN fc1, bit 2 = FFN fc2 */
+  int attn_f32;       /* passes == 6: 1 = attention on fp32 q | k | v (mer_attention_f32: the QKV GEMM writes fp32) as passes == 3 always does;
+                       * 0 = the 16-bit attention kernels */
 } mer_tf_config;
 
 /* ---- HuBERT / wav2vec2 audio encoder --------------------------------------------------------

@@ -59,7 +59,7 @@ class TfLayer(C.Structure):
 
 class TfConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("layers", c_int), ("pre_ln", c_int),
-                ("act", c_int), ("ln_eps", c_float), ("dtype", c_int), ("passes", c_int), ("gated_rel_pos", c_int), ("ffn_swiglu", c_int), ("mx_skip", c_int)]
+                ("act", c_int), ("ln_eps", c_float), ("dtype", c_int), ("passes", c_int), ("gated_rel_pos", c_int), ("ffn_swiglu", c_int), ("mx_skip", c_int), ("attn_f32", c_int)]
 
 
 class HubertConfig(C.Structure):

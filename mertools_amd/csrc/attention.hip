@@ -383,8 +383,13 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const T* __restrict__ 
         psum2 += p23;
       }
       lsum[u] = lsum[u] * alpha[u] + (psum2[0] + psum2[1]);  // per-lane partial of the query's normaliser (4 lanes share a query and its alpha)
+      // the accumulator rescale only when some query of this 16-row group raised its running max in this block (wave-uniform test: one
+      // ballot + a scalar branch): after the first few key blocks alpha is exactly 1.0 for every lane of most blocks, and a multiply by
+      // 1.0 skipped changes no bit — 16 VALU slots of the ~100 per query group and key block (round 5)
+      if (__builtin_amdgcn_ballot_w64(alpha[u] != 1.0f) != 0) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha[u];
+        for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha[u];
+      }
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {

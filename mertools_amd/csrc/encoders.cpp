@@ -69,19 +69,24 @@ static void corr_plan(Arena& ar, CorrArena& ca, bool on, int kmax, long long nma
 }
 
 // mer_gemm16 with the passes == 5 preamble; `g` is complete except for the pass code handling
+// passes == 6: the same table, but the GEMM runs TWO passes, a_hi*w_hi + a_lo*w_hi: every input is carried as hi + lo 16-bit planes
+// (activations that do not fit 11 bits of mantissa: outlier channels riding a post-LN residual stream), the weight residual still
+// goes through the sequence's mean token.  Without the table scratch it runs all three passes.
 static int run_gemm(hipStream_t st, mer_gemm16_args g, const CorrWs* cw) {
-  if (g.passes == 5) {
+  if (g.passes == 5 || g.passes == 6) {
+    const bool a2 = g.passes == 6 && g.a_lo;
     CorrArena* ca = cw ? cw->arena : nullptr;
     const int nseq = (cw && cw->seg_rows > 0) ? (int)((g.M + cw->seg_rows - 1) / cw->seg_rows) : 0;
     const bool ok = ca && ca->mean16 && nseq > 0 && nseq <= ca->nseq && g.K <= ca->kmax && g.N <= ca->nmax && g.w_lo &&
                     g.N % 8 == 0 && g.K % 8 == 0 && g.nbatch <= 1;
     if (!ok) {
-      g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
+      if (a2) g.passes = g.w_lo ? 3 : 6;
+      else g.passes = (g.w_mx || g.w_lo) ? 4 : 1;   // mer_gemm16 turns 4 into the 2-pass path where the MX kernel does not apply
     } else {
       int rc = mer_seq_bias(g.a_hi, g.dtype, g.lda, g.a_rows_per_batch, g.a_batch_stride, g.M, g.K, cw->seg_rows, cw->valid,
                             g.w_lo, g.ldw, g.bias, g.N, cw->n_first, ca->mean16, ca->table, g.N, (mer_stream_t)st);
       if (rc != MER_OK) return rc;
-      g.passes = 1;
+      g.passes = a2 ? 6 : 1;
       g.w_lo = nullptr; g.w_mx = nullptr; g.w_lo_blk = nullptr;
       g.bias = ca->table;
       g.bias_seg_rows = cw->seg_rows;
@@ -131,7 +136,7 @@ struct ClsBufs {
   float* y32;      // ... after the FFN: what post_layernorm reads
 };
 static void cls_plan(Arena& ar, const mer_tf_config& c, long long nseq, ClsBufs& b) {
-  const bool lo = c.passes == 3;
+  const bool lo = c.passes == 3 || c.passes == 6;
   const long long D = c.hidden, F = c.ffn;
   b.q16 = take16(ar, nseq * D, false);
   b.ctx16 = take16(ar, nseq * D, lo);
@@ -143,13 +148,13 @@ static void cls_plan(Arena& ar, const mer_tf_config& c, long long nseq, ClsBufs&
 
 // extra_sites / extra_k / extra_n: corrected GEMMs outside the blocks that share the arena (conv stack, patch embedding)
 static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, int nseq, TfBufs& b, bool extra_on = false, int extra_k = 0, long long extra_n = 0) {
-  const bool lo = c.passes == 3;
+  const bool lo = c.passes == 3 || c.passes == 6;
   const long long D = c.hidden, F = c.ffn;
   b.t32 = (float*)ar.take(M * D * 4);
   b.h1_32 = c.pre_ln ? nullptr : (float*)ar.take(M * D * 4);
   b.cur16 = take16(ar, M * D, lo);
   b.qkv16 = take16(ar, M * 3 * D, false);
-  b.qkv32 = lo ? (float*)ar.take(M * 3 * D * 4) : nullptr;
+  b.qkv32 = (c.passes == 3 || (c.passes == 6 && c.attn_f32)) ? (float*)ar.take(M * 3 * D * 4) : nullptr;
   b.ctx16 = take16(ar, M * D, lo);
   b.h1_16 = take16(ar, M * D, lo);
   b.f16 = take16(ar, M * F, lo);
@@ -160,7 +165,7 @@ static void tf_plan(Arena& ar, const mer_tf_config& c, long long M, int nseq, Tf
   wide = extra_n > wide ? extra_n : wide;
   int kmax = (int)(F > D ? F : D);
   kmax = extra_k > kmax ? extra_k : kmax;
-  corr_plan(ar, b.corr, c.passes == 5 || extra_on, kmax, wide, nseq);
+  corr_plan(ar, b.corr, c.passes == 5 || c.passes == 6 || extra_on, kmax, wide, nseq);
 }
 
 // Runs c.layers transformer blocks.  Post-LN: hs.at(0) and b.cur16 hold the (already normalised)
@@ -175,7 +180,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
   // passes == 5: the correction goes through the batch's mean token (run_gemm() above); a sequence = T rows, kv_len = its valid rows
   const CorrWs cwv = {&b.corr, T, kv_len, 0};
   const CorrWs cwqkv = {&b.corr, T, kv_len, (c.mx_skip & 1) && (2 * D) % 16 == 0 ? 2 * D : 0};   // Q | K uncorrected (mx_skip bit 0)
-  const CorrWs* mc = (ps == 5 && b.corr.mean16) ? &cwv : nullptr;
+  const CorrWs* mc = ((ps == 5 || ps == 6) && b.corr.mean16) ? &cwv : nullptr;
   const CorrWs cw1 = {&b.corr, 1, nullptr, 0};                  // CLS-only block: one row per sequence (its "mean" is the row itself)
   const CorrWs* mc1 = mc ? &cw1 : nullptr;
   const CorrWs* mcq = mc ? &cwqkv : nullptr;
@@ -213,7 +218,7 @@ static int tf_forward(hipStream_t st, const mer_tf_config& c, const mer_tf_layer
     }
     const float* ab = w.attn_bias ? w.attn_bias : pos_bias;
     // three passes: q | k | v stay fp32 and attention runs on the exact fp32 MFMA (not with a score bias: WavLM / BEiT keep the f16 kernel)
-    const bool f32attn = ps == 3 && b.qkv32 != nullptr && !ab;
+    const bool f32attn = (ps == 3 || (ps == 6 && c.attn_f32)) && b.qkv32 != nullptr && !ab;
     // (a head-major QKV layout — mer_gemm16's headmajor_* output + mer_attention_hm — was measured: attention gains
     //  nothing from the contiguous K/V streams while the scatter epilogue costs the QKV GEMM ~4 %, so row-major stays)
     if (ps == 4 && (c.mx_skip & 1) && (2 * D) % 256 == 0 && w.wqkv.mx != nullptr) {
@@ -270,7 +275,7 @@ static int check_tf(const mer_tf_config& c, const char* who) {
   MER_REQUIRE(c.hidden > 0 && c.heads > 0 && c.hidden % c.heads == 0, MER_EINVAL, "%s: bad hidden/heads", who);
   MER_REQUIRE(c.hidden / c.heads == 64, MER_EUNSUPPORTED, "%s: head_dim %d != 64 unsupported", who, c.hidden / c.heads);
   MER_REQUIRE(c.hidden % 8 == 0 && c.ffn % 8 == 0, MER_ESHAPE, "%s: hidden/ffn must be multiples of 8", who);
-  MER_REQUIRE(c.passes >= 1 && c.passes <= 5, MER_EINVAL, "%s: passes must be 1, 2, 3, 4 (MX-corrected) or 5 (mean-corrected)", who);
+  MER_REQUIRE(c.passes >= 1 && c.passes <= 6, MER_EINVAL, "%s: passes must be 1, 2, 3, 4 (MX-corrected), 5 (mean-corrected) or 6 (5 with hi + lo activation planes)", who);
   MER_REQUIRE(c.layers >= 1, MER_EINVAL, "%s: layers < 1", who);
   MER_REQUIRE(c.gated_rel_pos == 0 || c.gated_rel_pos == 1, MER_EINVAL, "%s: gated_rel_pos must be 0 or 1", who);
   MER_REQUIRE(c.mx_skip >= 0 && c.mx_skip <= 7, MER_EINVAL, "%s: mx_skip must be a 3-bit mask", who);
@@ -489,7 +494,7 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   const CorrWs pcw = {&p.tf.corr, Tn, tn_len, 0};
   // (behind a LayerNorm: rows of one size, so the per-sequence table applies under "mean" as it does in the blocks; the conv stack above
   //  reads un-normalised GELU outputs and keeps its per-row MX correction — DESIGN.md §4)
-  const bool fp_tab = (cps == 5 || (c.tf.passes == 5 && c.feat_proj_layer_norm)) && p.tf.corr.mean16;
+  const bool fp_tab = (cps == 5 || ((c.tf.passes == 5 || c.tf.passes == 6) && c.feat_proj_layer_norm)) && p.tf.corr.mean16;
   MER_TRY(gemm(st, dt, fp_tab ? 5 : cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, fp_tab ? &pcw : nullptr));
 
   // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
@@ -588,14 +593,14 @@ struct VitPlan {
 static bool vit_cls_only(const mer_vit_config& c) {
   const long long g = c.image_size / (c.patch_size > 0 ? c.patch_size : 1);
   // (not under the three-pass preset: its blocks run mer_attention_f32 on fp32 q | k | v, the CLS kernel reads 16-bit K / V planes)
-  return c.variant == 0 && c.tf.pre_ln && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1 && g * g + 1 <= 584 && c.tf.passes != 3;
+  return c.variant == 0 && c.tf.pre_ln && !c.tf.ffn_swiglu && !c.tf.gated_rel_pos && c.tf.layers >= 1 && g * g + 1 <= 584 && c.tf.passes != 3 && !(c.tf.passes == 6 && c.tf.attn_f32);
 }
 
 static long long vit_plan(const mer_vit* h, Arena& ar, int N, VitPlan& p) {
   const mer_vit_config& c = h->cfg;
   const long long g = c.image_size / c.patch_size, P = g * g, D = c.tf.hidden;
   const long long cols = ((long long)c.channels * c.patch_size * c.patch_size + 7) / 8 * 8;
-  const bool lo = c.tf.passes == 3;
+  const bool lo = c.tf.passes == 3 || c.tf.passes == 6;
   p.patches = take16(ar, N * P * cols, lo);
   p.patch32 = (float*)ar.take(N * P * D * 4);
   p.x = (float*)ar.take(N * (P + 1) * D * 4);
@@ -700,7 +705,7 @@ static long long vmae_plan(const mer_videomae* h, Arena& ar, int B, VmaePlan& p)
   const mer_videomae_config& c = h->cfg;
   const long long g = c.image_size / c.patch_size, NP = g * g * (c.num_frames / c.tubelet_size), D = c.tf.hidden;
   const long long cols = (long long)c.channels * c.tubelet_size * c.patch_size * c.patch_size;
-  p.patches = take16(ar, B * NP * cols, c.tf.passes == 3);
+  p.patches = take16(ar, B * NP * cols, c.tf.passes == 3 || c.tf.passes == 6);
   p.x = (float*)ar.take(B * NP * D * 4);
   tf_plan(ar, c.tf, B * NP, B, p.tf, false, (int)cols);
   return ar.off;
@@ -779,7 +784,7 @@ static long long bert_plan(const mer_bert* h, Arena& ar, int B, int T, bool want
   const long long M = (long long)B * T, D = h->cfg.tf.hidden;
   const int E = h->cfg.emb_dim;
   p.ring = want_hs ? nullptr : (float*)ar.take(5 * M * D * 4);
-  p.emb16 = (E > 0 && E != D) ? take16(ar, M * E, h->cfg.tf.passes == 3) : P16{nullptr, nullptr};
+  p.emb16 = (E > 0 && E != D) ? take16(ar, M * E, h->cfg.tf.passes == 3 || h->cfg.tf.passes == 6) : P16{nullptr, nullptr};
   tf_plan(ar, h->cfg.tf, M, B, p.tf);
   return ar.off;
 }

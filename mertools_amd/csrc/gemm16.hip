@@ -169,9 +169,9 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
   MER_REQUIRE(a != nullptr, MER_EINVAL, "mer_gemm16: null args");
   MER_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, MER_ESHAPE, "mer_gemm16: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   MER_REQUIRE(a->a_hi && a->w_hi, MER_EINVAL, "mer_gemm16: a_hi / w_hi must be non-null");
-  MER_REQUIRE(a->passes >= 1 && a->passes <= 4, MER_EINVAL, "mer_gemm16: passes must be 1, 2, 3 or 4 (got %d)", a->passes);
-  MER_REQUIRE(a->passes == 4 || a->passes < 2 || a->w_lo, MER_EINVAL, "mer_gemm16: passes 2/3 need w_lo");
-  MER_REQUIRE(a->passes != 3 || a->a_lo, MER_EINVAL, "mer_gemm16: passes=3 needs a_lo");
+  MER_REQUIRE((a->passes >= 1 && a->passes <= 4) || a->passes == 6, MER_EINVAL, "mer_gemm16: passes must be 1, 2, 3, 4 or 6 (got %d)", a->passes);
+  MER_REQUIRE(a->passes == 4 || a->passes == 6 || a->passes < 2 || a->w_lo, MER_EINVAL, "mer_gemm16: passes 2/3 need w_lo");
+  MER_REQUIRE((a->passes != 3 && a->passes != 6) || a->a_lo, MER_EINVAL, "mer_gemm16: passes=3 / 6 need a_lo");
   MER_REQUIRE(a->passes != 4 || a->w_mx || a->w_lo, MER_EINVAL, "mer_gemm16: passes=4 needs w_mx (or w_lo for the 2-pass fallback)");
   MER_REQUIRE(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0, MER_ESHAPE,
               "mer_gemm16: K, lda, ldw must be multiples of 8 (K=%d lda=%lld ldw=%lld)", a->K, a->lda, a->ldw);
@@ -248,10 +248,10 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
     }
   }
   // pre-blocked weight planes feed the 256-wide LDS-DMA kernels only (their block is one 256 x 32 stage plane)
-  if (a->w_hi_blk && tile == 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && (passes == 1 || passes == 4 || a->w_lo_blk)) {
+  if (a->w_hi_blk && tile == 3 && g_gemm_glds == 1 && a->K % 32 == 0 && nbatch == 1 && (passes == 1 || passes == 4 || passes == 6 || a->w_lo_blk)) {
     MER_REQUIRE((((uintptr_t)a->w_hi_blk | (uintptr_t)a->w_lo_blk) & 15) == 0, MER_EINVAL, "mer_gemm16: pre-blocked planes must be 16-byte aligned");
     p.w_hi = a->w_hi_blk;
-    p.w_lo = a->w_lo_blk;
+    p.w_lo = passes == 6 ? nullptr : a->w_lo_blk;
     p.w_blk = 1;
   }
   // the persistent 256x256 kernel (gemm16p_impl.h): one pass, its own row-permuted pre-blocked plane (layout A for a 16-bit output,

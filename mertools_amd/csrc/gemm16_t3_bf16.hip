@@ -9,6 +9,7 @@ int dispatch_t3<bf16>(const Gemm16Params& p, int nbatch, int passes, hipStream_t
   // 256x256, 8 waves (2x4), one workgroup per CU: twice the FLOP per byte pulled into the CU
   if (passes == 3) return launch<bf16, 256, 256, 32, 2, 4, 2, 2, 2>(p, nbatch, st);
   if (passes == 2) return launch<bf16, 256, 256, 32, 2, 4, 1, 2, 3>(p, nbatch, st);
+  if (passes == 6) return launch<bf16, 256, 256, 32, 2, 4, 2, 1, 3>(p, nbatch, st);   // activation planes hi + lo against w_hi
   return launch<bf16, 256, 256, 32, 2, 4, 1, 1, 4>(p, nbatch, st);
 }
 

@@ -429,7 +429,7 @@ int dispatch_p_impl(const Gemm16Params& p0, hipStream_t st) {
   const int cus = device_cu_count();
   dim3 grid(nblk < cus ? nblk : cus, 1, 1);
   const double mn = (double)p.M * p.N;
-  ProfScope prof("gemm16", 2.0 * mn * p.K,
+  ProfScope prof("gemm16p", 2.0 * mn * p.K,   // (its own label: bench.py compares this launch set's algorithmic bytes with the PMC pool of the same kernels)
                  2.0 * (double)p.M * p.K + 2.0 * (double)p.N * p.K + mn * ((p.c32 ? 4 : 0) + (p.c16_hi ? 2 : 0) + (p.residual ? 4 : 0)), st);
   if (p.c16_hi) return launch_p_act<T, 0, TM>(p, grid, st);
   if (p.residual) return launch_p_act<T, 2, TM>(p, grid, st);

@@ -211,6 +211,21 @@ def device_normalize(samples, do_normalize, device):
         return ops.wave_normalize(t, do_normalize)
 
 
+def constant_rows(arr):
+    """Row indices of a host [rows, L] (or [L]) array / tensor that hold ONE value throughout — digital silence, a DC clip, an all-zero
+    chunk of a long clip.  The degenerate input of the HuBERT family (every frame identical): the encoder routes such rows through its
+    accurate twin (HipHubertModel.forward_raw, constant_rows).  O(1) per ordinary row: three samples are compared first."""
+    a = arr.numpy() if torch.is_tensor(arr) else np.asarray(arr)
+    if a.ndim == 1:
+        a = a[None]
+    out = []
+    for r in range(a.shape[0]):
+        row = a[r]
+        if row[0] == row[len(row) // 2] == row[-1] and row.min() == row.max():
+            out.append(r)
+    return out
+
+
 def plan_batches(pending, batch_rows, ragged, final, max_stretch=1.5, keep_at_most=0):
     """Cuts the pending clips (dicts with 'rows', 'len') into batches; returns (batches, still_pending).
     ragged: clips are sorted by length and consecutive ones share a batch while the longest is at most `max_stretch` x the
@@ -270,12 +285,14 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
             got = read_pcm16(audio_file)
             if got is not None:
                 assert got[1] == 16000, 'currently, we only test on 16k audio'
-                return audio_file, got[0]
+                return audio_file, got[0], constant_rows(got[0]) if len(got[0]) <= MAXLEN else []
         samples, sr = reader(audio_file)
         assert sr == 16000, 'currently, we only test on 16k audio'
         if device_preprocess:   # (a worker thread: numpy releases the GIL) 16-bit PCM when the file holds exactly that, else fp32
-            return audio_file, to_pcm16_or_f32(samples)
-        return audio_file, split_into_batch(wav2vec2_normalize(samples, do_normalize))
+            raw = to_pcm16_or_f32(samples)
+            return audio_file, raw, constant_rows(raw) if len(raw) <= MAXLEN else []
+        iv = split_into_batch(wav2vec2_normalize(samples, do_normalize))
+        return audio_file, iv, constant_rows(iv)
 
     up = None
     if device_preprocess:
@@ -316,11 +333,16 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
                 r += it['rows']
         chunks = [it['rows'] for it in items]
         valid = None if same else [it['len'] for it in items for _ in range(it['rows'])]
+        const, r0 = [], 0           # batch rows that hold one value throughout (found on the host, before the upload)
+        for it in items:
+            const += [r0 + r for r in it.get('const', ())]
+            r0 += it['rows']
+        ckw = {'constant_rows': const} if const else {}   # (only then: any object with the encoder's older call signature still works)
         T = model.out_frames(L)
         vids = [it['vid'] for it in items]
         if feature_level == 'UTTERANCE':
             with span("forward"):
-                pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid)
+                pooled = model.extract_utterance(rows, clip_chunks=chunks, valid_samples=valid, **ckw)
 
             def save_utt(arr, vids=vids):
                 for vid, feat in zip(vids, arr):
@@ -330,7 +352,7 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
         else:
             starts, lens = model.clip_segments(L, chunks, valid)
             with span("forward"):
-                _, frames, _ = model.forward_raw(rows, frames=True, valid_samples=valid)
+                _, frames, _ = model.forward_raw(rows, frames=True, valid_samples=valid, **ckw)
 
             def save_frames(arr, vids=vids, starts=starts, lens=lens):
                 for vid, s0, n in zip(vids, starts, lens):
@@ -360,7 +382,7 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
                             it['iv'] = ops.wave_normalize(torch.from_numpy(it['raw'])[None].to(model.device), do_normalize)
             flush(b)
 
-        for audio_file, iv in prefetch_map(host_stage, audio_files, workers, chunk=4):
+        for audio_file, iv, const in prefetch_map(host_stage, audio_files, workers, chunk=4):
             vid = os.path.basename(audio_file)[:-4]
             if device_preprocess:
                 if len(iv) > MAXLEN:   # > 10 s: chunked after the normalisation (reference :40-50)
@@ -369,9 +391,9 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
                         ivd = split_into_batch_any(ops.wave_normalize(torch.from_numpy(iv)[None].to(model.device), do_normalize))
                     pending.append(dict(vid=vid, iv=ivd, rows=ivd.shape[0], len=ivd.shape[1]))
                 else:
-                    pending.append(dict(vid=vid, raw=iv, rows=1, len=len(iv)))
+                    pending.append(dict(vid=vid, raw=iv, rows=1, len=len(iv), const=const))
             else:
-                pending.append(dict(vid=vid, iv=iv, rows=iv.shape[0], len=iv.shape[1]))
+                pending.append(dict(vid=vid, iv=iv, rows=iv.shape[0], len=iv.shape[1], const=const))
             # a full batch of clips of ONE length needs no sorting window: cut it as soon as it exists (a corpus of equal-length
             # clips would otherwise sit on the host until `window` files have been read, with the GPU idle)
             same = [it for it in pending if it['len'] == pending[-1]['len'] and it['rows'] == pending[-1]['rows'] and ('raw' in it) == ('raw' in pending[-1])]

@@ -7,6 +7,11 @@ import time
 import numpy as np
 import torch
 
+try:     # at import time, like the reference script's own `import pandas` — not inside the first call of a cold process (0.1 s)
+    import pandas as _pd
+except ImportError:
+    _pd = None
+
 from .pipeline import npy_save, span
 
 PROBE = '今天天气真好'
@@ -61,7 +66,9 @@ def save_embeddings(csv_file, embeddings, feature_level, feature_dim):
 
 def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, punc_case=None, language='chinese',
                       model_dir=None, model=None, tokenizer=None, batch_size=64, rank=None, world=None, async_save=True):
-    import pandas as pd
+    pd = _pd
+    if pd is None:
+        import pandas as pd
     print('=' * 30 + f' Extracting "{model_name}" ' + '=' * 30)
     start_time = time.time()
     if punc_case is None and language == 'chinese' and model_dir is None:
@@ -103,45 +110,102 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
         if not k:
             save_embeddings(os.path.join(save_dir, f"{name}.npy"), [], feature_level, feature_dim)
     kept = [s for s, k in zip(sentences, keep) if k]
-    # one call over the list = one call per sentence (no padding / truncation is requested, so each row is tokenised on its own);
-    # a Rust-backed tokenizer spreads the list over the host cores
-    with span("tokenize"):
-        ids_all = tokenizer(kept)['input_ids'] if kept else []
-    todo = list(zip([n for n, k in zip(names, keep) if k], ids_all))
-    todo.sort(key=lambda it: len(it[1]))
+    kept_names = [n for n, k in zip(names, keep) if k]
+    # Tokenisation runs AHEAD of the GPU loop on one worker thread, chunk by chunk (the Rust backend releases the GIL and spreads a
+    # chunk over the cores): the first batch is queued after the first chunk instead of after the whole corpus.  Every sentence is
+    # tokenised on its own (no padding / truncation is requested), so the ids are those of the reference's per-row loop (:216-225);
+    # sentences are sorted by length WITHIN a chunk — a sentence's features do not depend on its batch mates or on the padding
+    # (tests/test_parity_hardening_gpu.py), so neither does any file.
+    encode = batch_encoder(tokenizer, kept[:256])
+    step = max(4 * batch_size, 256)
+    chunks = [(kept_names[i:i + step], kept[i:i + step]) for i in range(0, len(kept), step)]
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mer-tokenize")
+    pending = [pool.submit(encode, sents) for _, sents in chunks]
     from .pipeline import writer
     with writer(model.device, async_save) as out:   # pinned non-blocking D2H + np.save on worker threads (extract.pipeline)
-        for i in range(0, len(todo), batch_size):
-            chunk = todo[i:i + batch_size]
-            T = max(len(ids) for _, ids in chunk)
-            batch = torch.full((len(chunk), T), pad_id, dtype=torch.int64)
-            lens = []
-            for r, (_, ids) in enumerate(chunk):
-                batch[r, :len(ids)] = torch.as_tensor(ids, dtype=torch.int64)
-                lens.append(len(ids))
-            names = [name for name, _ in chunk]
-            if feature_level == 'FRAME':
-                with span("forward"):
-                    _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
+        for (chunk_names, _), fut in zip(chunks, pending):
+            with span("tokenize"):
+                ids_all = fut.result()
+            todo = sorted(zip(chunk_names, ids_all), key=lambda it: len(it[1]))
+            for i in range(0, len(todo), batch_size):
+                chunk = todo[i:i + batch_size]
+                T = max(len(ids) for _, ids in chunk)
+                batch = torch.full((len(chunk), T), pad_id, dtype=torch.int64)
+                lens = []
+                for r, (_, ids) in enumerate(chunk):
+                    batch[r, :len(ids)] = torch.as_tensor(ids, dtype=torch.int64)
+                    lens.append(len(ids))
+                names = [name for name, _ in chunk]
+                if feature_level == 'FRAME':
+                    with span("forward"):
+                        _, frames, _ = model.forward_raw(batch, lengths=lens, frames=True)
 
-                def save_frames(arr, names=names, lens=lens, T=T):
-                    arr = arr.reshape(len(names), T, -1)
-                    for r, name in enumerate(names):
-                        e = lens[r] + end if end is not None else lens[r]
-                        save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r, start:e], feature_level, feature_dim)
-                with span("submit"):
-                    out.submit(frames, save_frames)
-            else:
-                with span("forward"):
-                    pooled = model.extract_utterance(batch, lens, start, end)
+                    def save_frames(arr, names=names, lens=lens, T=T):
+                        arr = arr.reshape(len(names), T, -1)
+                        for r, name in enumerate(names):
+                            e = lens[r] + end if end is not None else lens[r]
+                            save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r, start:e], feature_level, feature_dim)
+                    with span("submit"):
+                        out.submit(frames, save_frames)
+                else:
+                    with span("forward"):
+                        pooled = model.extract_utterance(batch, lens, start, end)
 
-                def save_utt(arr, names=names, lens=lens):
-                    for r, name in enumerate(names):
-                        n_tok = (lens[r] + (end if end is not None else 0)) - start
-                        save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r] if n_tok > 0 else [], feature_level, feature_dim)
-                with span("submit"):
-                    out.submit(pooled, save_utt)
+                    def save_utt(arr, names=names, lens=lens):
+                        for r, name in enumerate(names):
+                            n_tok = (lens[r] + (end if end is not None else 0)) - start
+                            save_embeddings(os.path.join(save_dir, f'{name}.npy'), arr[r] if n_tok > 0 else [], feature_level, feature_dim)
+                    with span("submit"):
+                        out.submit(pooled, save_utt)
+    pool.shutdown(wait=True)
     print(f'Total {len(df)} files done! Time used ({model_name}): {time.time() - start_time:.1f}s.')
+
+
+def batch_encoder(tokenizer, probe_sentences=()):
+    """-> encode(list of sentences) == [tokenizer(s)['input_ids'] for s in sentences] (the reference's per-row call, :216-225), by the
+    cheapest route a PROBE shows to give the same ids on this corpus' first sentences:
+      1. a Rust-backed tokenizer's backend `encode_batch` called directly — transformers' wrapper spends 4x the tokenisation time
+         turning every Encoding into six Python lists of which the driver reads one;
+      2. for a pure-Python ("slow", what use_fast=False gives under transformers 4) tokenizer: the Rust twin AutoTokenizer loads from
+         the same directory, if it reproduces the slow tokenizer's ids on the probe sentences (up to 256) and the probe sentence;
+      3. otherwise the tokenizer as given, one call over the list."""
+    probe = [s for s in list(probe_sentences)[:256] if s] + [PROBE]
+
+    def as_given(sents):
+        return tokenizer(sents)['input_ids'] if sents else []
+
+    def raw_route(tok):
+        backend = getattr(tok, 'backend_tokenizer', None)
+        if backend is None or not getattr(tok, 'is_fast', False):
+            return None
+
+        def enc(sents):
+            return [e.ids for e in backend.encode_batch(sents, add_special_tokens=True)] if sents else []
+        return enc
+
+    want = None
+    for cand_name in ('raw', 'twin'):
+        try:
+            if cand_name == 'raw':
+                enc = raw_route(tokenizer)
+            else:
+                if getattr(tokenizer, 'is_fast', False):
+                    break
+                path = getattr(tokenizer, 'name_or_path', '')
+                if not (path and os.path.isdir(path)):
+                    break
+                from transformers import AutoTokenizer
+                enc = raw_route(AutoTokenizer.from_pretrained(path, use_fast=True))
+            if enc is None:
+                continue
+            if want is None:
+                want = [tokenizer(s)['input_ids'] for s in probe]      # the reference's call, sentence by sentence
+            if enc(probe) == want:
+                return enc
+        except Exception:
+            continue
+    return as_given
 
 
 def merge_subword_embeddings(tokens, output, sentence, combine_type='mean'):

@@ -1,7 +1,7 @@
 // gemm16_bench.cpp — times the REAL mer_gemm16 kernels through the C ABI of libmer_hip.so, without Python or torch, so that one
 // GPU-box call costs ~15 s instead of ~45 s (no interpreter / torch import): the tool for A/B-ing kernel changes next round.
 //
-//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | roberta | hubert32 | all;   MER_TILE=3|4 forces a tile class
+//   gemm16_bench.bin [warm] [reps] [set]      set: clip (default) | hubert | roberta | hubert32 | square | all;   MER_TILE=3|4 forces a tile class
 //
 // For every (shape, epilogue) of the bench's block GEMMs it runs pre-blocked W (mer_w_block_pack) with hot operands (one set of planes,
 // re-launched) and with cold ones (four rotating A / output plane sets).  Operands are pseudo-random f16 values: constant-filled planes
@@ -220,7 +220,16 @@ int main(int argc, char** argv) {
       {"hubert b32 fc1 (gelu)", Mh2, 3072, 768, 1, MER_ACT_GELU, false, false, true},
       {"hubert b32 fc2 (residual, fp32 out)", Mh2, 768, 3072, 1, MER_ACT_NONE, true, true, false},
   };
+  // the guide's calibration shapes (cdna_hip_programming.md §5: its plain-HIP 256^2 8-phase template reaches ~1320-1340 TF at 4096^3 and
+  // ~1470 TF at 8192^3 on uniform random operands): what THIS kernel does on them says how much of the gap to that template is the
+  // K loop and how much is the encoder's shapes (K = 768: a tile boundary every 24 slabs, fp32 + residual epilogues, partial rounds)
+  const Shape square[] = {
+      {"4096^3 (16-bit out)", 4096, 4096, 4096, 1, MER_ACT_NONE, false, false, true},
+      {"8192^3 (16-bit out)", 8192, 8192, 8192, 1, MER_ACT_NONE, false, false, true},
+      {"M = 100864, N = 2304, K = 4096 (CLIP QKV's plane with a long K)", Mc, 2304, 4096, 1, MER_ACT_NONE, false, false, true},
+  };
   const bool all = !strcmp(set, "all");
+  if (!strcmp(set, "square")) for (const Shape& s : square) run_shape(s, warm, reps);
   if (all || !strcmp(set, "clip")) for (const Shape& s : clip) run_shape(s, warm, reps);
   if (all || !strcmp(set, "hubert")) for (const Shape& s : hubert) run_shape(s, warm, reps);
   if (all || !strcmp(set, "roberta")) for (const Shape& s : roberta) run_shape(s, warm, reps);

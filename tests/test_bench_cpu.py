@@ -18,10 +18,10 @@ def test_committed_pmc_collection_matches_the_kernel_source():
     """Editing ANY source under mertools_amd/csrc/ without re-collecting the PMC passes (scripts/pmc_traffic.sh, scripts/pmc_mfma.sh) makes this
     fail — on purpose: the bench would otherwise print traffic = null / mfma_busy = null on the GPU box."""
     b = _bench()
-    traffic, detail = b.pmc_traffic("gemm16", 5e8)   # (the default preset launches the one-pass kernel only)
+    traffic, detail = b.pmc_traffic("gemm16p", 5e8)   # (the default preset launches the one-pass kernel only)
     assert traffic is not None and traffic > 1e8, detail
     assert detail["kernel_source_sha"] == b.kernel_source_sha() and detail["source"].startswith("profiles/")
-    busy = b.pmc_mfma_busy("gemm16")
+    busy = b.pmc_mfma_busy("gemm16p")
     assert busy is not None and 0.05 < busy["mfma_busy"] < 1.0 and busy["kernel_source_sha"] == b.kernel_source_sha(), busy
     # the counter calibration the definition rests on: 16 busy cycles per 16x16x32 MFMA
     assert abs(busy["SQ_VALU_MFMA_BUSY_CYCLES"] / busy["SQ_INSTS_MFMA"] - 16.0) < 0.01
@@ -32,7 +32,7 @@ def test_committed_kernel_stats_match_the_kernel_source():
     carries the sha of the library sources it was taken on (scripts/stamp_kernel_stats.py): a summary of another tree fails here."""
     import glob
     b = _bench()
-    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*kernel_stats.json")))
+    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*kernel_stats.json")))
     assert stamps, "no stamped kernel-stats summary under profiles/"
     d = json.load(open(stamps[-1]))
     assert d["_source_sha"] == b.kernel_source_sha(), (stamps[-1], d["_source_sha"], b.kernel_source_sha())
@@ -49,15 +49,15 @@ def test_stale_pmc_collection_is_refused(tmp_path):
     for f in glob.glob(os.path.join(ROOT, "mertools_amd", "csrc", "*")):
         if f.endswith((".h", ".hip", ".cpp")):
             shutil.copy(f, root / "mertools_amd" / "csrc" / os.path.basename(f))
-    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*pmc_hbm_traffic*.json")))[-1]
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*pmc_hbm_traffic*.json")))[-1]
     shutil.copy(pmc, root / "profiles" / os.path.basename(pmc))
-    assert b.pmc_traffic("gemm16", 5e8, root=str(root))[0] is not None
+    assert b.pmc_traffic("gemm16p", 5e8, root=str(root))[0] is not None
     with open(root / "mertools_amd" / "csrc" / "norm.hip", "a") as f:      # ANY source of the library, not only the GEMM template
         f.write("// a kernel edit\n")
-    traffic, detail = b.pmc_traffic("gemm16", 5e8, root=str(root))
+    traffic, detail = b.pmc_traffic("gemm16p", 5e8, root=str(root))
     assert traffic is None and os.path.basename(pmc) in detail["note"] and b.kernel_source_sha(str(root)) in detail["note"]
     # a collection without a stamp (round 1's) is never quoted either
     d = json.load(open(root / "profiles" / os.path.basename(pmc)))
     d.pop("_source_sha")
     json.dump(d, open(root / "profiles" / "r05_pmc_hbm_traffic.json", "w"))
-    assert b.pmc_traffic("gemm16", 5e8, root=str(root))[0] is None
+    assert b.pmc_traffic("gemm16p", 5e8, root=str(root))[0] is None

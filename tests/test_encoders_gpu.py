@@ -191,7 +191,7 @@ def test_hubert_base_5s(dev):
     feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)
     utt = feat.mean(1)
     res = {}
-    for prec in ("fast", "mixed", "balanced", "mx", "mean", "balanced3", "accurate"):
+    for prec in ("fast", "mixed", "balanced", "mx", "mean", "mean_a2", "balanced3", "accurate"):
         m = HipHubertModel(sd, cfg, device=dev, precision=prec)
         assert m.out_frames(80000) == 249
         hsd, fr, pooled = m.forward_raw(wav.to(dev), hidden_states=True, frames=True, seg_start=[0, 249], seg_len=[249, 249])
@@ -203,6 +203,8 @@ def test_hubert_base_5s(dev):
     assert res["balanced"]["utt"] <= TOL, res
     assert res["mx"]["utt"] <= TOL and res["mx"]["frame"] <= TOL, res     # the MX-corrected kernel whatever the row count (round 4)
     assert res["mean"]["utt"] <= TOL and res["mean"]["frame"] <= TOL, res  # the default preset: one pass + per-sequence correction table
+    # round 5: hi + lo activation planes, two passes + the table, f16 attention: the first rung of the self-check's ladder
+    assert res["mean_a2"]["utt"] <= TOL and res["mean_a2"]["frame"] <= TOL and res["mean_a2"]["frame"] <= res["mean"]["frame"], res
     # three passes + fp32 attention (mer_attention_f32, round 4): no operand of a block is a single 16-bit plane any more
     assert res["accurate"]["utt"] <= 2e-5 and res["accurate"]["frame"] <= 1e-4 and res["accurate"]["hs12"] <= 1e-4, res
 
@@ -215,7 +217,7 @@ def test_clip_base16_8frames(dev):
     px = W.synth_frames(8)
     ref = R.clip_image_features(sd, dict(vars(cfg.vision_config), projection_dim=cfg.projection_dim), px)
     res = {}
-    for prec in ("fast", "balanced", "mx", "mean", "accurate"):
+    for prec in ("fast", "balanced", "mx", "mean", "mean_a2", "accurate"):
         m = HipCLIPModel(sd, cfg, device=dev, precision=prec)
         out = m.get_image_features(px.to(dev))
         pooled = m.extract_utterance(px.to(dev), [8])
@@ -226,6 +228,7 @@ def test_clip_base16_8frames(dev):
     assert res["balanced"]["utt"] <= TOL, res
     assert res["mx"]["utt"] <= TOL and res["mx"]["frames"] <= TOL, res   # 1576 rows: every block GEMM runs the MX kernel
     assert res["mean"]["utt"] <= TOL and res["mean"]["frames"] <= TOL, res  # one pass + per-frame mean-token correction
+    assert res["mean_a2"]["utt"] <= TOL and res["mean_a2"]["frames"] <= TOL, res
     assert res["accurate"]["frames"] <= 1e-4 and res["accurate"]["utt"] <= 2e-5, res
 
 
@@ -238,7 +241,7 @@ def test_roberta_base_64tok(dev):
     ref = R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), ids, torch.ones_like(ids))
     feat = torch.stack(ref)[[-4, -3, -2, -1]].sum(0)
     res = {}
-    for prec in ("fast", "balanced", "mx", "mean", "accurate"):
+    for prec in ("fast", "balanced", "mx", "mean", "mean_a2", "accurate"):
         m = HipBertModel(sd, cfg, device=dev, precision=prec)
         hs, fr, pooled = m.forward_raw(ids.to(dev), lengths=[64] * 4, hidden_states=True, frames=True,
                                        seg_start=[b * 64 + 1 for b in range(4)], seg_len=[62] * 4)
@@ -250,6 +253,7 @@ def test_roberta_base_64tok(dev):
     assert res["balanced"]["utt"] <= TOL, res
     assert res["mx"]["utt"] <= TOL and res["mx"]["frame"] <= TOL, res      # 256 rows: still the MX-corrected kernel (a clip alone == its row of 64)
     assert res["mean"]["utt"] <= TOL and res["mean"]["frame"] <= TOL, res  # the default preset
+    assert res["mean_a2"]["utt"] <= TOL and res["mean_a2"]["frame"] <= TOL, res
     assert res["accurate"]["frame"] <= 1e-4 and res["accurate"]["utt"] <= 2e-5, res
 
 
@@ -688,7 +692,8 @@ def test_activation_outliers_post_ln(dev, kind):
         feat = torch.stack(R.bert_hidden_states(sd, dict(vars(cfg), roberta=True), x, torch.ones_like(x)))[[-4, -3, -2, -1]].sum(0)
         utt = feat[:, 1:-1].mean(1)
     res, clipwise = {}, {}
-    for prec in ("mean", "mx", "balanced", "accurate", "mean_blocks", "mean_conv", None):
+    study = ("mean_a2f", "a2_conv2", "a2_conv3", "a2f_conv3", "mean_conv3", "x3_conv4") if kind == "hubert" else ()   # (printed, not asserted: where the error enters)
+    for prec in ("mean", "mx", "balanced", "mean_a2", "accurate", "mean_blocks", "mean_conv") + study + (None,):
         kw = dict(precision=prec, self_check=False) if prec else {}     # None: the default constructor, self-check on
         if kind == "hubert":
             m = HipHubertModel(sd, cfg, device=dev, **kw)

@@ -38,13 +38,17 @@ def _perturb(m, seed):
     return m.eval()
 
 
-def _checked(m, name):
-    """Every from_hf() object has gone through the load-time comparison with its accurate twin and kept its preset on these
-    ordinary checkpoints."""
+def _checked(m, name, may_escalate_to=()):
+    """Every from_hf() object has gone through the load-time comparison with its accurate twin; these ordinary checkpoints keep the
+    default preset — but for the one whose calibration batch exceeds the bar (data2vec-audio as HF initialises it: a "layer"-norm
+    conv stack + post-LN blocks with small weights, FRAME 1.5e-3 under "mean"), which must have moved up the ladder BY ITSELF."""
     r = getattr(m, "self_check_result", None)
     assert r is not None, f"{name}: from_hf() did not run the load-time self-check"
-    assert m.escalated is None and m.precision == "mean", (name, r, m.escalated)
-    print(f"{name}: self-check {r}")
+    print(f"{name}: self-check {r} -> running '{m.precision}'")
+    if m.escalated is None:
+        assert m.precision == "mean", (name, r)
+    else:
+        assert m.precision in may_escalate_to, (name, r, m.escalated)
 
 
 # ---- the base trio BASELINE.json names, as live HF modules carrying the synthetic base checkpoints -------------------------------
@@ -86,14 +90,20 @@ def test_from_hf_base_trio(dev):
     assert max(ea, eaf, ev, evu, et, etf) <= TOL
 
 
-# ---- every other architecture the constructors accept, as a live module of real width (2 blocks keep the CPU forward at seconds) ----
-def _audio_pair(hf, dev, name):
+# ---- every other architecture the constructors accept, as a live module of real width; the audio encoders at their real depth too
+# (their saved feature is the sum of the LAST FOUR of 12 / 24 hidden states: a 4-block truncation would sum the four states right behind
+# the conv stack instead, whose one-plane rounding (hs[0]: 1e-3 on a "layer"-norm front end, profiles/r05_d2v_audio_hs_errors.txt) has
+# not yet been forgotten by the post-LN blocks); vision / text: 2 - 4 blocks keep the CPU forward at seconds ----
+def _audio_pair(hf, dev, name, may_escalate_to=()):
+    import warnings
     from mertools_amd.encoders import HipHubertModel
     wav = W.synth_audio(2, 48000, seed=31)
     with torch.no_grad():
         feat = torch.stack(hf(wav, output_hidden_states=True).hidden_states)[[-4, -3, -2, -1]].sum(0)
-    m = HipHubertModel.from_hf(hf, device=dev)
-    _checked(m, name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # (an escalation warns)
+        m = HipHubertModel.from_hf(hf, device=dev)
+    _checked(m, name, may_escalate_to)
     T = feat.shape[1]
     _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[0, T], seg_len=[T, T])
     return rel_err(pooled.cpu(), feat.mean(1))[0], rel_err(fr.cpu().view(2, T, -1), feat)[0]
@@ -116,15 +126,16 @@ def test_from_hf_other_architectures(dev, kind):
     import transformers as tr
     eager = dict(attn_implementation="eager")
     if kind == "wav2vec2":
-        e = _audio_pair(_perturb(tr.Wav2Vec2Model(tr.Wav2Vec2Config(num_hidden_layers=4, mask_time_prob=0.0, **eager)), 1), dev, kind)
+        e = _audio_pair(_perturb(tr.Wav2Vec2Model(tr.Wav2Vec2Config(mask_time_prob=0.0, **eager)), 1), dev, kind)
     elif kind == "wav2vec2-large-style":   # "layer" front end with conv bias, pre-LN blocks, hidden 1024
-        c = tr.Wav2Vec2Config(num_hidden_layers=4, hidden_size=1024, num_attention_heads=16, intermediate_size=4096, feat_extract_norm="layer",
+        c = tr.Wav2Vec2Config(num_hidden_layers=24, hidden_size=1024, num_attention_heads=16, intermediate_size=4096, feat_extract_norm="layer",
                               conv_bias=True, do_stable_layer_norm=True, mask_time_prob=0.0, **eager)
         e = _audio_pair(_perturb(tr.Wav2Vec2Model(c), 2), dev, kind)
     elif kind == "wavlm":
-        e = _audio_pair(_perturb(tr.WavLMModel(tr.WavLMConfig(num_hidden_layers=4, mask_time_prob=0.0)), 3), dev, kind)
+        e = _audio_pair(_perturb(tr.WavLMModel(tr.WavLMConfig(mask_time_prob=0.0)), 3), dev, kind)
     elif kind == "data2vec-audio":
-        e = _audio_pair(_perturb(tr.Data2VecAudioModel(tr.Data2VecAudioConfig(num_hidden_layers=4, mask_time_prob=0.0, **eager)), 4), dev, kind)
+        e = _audio_pair(_perturb(tr.Data2VecAudioModel(tr.Data2VecAudioConfig(mask_time_prob=0.0, **eager)), 4), dev, kind,
+                        may_escalate_to=("mean_conv3", "mean_a2", "a2_conv3"))
     elif kind == "bert":
         e = _text_pair(_perturb(tr.BertModel(tr.BertConfig(num_hidden_layers=4, vocab_size=2000, **eager), add_pooling_layer=False), 5), dev, kind, 2000)
     elif kind == "electra":
@@ -209,16 +220,16 @@ def test_audio_driver_by_name(dev, tmp_path, pretrained_root, level):
     import transformers as tr
     from mertools_amd.extract import audio
     name = "chinese-hubert-base"
-    hf = _perturb(tr.HubertModel(tr.HubertConfig(num_hidden_layers=4, mask_time_prob=0.0, attn_implementation="eager")), 21)
+    hf = _perturb(tr.HubertModel(tr.HubertConfig(mask_time_prob=0.0, attn_implementation="eager")), 21)
     d = str(pretrained_root / "transformers" / name)
     hf.save_pretrained(d)
     fe = tr.Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True, return_attention_mask=False)
     fe.save_pretrained(d)
     rng = np.random.RandomState(3)
     files = []
-    for i, L in enumerate([24000, 30500, 16000]):
+    for i, L in enumerate([24000, 30500, 16000, 24000]):
         p = str(tmp_path / f"clip{i}.wav")
-        _write_wav(p, rng.randn(L) * 0.1)
+        _write_wav(p, rng.randn(L) * 0.1 if i < 3 else np.zeros(L))      # the last clip is digital silence: constant rows go through the accurate twin
         files.append(p)
     save_dir = str(tmp_path / f"{name}-{level[:3]}")
     audio.extract(name, files, save_dir, level, 0)
@@ -232,7 +243,9 @@ def test_audio_driver_by_name(dev, tmp_path, pretrained_root, level):
         ref = feat.mean(0) if level == "UTTERANCE" else feat
         out = np.load(os.path.join(save_dir, f"clip{i}.npy"))
         assert out.shape == ref.shape and out.dtype == np.float32, (out.shape, ref.shape)
-        worst = max(worst, rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0])
+        e = rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0]
+        print(f"audio driver by name [{level}] clip{i} ({len(samples)} samples{', silent' if i == 3 else ''}): {e:.2e}")
+        worst = max(worst, e)
     print(f"audio driver by name [{level}]: worst clip {worst:.2e}")
     assert worst <= TOL
 

@@ -77,6 +77,35 @@ def test_gemm16_three_pass_is_fp32_grade(dev, M, N, K, tile):
     assert_close(c2.cpu(), ref2.float(), 2e-5, "gemm16 w2 vs exact-weights reference")
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 200, 136, 1), (1000, 768, 768, 1), (257, 48, 6144, 2), (2048, 768, 768, 3), (700, 264, 96, 3)])
+def test_gemm16_activation_split_passes6(dev, M, N, K, tile):
+    """passes = 6 (round 5): a_hi*w_hi + a_lo*w_hi — the activation split alone.  Against A (fp32) x f16(W): fp32-grade, with a plain
+    bias, with a per-sequence bias table (how the `mean_a2` preset applies the weight residual), and through the pre-blocked plane."""
+    ops = _ops()
+    a = _rand((M, K), 15)
+    a[:, 3] *= 300.0          # a channel a single 16-bit plane cannot carry next to the others
+    w = _rand((N, K), 16) * 0.05
+    ah, al = ops.split16(a.to(dev), "f16")
+    wh, _ = ops.split16_host(w, "f16")
+    ref = a.double() @ wh.double().T
+    c6, _, _ = ops.gemm16(ah, wh.to(dev), a_lo=al, out32=True, passes=6, dtype="f16", tile=tile)
+    torch.cuda.synchronize()
+    assert_close(c6.cpu(), ref.float(), 2e-5, "gemm16 passes=6 vs fp32 A x f16(W)")
+    c1, _, _ = ops.gemm16(ah, wh.to(dev), out32=True, passes=1, dtype="f16", tile=tile)
+    assert ((c1.cpu().double() - ref).abs().max() / ref.abs().max()) > 5e-5      # one plane of A is visibly worse on this data
+    T = 50
+    tab = _rand(((M + T - 1) // T, N), 17).to(dev)
+    ct, c16, _ = ops.gemm16(ah, wh.to(dev), a_lo=al, bias=tab, bias_seg_rows=T, out32=True, out16=True, passes=6, dtype="f16", tile=tile)
+    torch.cuda.synchronize()
+    reft = ref + tab.cpu().double().repeat_interleave(T, 0)[:M]
+    assert_close(ct.cpu(), reft.float(), 2e-5, "gemm16 passes=6 + bias table")
+    assert_close(c16.float().cpu(), reft.float(), 1e-3, "gemm16 passes=6 16-bit output")
+    if tile == 3 and K % 32 == 0 and N >= 192:
+        cb, _, _ = ops.gemm16(ah, wh.to(dev), a_lo=al, out32=True, passes=6, dtype="f16", tile=tile, w_hi_blk=ops.w_block_pack(wh.to(dev)))
+        torch.cuda.synchronize()
+        assert torch.equal(cb, c6), "pre-blocked plane changes the bits of passes=6"
+
+
 def test_gemm16_implicit_conv1d(dev):
     """Strided Conv1d over channels-last input as a row-mapped GEMM (HuBERT conv layers 1..6)."""
     ops = _ops()

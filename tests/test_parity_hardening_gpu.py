@@ -49,22 +49,35 @@ def test_hubert_noise_clip_among_tones_and_silence(dev, preset):
     B = 64
     wav = _audio_mix(B)
     m = HipHubertModel(sd, cfg, device=dev, **_kw(preset))
-    _, fr, pooled = m.forward_raw(wav.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
+    # the batch arrives as a HOST tensor, as the audio driver's batches do: forward_raw sees the constant rows before the upload and
+    # runs them through the accurate twin (round 5; a device tensor is not inspected: the device-side call below passes the rows)
+    _, fr, pooled = m.forward_raw(wav, frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
     torch.cuda.synchronize()
+    assert "_twin" in m.__dict__, "the constant rows did not reach the accurate twin"
+    _, fr_d, pooled_d = m.forward_raw(wav.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B,
+                                      constant_rows=HipHubertModel.constant_rows_of(wav))
+    assert torch.equal(fr_d, fr) and torch.equal(pooled_d, pooled)
+    # ... and the other rows are untouched by the patching: bit for bit what the un-patched forward gives
+    _, fr_0, pooled_0 = m.forward_raw(wav.to(dev), frames=True, seg_start=[b * 249 for b in range(B)], seg_len=[249] * B)
+    assert torch.equal(fr_0.view(B, 249, 768)[:B // 2 + 1], fr.view(B, 249, 768)[:B // 2 + 1]) and torch.equal(pooled_0[:B // 2 + 1], pooled[:B // 2 + 1])
     fr = fr.cpu().view(B, 249, 768)
     worst = {}
     for b in (0, 1, B - 1):      # the noise clip, a tone, a silent clip: each against its own batch-of-one oracle forward
         hs = R.hubert_hidden_states(sd, vars(cfg), wav[b:b + 1])
         feat = torch.stack(hs)[[-4, -3, -2, -1]].sum(0)[0]
         worst[b] = (rel_err(pooled[b].cpu(), feat.mean(0))[0], rel_err(fr[b], feat)[0])
+        if b == B - 1:
+            worst["silent, un-patched"] = (rel_err(pooled_0[b].cpu(), feat.mean(0))[0], rel_err(fr_0.cpu().view(B, 249, 768)[b], feat)[0])
     print(f"hubert-base noise clip among tones / silence [{m.precision}]: " +
           "  ".join(f"clip{b}: utt={u:.2e} frame={f:.2e}" for b, (u, f) in worst.items()))
     for b, (u, f) in worst.items():
         # Digital silence is the degenerate case: conv0's output is zero, GroupNorm hands every frame the same beta, all 249 frames of
-        # the clip are identical — so are their rounding errors, nothing averages out over frames or attention, and what is left is the
-        # raw one-pass error of a single row (9e-4 UTT / 1.2e-3 FRAME with the per-row `mx` correction too: not a batch effect).
-        tol = 2e-3 if b == B - 1 else TOL
+        # the clip are identical — so are their rounding errors, nothing averages out over frames or attention, and what a one-plane
+        # preset leaves is the raw one-pass error of a single row (9e-4 UTT / 1.1e-3 FRAME: the "un-patched" figures, asserted at 2e-3
+        # as a regression bound).  Constant rows therefore go through the accurate twin: 1e-3 like every other clip.
+        tol = 2e-3 if b == "silent, un-patched" else TOL
         assert u <= tol and f <= tol, (preset, b, u, f)
+    assert worst[B - 1][1] <= 3e-4, worst       # the twin is fp32-grade
 
 
 @pytest.mark.parametrize("preset", PRESETS)

@@ -75,3 +75,38 @@ def test_visual_branches_cover_the_reference_name_list():
         assert callable(getattr(visual, driver))
         from mertools_amd import encoders
         assert hasattr(getattr(encoders, cls), "from_hf")
+
+
+def test_batch_encoder_gives_the_per_sentence_ids(tmp_path):
+    """extract.text.batch_encoder: whatever route it picks (the Rust backend called directly, the Rust twin of a slow tokenizer, or the
+    tokenizer as given) returns exactly [tokenizer(s)['input_ids'] for s in sentences] — the reference's per-row call
+    (extract_text_huggingface.py:216-225) — and falls back to the tokenizer as given when the probe disagrees."""
+    tr = pytest.importorskip("transformers")
+    import numpy as np
+    from mertools_amd.extract import text
+    chars = [chr(c) for c in range(0x4E00, 0x4E00 + 500)] + [c for c in text.PROBE if not (0x4E00 <= ord(c) < 0x4E00 + 500)]
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(dict.fromkeys(chars))
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab), encoding="utf-8")
+    tok = tr.BertTokenizer(str(tmp_path / "vocab.txt"))
+    rng = np.random.RandomState(0)
+    sents = ["".join(vocab[5 + j] for j in rng.randint(0, 500, n)) for n in rng.randint(1, 60, 300)] + ["未知字符 mixed ascii 123", text.PROBE]
+    want = [tok(s)["input_ids"] for s in sents]
+    enc = text.batch_encoder(tok, sents[:256])
+    assert enc(sents) == want and enc([]) == []
+
+    class Odd:      # a tokenizer whose batch backend disagrees with its per-sentence call: the probe must reject the shortcut
+        is_fast = True
+        name_or_path = ""
+
+        class backend_tokenizer:
+            @staticmethod
+            def encode_batch(sents, add_special_tokens=True):
+                class E:
+                    ids = [0]
+                return [E() for _ in sents]
+
+        def __call__(self, s):
+            if isinstance(s, str):
+                return {"input_ids": tok(s)["input_ids"]}
+            return {"input_ids": [tok(x)["input_ids"] for x in s]}
+    assert text.batch_encoder(Odd(), sents[:8])(sents[:20]) == want[:20]
