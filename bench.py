@@ -68,10 +68,11 @@ def parse():
     ap.add_argument("--config", default="base", choices=sorted(CONFIGS), help="base = BASELINE configs[3] (the headline metric); large = configs[4]")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="16-bit MFMA operand type; bf16 has no MX kernel: use --precision accurate (3 passes) for parity")
     ap.add_argument("--modalities", default="avt", help="subset of a,v,t (default all three = the headline metric)")
-    ap.add_argument("--precision", default="mean", choices=["fast", "balanced", "mx", "mean", "accurate"],
+    ap.add_argument("--precision", default="mean", choices=["fast", "balanced", "mx", "mean", "mean_a2", "mean_conv3", "accurate"],
                     help="GEMM passes: fast=1 (fp16), balanced=2 (weights hi+lo f16 planes), mx=1 + MX-fp4 correction of the weight "
                          "residual, mean (default)=1 + the weight residual applied through each sequence's mean activation (a per-clip correction row: "
-                         "mer_seq_bias; same parity as balanced / mx), accurate=3 + fp32 attention")
+                         "mer_seq_bias; same parity as balanced / mx), mean_a2 = mean with hi + lo ACTIVATION planes in the blocks (2 passes + the table), "
+                         "mean_conv3 = mean with the HuBERT conv stack on three passes (the rungs the load-time self-check tries before accurate), accurate=3 + fp32 attention")
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream per modality (default); 0: single stream")
     ap.add_argument("--split", type=int, default=1, help="run each modality's batch as this many sub-batches on their own HIP streams "
                                                            "(kernels of one sub-batch fill the partial last wave of workgroups of the other)")
@@ -334,6 +335,8 @@ def measure(args, config, steps, warmup, dev, dist, rank, world, sustain_s=0.0, 
     mods = set(args.modalities)
     cfgset = CONFIGS[config]
     models, inputs = build_models(cfgset, mods, B, dev, args.precision, args.dtype, rank)
+    # what each encoder object actually runs (a load-time self-check may have moved it up the precision ladder: ADVICE r4)
+    running = {m: {"precision": getattr(models[m], "precision", args.precision), "escalated": getattr(models[m], "escalated", None)} for m in models}
     frames_per_clip = [8] * B
     lengths = [64] * B
 
@@ -455,6 +458,7 @@ def measure(args, config, steps, warmup, dev, dist, rank, world, sustain_s=0.0, 
 
     gflop_clip = sum(GFLOP_PER_CLIP[cfgset[m][2]] for m in mods)
     res["gflop_per_clip"] = gflop_clip
+    res["running"] = running
     res["whole_step_tflops"] = gflop_clip * B * world * steps / dt / 1e3
     if rank == 0 and want_parity:
         res["parity"], res["oracle_secs"] = parity_check(feats, inputs, mods, config, nclip=2 if config == "base" else 1)
@@ -774,7 +778,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfgset["workload"],
                        "clips_per_gpu_per_step": B, "modalities": "".join(sorted(mods)), "precision": args.precision,
-                       "weights": "random-init (seed 0), HF architectures", "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": r["sub_batches"], "parallelism": f"clip-sharded x{world}, no data-path collective" + ("; one fused fusion-minibatch all-gather per step (side stream)" if "allgather" in r else ""),
+                       "weights": "random-init (seed 0), HF architectures", "running": r.get("running"), "streams": (3 if args.streams else 1) * max(1, args.split), "sub_batches": r["sub_batches"], "parallelism": f"clip-sharded x{world}, no data-path collective" + ("; one fused fusion-minibatch all-gather per step (side stream)" if "allgather" in r else ""),
                        "gflop_per_clip": r["gflop_per_clip"]},
             "roofline": r.get("roofline"),
             "parity": parity,

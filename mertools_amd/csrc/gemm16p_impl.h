@@ -346,7 +346,9 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     stamp(0);
 #pragma clang loop unroll(disable)   // (also keeps hipcc from peeling the first three iterations: three more copies of the loop body)
     for (int kt = 0; kt < nk; ++kt) {
-      // slab kt + 3 of the stream into the stage slab kt - 1 was read from (iteration 0's went out at the tile boundary)
+      // slab kt + 3 of the stream into the stage slab kt - 1 was read from (iteration 0's went out at the tile boundary).  (Issuing
+      // these four DMA pieces BEHIND the twelve fragment reads instead of in front of them was A/B'd in round 5: 1-3 % slower on
+      // every shape, profiles/r05_gemm16p_dma_order_ab.txt.)
       if (kt >= 1) {
         if (kt + 3 < nk) glds_slab(ao, tn, kt + 3, (base + kt + 3) & 3);
         else if (has_next) {

@@ -342,9 +342,10 @@ __host__ __device__ inline int seq_sample_stride(int T) {
 template <typename T>
 __global__ __launch_bounds__(512) void seqmean16_kernel(const T* a, long long lda, int rpb, long long bstride, int M, int K, int seg_rows,
                                                         const int* valid_rows, T* mean16, long long ldm) {
-  // workgroup = (512-column slice, sequence), 8 waves; wave w takes sample rows w, w + 8, w + 16, w + 24 (a sequence has at most 31
-  // samples) and issues its (up to four) row loads back to back before it touches the data: the launch is one memory round trip,
-  // not one per row.  A wave-load = one row x 1 KiB (whole lines).
+  // workgroup = (512-column slice, sequence), 8 waves; wave w takes sample rows w, w + 8, w + 16, w + 24 — a sequence has at most 32
+  // samples (seq_sample_stride leaves 16 .. 31 full strides, plus one when T - s/2 is not a multiple of s: the 8 waves x 4 slots
+  // cover exactly that, mer_seq_bias checks it) — and issues its (up to four) row loads back to back before it touches the data: the
+  // launch is one memory round trip, not one per row.  A wave-load = one row x 1 KiB (whole lines).
   typedef typename T16<T>::v8 v8;
   __shared__ long long red[8][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -477,6 +478,11 @@ extern "C" int mer_seq_bias(const void* a, int dtype, long long lda, int a_rows_
   MER_REQUIRE(nseq <= 65535, MER_EUNSUPPORTED, "mer_seq_bias: %d sequences > 65535", nseq);
   dim3 g1((unsigned)cdiv(K, 512), (unsigned)nseq), g2((unsigned)cdiv(N, 16), (unsigned)cdiv(nseq, 64));
   const int samples = (seg_rows + seq_sample_stride(seg_rows) - 1) / seq_sample_stride(seg_rows);
+  {   // the sampled rows of a full sequence must fit seqmean16_kernel's 8 waves x 4 slots
+    const int s_ = seq_sample_stride(seg_rows), h_ = s_ >> 1;
+    const int total = seg_rows > h_ ? (seg_rows - h_ + s_ - 1) / s_ : 0;
+    MER_REQUIRE(total <= 32, MER_EUNSUPPORTED, "mer_seq_bias: %d samples per sequence (seg_rows %d) exceed the kernel's 32 slots", total, seg_rows);
+  }
   ProfScope prof("bias_corr", 2.0 * nseq * (double)(N - n_first) * K, (double)nseq * samples * K * 2 + (double)N * K * 2 + (double)nseq * N * 4, st);
   if (dtype == MER_DT_F16) {
     hipLaunchKernelGGL((seqmean16_kernel<f16>), g1, dim3(512), 0, st, (const f16*)a, lda, a_rows_per_batch, a_batch_stride, M, K, seg_rows, valid_rows, (f16*)scratch, (long long)K);
