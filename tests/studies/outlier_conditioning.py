@@ -54,6 +54,34 @@ def main():
                   f"(= {float(dy.max() / y.abs().max()):.1e} of max|hs1|); elsewhere (|y| < 5) {float(dy[:, y.abs().amax(0) < 5].max()):.2e}")
 
 
+def frame_sensitivity(sd, cfg, wav, trials=2, seed=2):
+    """Per clip: how far the FRAME feature (sum of the last four hidden states, relative to its batch maximum) moves, in fp64 and with
+    no kernel involved, when hs[0] is perturbed by noise of the size of the `accurate` front end's error (3e-6 of the large channels,
+    1e-5 absolute elsewhere) — the network's own conditioning, which any arithmetic's rounding is multiplied by.  Max over `trials`
+    noise draws.  Used by tests/test_encoders_gpu.py::test_activation_outliers_post_ln to bound the HIP path's error per clip."""
+    hs_all = R.hubert_hidden_states(sd, vars(cfg), wav)
+    hs0 = hs_all[0]
+    B, T, D = hs0.shape
+    x = hs0.reshape(B * T, D).double()
+    g = torch.Generator().manual_seed(seed)
+
+    def run(x0):
+        hs, h = [], x0
+        for l in range(cfg.num_hidden_layers):
+            h = block(sd, cfg, h, B, T, l)
+            hs.append(h)
+        return torch.stack(hs[-4:]).sum(0).view(B, T, D)
+    ref = run(x)
+    sens = [0.0] * B
+    for _ in range(trials):
+        noise = torch.randn(x.shape, generator=g, dtype=torch.float64)
+        dx = torch.where(x.abs() > 5, x.abs() * 3e-6, torch.full_like(x, 1e-5)) * noise
+        got = run(x + dx)
+        for b in range(B):
+            sens[b] = max(sens[b], float((got[b] - ref[b]).abs().max() / ref.abs().max()))
+    return sens
+
+
 def deep():
     """The same question through all 12 blocks, on the batch of test_activation_outliers_post_ln: fp64 from the oracle's hs[0] and from
     hs[0] + noise of the size of the accurate front end's error -> the FRAME feature (sum of the last four hidden states), per clip."""

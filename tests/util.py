@@ -9,6 +9,16 @@ def rel_err(out, ref):
     return d / max(ref.abs().max().item(), 1e-30), ((out - ref).norm() / max(ref.norm().item(), 1e-30)).item()
 
 
+def dim_rel(out, ref):
+    """Norm-free companion of rel_err for a [rows, D] feature matrix: the WORST feature dimension's RMS error over the rows relative to
+    that dimension's own RMS — max-norm figures are blind to the small-magnitude dimensions of a feature vector (VERDICT r4 weak #1 iii)."""
+    out = out.detach().double().cpu().reshape(-1, out.shape[-1])
+    ref = ref.detach().double().cpu().reshape(-1, ref.shape[-1])
+    err = (out - ref).pow(2).mean(0).sqrt()
+    mag = ref.pow(2).mean(0).sqrt()
+    return float((err / mag.clamp_min(1e-30)).max())
+
+
 def assert_close(out, ref, tol, what=""):
     assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(out).all(), f"{what}: non-finite values in output"
