@@ -16,8 +16,12 @@ from util import assert_close
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 X3 = 4e-4
-L2_TOL = 5e-4      # RMS error / RMS feature (norm-free; the bench line's parity_detail.rms_rel): measured 2.5-3.1e-4 UTT
-DIM_TOL = 5e-3     # the worst feature dimension's RMS error over ITS OWN RMS (provisional until measured: util.dim_rel)
+L2_TOL = 5e-4      # RMS error / RMS feature (norm-free; the bench line's parity_detail.rms_rel): measured, default preset, UTT / FRAME:
+                   # HuBERT-base 2.7e-4 / 3.8e-4, CLIP-B/16 2.5e-4 / 4.4e-4, RoBERTa-base 2.3e-4 / 3.8e-4
+DIM_TOL = 2e-2     # the WORST single feature dimension's RMS error over ITS OWN RMS across the frames (util.dim_rel; what a max-norm figure
+                   # cannot see: the small-magnitude dimensions).  Measured, default preset: HuBERT-base 1.1e-2, RoBERTa-base 5.4e-3,
+                   # CLIP-B/16 3.3e-3 (`accurate`: 1.4e-4 / 4.6e-5): a dimension whose RMS is 1 % of the vector's maximum carries the
+                   # same absolute error as the others.  A regression guard at ~2x the measurement, not a parity claim.
 
 
 def _hf_like_cfg(cfg):
