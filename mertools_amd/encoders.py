@@ -210,7 +210,10 @@ def _planes(tf_passes):
 # the GPU: if they disagree by more than the parity bar allows, the object becomes the twin (`model.escalated` says why) and a
 # warning is raised.  `self_check=False` (or MER_SELF_CHECK=0) skips it, `self_check=True` always runs the comparison.
 _ONE_PLANE = ("fast", "f16", "mean", "mx", "balanced", "mean_all", "mean_blocks", "mean_conv")
-SELF_CHECK_UTT, SELF_CHECK_FRAME = 1.0e-3, 1.0e-3     # preset vs accurate on the calibration batch = north_star's bar (a healthy checkpoint: 1-5e-4 / 2-8e-4)
+# preset vs accurate on the calibration batch: north_star's bar (1e-3, UTT and FRAME) with a 20 % margin — the calibration batch is two
+# clips, a user's corpus is not: an HF-initialised data2vec-audio module measured 8.8e-4 on it and 1.14e-3 on other audio (round 5).
+# A healthy checkpoint sits at 1-5e-4 / 2-7e-4.
+SELF_CHECK_UTT, SELF_CHECK_FRAME = 0.8e-3, 0.8e-3
 # What is tried, in order, when the preset fails it — each a cheaper arithmetic than `accurate` (three passes + fp32 attention, 0.4x):
 #   mean_conv3   the HuBERT family only: conv stack / projection / positional conv on hi + lo planes (three passes), blocks as "mean" —
 #                a "layer"-norm front end (wav2vec2-large, data2vec-audio, WavLM-large: a LayerNorm behind every conv) carries ~1e-3 at
@@ -630,7 +633,8 @@ class HipHubertModel(_HipModule):
         x = input_values
         if constant_rows is None:
             constant_rows = self.constant_rows_of(x, valid_samples) if (not x.is_cuda and x.dtype == torch.float32) else []
-        rows = [int(r) for r in constant_rows] if self.precision in _ONE_PLANE else []
+        # (every preset whose blocks carry ONE activation plane: the constant row's coherent rounding error is a property of the blocks)
+        rows = [int(r) for r in constant_rows] if (self.precision in _ONE_PLANE or self.precision in ("mean_conv3", "mixed", "balanced3")) else []
         if rows and self._escalation_twin() is None:
             rows = []
         if not x.is_cuda:
