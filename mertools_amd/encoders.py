@@ -35,13 +35,19 @@ precision (see DESIGN.md §numerics for the measured parity of each):
                 at 1/2 f16-pass of extra MFMA work instead of a whole pass.  GEMMs the MX kernel does not cover
                 (< 1024 rows, K % 128 != 0, batched, bf16) run the "balanced" path.
     "balanced"  weights carried as hi+lo fp16 planes, two MFMA passes (a*w_hi + a*w_lo)
-    "accurate"  both operands split, three passes: fp32-grade GEMMs (attention still rounds q/k/v/P to
-                fp16), ~1e-4
+    "accurate"  both operands split, three passes, attention on fp32 q | k | v (mer_attention_f32): fp32-grade, 2-4e-6 on the base
+                encoders, 0.40x the default's throughput
     "mean_a2"   "mean" with every GEMM input of the transformer blocks carried as hi + lo 16-bit planes: a_hi*w_hi + a_lo*w_hi (two
-                MFMA passes) + the per-sequence table for the weight residual, f16 attention.  What the load-time self-check tries
-                first when a checkpoint's activations do not fit one 16-bit plane (outlier channels riding a post-LN residual
-                stream); "accurate" is the last resort.
+                MFMA passes, mer_gemm16 passes = 6) + the per-sequence table for the weight residual, f16 attention: FRAME error a
+                third of "mean"'s on the base trio (1.9e-4 / 2.6e-4 / 2.0e-4), 0.61x its throughput
+    "mean_conv3"  HuBERT family: "mean" with the conv stack / projection / positional conv on hi + lo planes (three passes) — for a
+                "layer"-norm front end (a LayerNorm behind every conv: wav2vec2-large, data2vec-audio, WavLM-large), whose single
+                activation planes put ~1e-3 on hidden_states[0]
+    "a2_conv3"  both of the above
+                The load-time self-check (below) climbs mean -> mean_conv3 -> mean_a2 -> a2_conv3 -> accurate by itself.
     "mixed" / "balanced3"  HuBERT only: conv stack 3-pass with 1- / 2-pass transformer blocks
+    "mean_a2f", "a2_conv2", "a2f_conv3", "x3_conv4", "mean_blocks", "mean_conv"  study presets (where an error enters:
+                tests/test_encoders_gpu.py::test_activation_outliers_post_ln prints them); "...f" = fp32 attention under passes = 6
 """
 import ctypes as C
 import functools
