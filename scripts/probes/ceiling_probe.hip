@@ -259,7 +259,13 @@ __global__ __launch_bounds__(NW * 64) void ring_kernel(const RingParams p) {
 //                 of odd ones
 // BLK: 0 = row-major operands, 1 = W pre-blocked [n-tile][stage-slab][1-KiB piece] (each DMA piece is 1 KiB contiguous; what an
 //      offline weight packer can produce), 2 = A and W pre-blocked (upper bound: needs the activation producers to write blocked planes)
-template <bool BK64, bool DO_MATH, int BLK = 0, bool SADDR = false>
+// HALF (round 5): the guide's finer phase grain on this LDS organisation — every 32-deep k-step is TWO barrier phases of 16 MFMAs (one
+//      64 x 64 quadrant of the wave's 128 x 64 tile each: m-tiles 0-3, then 4-7), the first reading 4 A + 4 W fragments, the second 4 A
+//      fragments into the same registers (12 reads per k-step, as before; 32 fragment registers instead of 48), the slab's A pieces
+//      issued in the first half and its W pieces in the second, vmcnt waited once per k-step: the per-phase shape of
+//      cdna_hip_programming.md §5 "8 phases per iteration" (2 barriers per 16 MFMAs, two wave groups one barrier apart) on four
+//      32-KB stages of 64-byte rows.  BK64 = false only.
+template <bool BK64, bool DO_MATH, int BLK = 0, bool SADDR = false, int HALF = 0>
 __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
   constexpr int RB = BK64 ? 128 : 64, C = RB / 16, STAGE = 512 * RB, NS = BK64 ? 2 : 4, PLANE = 256 * RB;
   constexpr int PA = PLANE / 1024 / 8, LPS = 2 * PA, RPP = 64 / C;   // pieces per wave per plane, DMAs per wave per stage, rows per piece
@@ -283,8 +289,21 @@ __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
     if (BLK >= 2) a_src[i] = (unsigned)tm * 256u * (unsigned)p.K + (wave + i * 8) * 512 + lane * 8;
     if (BLK >= 1) w_src[i] = (unsigned)tn * 256u * (unsigned)p.K + (wave + i * 8) * 512 + lane * 8;
   }
-  auto issue = [&](int s, int stage) {   // stage-sized slab s (32 or 64 k)
+  auto issue = [&](int s, int stage, int which = 3) {   // stage-sized slab s (32 or 64 k); which: bit 0 = the A pieces, bit 1 = the W pieces
     char* base = smem + stage * STAGE;
+    if (!SADDR && which != 3) {
+      if (which & 1) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(p.a + a_src[i] + s * (BLK >= 2 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + (wave + i * 8) * 1024), 16, 0, 0);
+      }
+      if (which & 2) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(p.w + w_src[i] + s * (BLK >= 1 ? PLANE / 2 : RB / 2)), (lds_void_t*)(base + PLANE + (wave + i * 8) * 1024), 16, 0, 0);
+      }
+      return;
+    }
     if (SADDR) {
       const char* ab = (const char*)(p.a + (long long)s * (BLK >= 2 ? PLANE / 2 : RB / 2));
       const char* wb = (const char*)(p.w + (long long)s * (BLK >= 1 ? PLANE / 2 : RB / 2));
@@ -324,6 +343,42 @@ __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
   };
   const int nk = p.K / 32;
   const bool g1 = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  if (HALF >= 2 && !BK64) {
+    // HALF = 2 / 3 (round 5): the fragment reads are NOT waited for in front of the mid barrier — a load-phase wave arrives at the
+    // barrier as soon as its reads are issued, and waits for them behind it (2: one lgkmcnt(0); 3: the compiler's own per-use waits) —
+    // which needs one more stage of slack for the write-after-read hazard (the other group's reads of slab u - 1 may still be in
+    // flight when this group's DMA goes out): the DMA runs TWO slabs ahead instead of three (slab u + 2 into slab u - 2's stage).
+    issue(0, 0); issue(1, 1);
+    wait_vmcnt<LPS>();
+    __builtin_amdgcn_s_barrier();
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int u = 0; u < nk; ++u) {
+      const bool more = u + 2 < nk;
+      if (more) issue(u + 2, (u + 2) & 3);
+      load_frags(smem + (u & 3) * STAGE, 0);
+      if (more) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      if (HALF == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], fw[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
+    float sum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sum2 += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum2 == 12345.678f) p.sink[tid] = sum2;
+    __syncthreads();
+    if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+    return;
+  }
   if (BK64) {
     issue(0, 0);
     wait_vmcnt<0>();
@@ -335,6 +390,51 @@ __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
   __builtin_amdgcn_s_barrier();
   if (g1) __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = 3;
+  if (HALF == 1 && !BK64) {
+    for (int u = 0; u < nk; ++u) {
+      const bool more = u + 3 < nk;
+      const char* base = smem + cur * STAGE;
+      // ---- first half: m-tiles 0-3 x n-tiles 0-3
+      if (more) issue(u + 3, nxt, 1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int row = wm * 128 + mt * 16 + li;
+        fa[mt] = *reinterpret_cast<const f16x8*>(base + row * RB + ((lg ^ swz(row)) << 4));
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int row = wn * 64 + nt * 16 + li;
+        fw[nt] = *reinterpret_cast<const f16x8*>(base + PLANE + row * RB + ((lg ^ swz(row)) << 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], fw[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- second half: m-tiles 4-7 (the W fragments stay)
+      if (more) issue(u + 3, nxt, 2);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int row = wm * 128 + (4 + mt) * 16 + li;
+        fa[mt] = *reinterpret_cast<const f16x8*>(base + row * RB + ((lg ^ swz(row)) << 4));
+      }
+      if (more) wait_vmcnt<LPS * 2>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], fw[nt], acc[4 + mt][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      cur = (cur + 1) & 3; nxt = (nxt + 1) & 3;
+    }
+  } else
   for (int u = 0; u < nk; ++u) {
     if (BK64) {
       const int pr = u >> 1, h = u & 1;
@@ -549,11 +649,11 @@ static void run_ring(const char* name, const f16* a, const f16* w, int M, int N,
   fflush(stdout);
 }
 
-template <bool BK64, bool DO_MATH, int BLK = 0, bool SADDR = false>
+template <bool BK64, bool DO_MATH, int BLK = 0, bool SADDR = false, int HALF = 0>
 static void run_phase(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
   RingParams p{a, w, M, N, K, M / 256, N / 256, d_st, sink};
   const int nblk = p.tiles_m * p.tiles_n;
-  float us = time_launches([&] { hipLaunchKernelGGL((phase_kernel<BK64, DO_MATH, BLK, SADDR>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
+  float us = time_launches([&] { hipLaunchKernelGGL((phase_kernel<BK64, DO_MATH, BLK, SADDR, HALF>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
   std::vector<unsigned long long> st(2 * nblk);
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
   const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
@@ -593,6 +693,15 @@ static void run_store(char* c, int M, int N, unsigned long long* d_st, int warm,
   fflush(stdout);
 }
 
+// pseudo-random f16 operands (round 5): zero-filled planes toggle no bits and the chip then clocks 15-25 % higher than on real data
+__global__ void fill_rand16(f16* p, size_t n, float scale, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = (f16)(((int)(h & 0xffff) - 32768) * (scale / 32768.0f));
+  }
+}
+
 int main(int argc, char** argv) {
   const int warm = argc > 1 ? atoi(argv[1]) : 20, reps = argc > 2 ? atoi(argv[2]) : 40;
   const int M = 100864;          // CLIP-ViT-B/16 at 64 clips x 8 frames x 197 tokens (bench.py's visual leg)
@@ -611,6 +720,22 @@ int main(int argc, char** argv) {
   run_phase<BK64, MATH, BLK>(NAME, a, w, M, 768, 3072, st, sink, warm, reps);
   const char* set = argc > 3 ? argv[3] : "all";
   const bool all = !strcmp(set, "all");
+  if (!strcmp(set, "phase8")) {
+    // round 5: gemm16's loop (32 MFMAs per barrier phase) against the guide's phase grain (16 per phase) on the same LDS organisation,
+    // W pre-blocked, PSEUDO-RANDOM operands (realistic power), interleaved twice; CLIP's shapes and a 4096-row plane with K = 4096
+    hipLaunchKernelGGL(fill_rand16, dim3(4096), dim3(256), 0, 0, a, (size_t)M * KMAX, 2.0f, 1u);
+    hipLaunchKernelGGL(fill_rand16, dim3(4096), dim3(256), 0, 0, w, (size_t)NMAX * KMAX, 0.05f, 2u);
+    CK(hipDeviceSynchronize());
+    for (int round = 0; round < 2; ++round) {
+#define P8(MM, NN, KK) \
+      run_phase<false, true, 1, false, 0>("two-group loop, 32 MFMAs per phase (gemm16 now), random operands", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_phase<false, true, 1, false, 1>("two-group loop, 16 MFMAs per phase (the guide's 8-phase grain), random operands", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_phase<false, true, 1, false, 2>("32 per phase, fragment reads waited BEHIND the mid barrier (lgkmcnt(0)), DMA two slabs ahead", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_phase<false, true, 1, false, 3>("32 per phase, fragment reads waited behind the mid barrier by the compiler's per-use waits, DMA two slabs ahead", a, w, MM, NN, KK, st, sink, warm, reps);
+      P8(M, 2304, 768) P8(M, 3072, 768) P8(M, 768, 3072) P8(4096, 3072, 3072) P8(8192, 3072, 3072)
+    }
+    return 0;
+  }
   // --- the K loop's data path; shapes: CLIP QKV (N=2304, K=768), fc2 (N=768, K=3072)
 #define RING_SET(NW, NS, MODE, NAME) RING_SET_MF(NW, NS, MODE, 16, NAME)
 #define RING_SET_MF(NW, NS, MODE, MF, NAME) RING_SET_L(NW, NS, MODE, MF, 0, NAME)
