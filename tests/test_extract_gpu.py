@@ -13,15 +13,18 @@ from util import rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-# The drivers are exercised on TINY random-weight models (hidden 128-ish): structure, file layout, batching, raggedness.  The one-plane
-# presets' per-FRAME maximum sits right at 1e-3 there (a max over few, noisy entries: 0.9 .. 1.05e-3 from one rounding realisation to the
-# next); the 1e-3 bar on real-size models — utterance AND frame level — is asserted below through the same drivers
-# (test_*_extract_files_base_size, default preset) and, per preset, in test_encoders_gpu.py / test_parity_hardening_gpu.py.
+# The drivers are exercised on TINY random-weight models (hidden 128-ish): structure, file layout, batching, raggedness — at 1e-3, utterance
+# and frame level (only the tiny HuBERT's per-FRAME maximum sits at 1.1e-3 under the one-plane presets: _tol); the bar on real-size models
+# is asserted below through the same drivers (test_*_extract_files_base_size, default preset) and, per preset, in test_encoders_gpu.py /
+# test_parity_hardening_gpu.py.
 PRESETS = ["accurate", "mean", "mx"]   # "mean" = the drivers' default preset
 
 
-def _tol(precision, level):
-    return TOL if (precision == "accurate" or level == "UTTERANCE") else 1.5e-3
+def _tol(precision, level, tiny_audio=False):
+    """1e-3 everywhere but the per-FRAME maximum of the TINY HuBERT (hidden 128, 2 blocks right behind the conv stack) under a one-plane
+    preset: measured 1.10 - 1.14e-3 (profiles/r05_parity_lines.txt), held to 1.3e-3 here and to 1e-3 on the real-size model below.
+    The tiny CLIP / BERT drivers measure 3.6 - 5.5e-4 at FRAME level and are held to the bar (round 5: was 1.5e-3 for all three)."""
+    return 1.3e-3 if (tiny_audio and precision != "accurate" and level == "FRAME") else TOL
 
 
 def _write_wav(path, x):
@@ -64,7 +67,7 @@ def test_audio_extract_files(dev, tmp_path, level, precision):
             assert out.shape == ref.shape and out.dtype == np.float32, (out.shape, ref.shape)
             e = rel_err(torch.from_numpy(out), torch.from_numpy(ref))[0]
             worst = max(worst, e)
-            assert e < _tol(precision, level), (i, e)
+            assert e < _tol(precision, level, tiny_audio=True), (i, e)
         print(f"audio driver [{precision}, {level}]: worst clip {worst:.2e}")
     finally:
         audio.split_into_batch.__defaults__ = old
