@@ -117,6 +117,7 @@ _PROTOS = {
     "mer_target_arch": (C.c_char_p, []),
     "mer_abi_sizeof": (c_int, [C.c_char_p]),
     "mer_set_option": (c_int, [C.c_char_p, c_int]),
+    "mer_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),
     "mer_set_debug_buffer": (c_int, [c_void_p]),
     "mer_prof_enable": (c_int, [c_int]),
     "mer_prof_report": (c_int, [C.c_char_p, c_int]),
@@ -244,6 +245,13 @@ def lib():
                 raise MerError(f"MER_OPTIONS: unknown option {k!r}")
         _lib = h
     return _lib
+
+
+def get_option(name):
+    """Current value of a mer_set_option switch (include/mer_hip.h: mer_get_option)."""
+    v = c_int(0)
+    check(lib().mer_get_option(name.encode() if isinstance(name, str) else name, C.byref(v)), "mer_get_option")
+    return v.value
 
 
 def check(rc, what=""):

@@ -63,6 +63,83 @@ __device__ __forceinline__ void gstore16_s(unsigned long long sbase, unsigned vo
   else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 
+// ---- the lean 16-bit epilogue (round 6).  A wave's epilogue is bound by its OWN instruction issue: ~4.75 cycles per instruction whatever
+// the other wave of the SIMD does (profiles/r06_gemm16q_timeline.txt: 3.7 k cycles for the 16 rows of a plain 16-bit tile = ~45
+// instructions per row and store; 7.5 k with quick_gelu), not by VALU throughput or the store path.  So the fast path below spends
+// instructions, not cycles: rows go in PAIRS — acc[mt][nt] holds rows r .. r + 3 of one column in adjacent registers, so rows (r, r + 1)
+// of a column are a packed-fp32 operand as they sit (v_pk_add / v_pk_mul / v_pk_fma: each half the IEEE result of the scalar instruction,
+// hence the same bits) — and every wave-uniform decision (interior tile, bias vector or table, debug skips) is taken once per tile.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// both halves of a pair through exactly act_apply's arithmetic: the same operations, in the same order, per element
+template <int ACT>
+__device__ __forceinline__ f32x2v act_pair(f32x2v x) {
+  if constexpr (ACT == MER_ACT_NONE) {
+    return x;
+  } else if constexpr (ACT == MER_ACT_QUICK_GELU) {   // x * rcp(1 + __expf(-1.702 x)), __expf(t) = v_exp_f32(t * 0x3fb8aa3b)
+    const float l2e = __builtin_bit_cast(float, 0x3fb8aa3bu);
+    const f32x2v u = (x * f32x2v{-1.702f, -1.702f}) * f32x2v{l2e, l2e};
+    const f32x2v d = f32x2v{1.0f, 1.0f} + f32x2v{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+    return x * f32x2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  } else if constexpr (ACT == MER_ACT_GELU) {         // gelu_exp2poly: the polynomial as six packed FMAs
+    const f32x2v a = {fminf(fabsf(x[0]), 5.5f), fminf(fabsf(x[1]), 5.5f)};
+    f32x2v q = {3.589585917e-05f, 3.589585917e-05f};
+    q = __builtin_elementwise_fma(q, a, f32x2v{-7.945234977e-04f, -7.945234977e-04f});
+    q = __builtin_elementwise_fma(q, a, f32x2v{8.167289912e-03f, 8.167289912e-03f});
+    q = __builtin_elementwise_fma(q, a, f32x2v{-5.355345435e-02f, -5.355345435e-02f});
+    q = __builtin_elementwise_fma(q, a, f32x2v{-4.586574375e-01f, -4.586574375e-01f});
+    q = __builtin_elementwise_fma(q, a, f32x2v{-1.151242835e+00f, -1.151242835e+00f});
+    q = __builtin_elementwise_fma(q, a, f32x2v{-9.999880846e-01f, -9.999880846e-01f});
+    return f32x2v{fmaf(-fabsf(x[0]), __builtin_amdgcn_exp2f(q[0]), fmaxf(x[0], 0.f)), fmaf(-fabsf(x[1]), __builtin_amdgcn_exp2f(q[1]), fmaxf(x[1], 0.f))};
+  } else {
+    return f32x2v{act_apply(x[0], ACT), act_apply(x[1], ACT)};
+  }
+}
+
+// one row block (16 rows of the wave tile: 4 rows per lane, as two row pairs) of an INTERIOR tile's 16-bit epilogue.  TABLE: per-sequence
+// bias rows from the LDS slot (bl + slot row * 1024; bq / brem as in the generic epilogue), else the bias vector as pairs {b, b} in bp.
+template <typename T, int ACT, int TM, bool TABLE>
+__device__ __forceinline__ void epi0_block(const f32x4 (&acc)[TM][8], int mt, const f32x2v (&bp)[8], const char* bl, int& bq, int& brem, int bias_T,
+                                           unsigned long long cb, unsigned& vo, unsigned rstep) {
+  typedef typename T16<T>::v8 v8;
+#pragma unroll
+  for (int rp = 0; rp < 2; ++rp) {
+    f32x2v x[8];
+    if constexpr (TABLE) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(bl + bq * 1024), a1 = *reinterpret_cast<const f32x4*>(bl + bq * 1024 + 16);
+      brem += 1;
+      if (brem >= bias_T) { brem -= bias_T; ++bq; }
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(bl + bq * 1024), c1 = *reinterpret_cast<const f32x4*>(bl + bq * 1024 + 16);
+      brem += rp ? 13 : 1;
+      if (brem >= bias_T) { brem -= bias_T; ++bq; }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        x[nt] = f32x2v{acc[mt][nt][2 * rp] + a0[nt], acc[mt][nt][2 * rp + 1] + c0[nt]};
+        x[4 + nt] = f32x2v{acc[mt][4 + nt][2 * rp] + a1[nt], acc[mt][4 + nt][2 * rp + 1] + c1[nt]};
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) x[nt] = f32x2v{acc[mt][nt][2 * rp], acc[mt][nt][2 * rp + 1]} + bp[nt];
+    }
+    v8 h0, h1;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const f32x2v y = act_pair<ACT>(x[nt]);
+      // the fp32 values are pinned: hipcc otherwise fuses an activation's last FMA with the conversion (v_fma_mixlo_f16: ONE rounding to
+      // 16 bits where every other epilogue rounds to fp32 first) — 198 of 12.6 M GELU outputs then differ from the tile kernel's
+      float y0 = y[0], y1 = y[1];
+      asm volatile("" : "+v"(y0), "+v"(y1));
+      h0[nt] = T16<T>::from_f32(y0);
+      h1[nt] = T16<T>::from_f32(y1);
+    }
+    gstore16_s<0, true>(cb, vo, __builtin_bit_cast(u32x4, h0));
+    vo += rstep;
+    gstore16_s<0, true>(cb, vo, __builtin_bit_cast(u32x4, h1));
+    vo += rstep;
+  }
+  vo += 12 * rstep;
+}
+
 // plane row (within its 128-row block) that block row r = 16 nt + li must hold so that lane li's accumulators nt = 0 .. 7 are
 //   layout 0 (A): columns 8 li + nt;   layout 1 (B): columns 64 (nt >> 2) + 4 li + (nt & 3)
 __host__ __device__ inline int p_perm_row(int r, int layout) {
@@ -202,6 +279,19 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
       asm volatile("s_nop 4" :: "s"(cb));   // v_readfirstlane -> SGPR -> VMEM address: 5 wait states
       const unsigned rstep = (unsigned)p.ldc16 * 2;
       unsigned vo = opaque((unsigned)(4 * lg) * rstep + li * 16);
+      if (interior && st) {   // the lean path (epi0_block): every store of the tile is issued
+        f32x2v bp[8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { bp[nt] = f32x2v{b0[nt], b0[nt]}; bp[4 + nt] = f32x2v{b1[nt], b1[nt]}; }
+        if (p.bias_T > 0) {
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) epi0_block<T, ACT, TM, true>(acc, mt, bp, bl, bq, brem, p.bias_T, cb, vo, rstep);
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < TM; ++mt) epi0_block<T, ACT, TM, false>(acc, mt, bp, bl, bq, brem, p.bias_T, cb, vo, rstep);
+        }
+        return 4 * TM;
+      }
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
