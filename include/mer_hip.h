@@ -54,8 +54,8 @@ int mer_abi_sizeof(const char* name);
  * (timing decomposition); "gemm_stamp" 1 = s_memtime-instrumented kernels writing into mer_set_debug_buffer's buffer. */
 int mer_set_option(const char* name, int value);
 /* Current value of a mer_set_option switch (so that a caller that flips one can put back what it found, e.g. a user's
- * MER_OPTIONS=gemm_persist=0 kill-switch); MER_EINVAL for an unknown name.  "gemm_persist": 0 = tile kernels only, 1 = gemm16p_kernel,
- * 2 = gemm16q_kernel (lagged wave groups) where instantiated; "gemm_q_cfg": its schedule; "gemm_tm": 3 / 4 = forced tile rows / 64. */
+ * MER_OPTIONS=gemm_persist=0 kill-switch); MER_EINVAL for an unknown name.  "gemm_persist": 0 = tile kernels only, 1 = the persistent
+ * kernel where it applies (default); "gemm_tm": 3 / 4 = forced tile rows / 64 of the persistent kernel. */
 int mer_get_option(const char* name, int* value);
 /* Kernel-phase timing for tuning: when non-NULL, every mer_gemm16 workgroup writes 4 s_memtime stamps (start, first
  * slab ready, K loop done, end) at buffer[4*workgroup ..], per-phase counters at [4*W + 16*workgroup ..] (gemm_stamp builds)

@@ -14,8 +14,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmer_hip.so")
 # the gemm16 kernel family is instantiated in four translation units (tile class x dtype) so that it compiles in parallel;
 # the long ones go first
-SOURCES = ["gemm16q_f16_t4_c0.hip", "gemm16q_f16_t4_c1.hip", "gemm16q_f16_t4_c2.hip", "gemm16q_f16_t3_c0.hip", "gemm16q_f16_t3_c1.hip", "gemm16q_f16_t3_c2.hip", "gemm16q_f16.hip",
-           "gemm16p_f16.hip", "gemm16p_bf16.hip", "gemm16p_f16_r192.hip", "gemm16p_bf16_r192.hip", "gemm16_t3_f16.hip", "gemm16_t3_bf16.hip", "gemm16_small_f16.hip", "gemm16_small_bf16.hip", "attention.hip", "attention_f32.hip",
+SOURCES = ["gemm16p_f16.hip", "gemm16p_bf16.hip", "gemm16p_f16_r192.hip", "gemm16p_bf16_r192.hip", "gemm16_t3_f16.hip", "gemm16_t3_bf16.hip", "gemm16_small_f16.hip", "gemm16_small_bf16.hip", "attention.hip", "attention_f32.hip",
            "common.cpp", "gemm16.hip", "gemm32.hip", "norm.hip", "frontend.hip", "fusion.hip", "encoders.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-x", "hip", "-Rpass-analysis=kernel-resource-usage"]

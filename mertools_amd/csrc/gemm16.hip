@@ -1,6 +1,6 @@
 // gemm16.hip — C ABI of the 16-bit MFMA GEMM (mer_gemm16), its options and the weight packers; the kernel template lives in
 // gemm16_impl.h and is instantiated per (tile class, dtype) in gemm16_t3_*.hip / gemm16_small_*.hip.
-#include "gemm16q_impl.h"
+#include "gemm16p_impl.h"
 
 namespace mer {
 // debug / tuning switches (mer_set_option; process-global and NOT thread-safe: set them before any forward is in flight)
@@ -8,9 +8,7 @@ int g_gemm_skip = 0;          // "gemm_dbg_skip": 1 = skip the epilogue's global
 int g_gemm_stamp = 0;         // "gemm_stamp": the instrumented (s_memtime) build of the 8-wave kernels, with mer_set_debug_buffer
 int g_gemm_glds = 1;          // "gemm_glds": 0 = register-staged loader instead of LDS-DMA (A/B and the K % 32 != 0 fallback's twin)
 int g_gemm_tm = 0;            // "gemm_tm": rows per persistent tile / 64: 0 = chosen per shape (p_pick_tm), 3 or 4 = forced
-int g_gemm_persist = 1;       // "gemm_persist": 0 = never take a persistent kernel (A/B against gemm16_kernel on the same planes), 1 = gemm16p_kernel,
-                              // 2 = gemm16q_kernel (lagged wave groups, gemm16q_impl.h) where it is instantiated (f16), else gemm16p_kernel
-int g_gemm_q_cfg = 0;         // "gemm_q_cfg": gemm16q schedule: 0 = (D 3, S 1), 1 = (D 2, S 1), 2 = (D 2, S 2)
+int g_gemm_persist = 1;       // "gemm_persist": 0 = never take the persistent kernel (A/B against gemm16_kernel on the same planes)
 int g_gemm_generic_epi = 0;   // "gemm_generic_epi": 1 = every launch takes the generic epilogue (the specialised ones must equal it)
 unsigned long long* g_gemm_dbg = nullptr;  // mer_set_debug_buffer(); also stamped by attn_sp_kernel
 
@@ -33,7 +31,6 @@ extern "C" int mer_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_stamp") == 0) { mer::g_gemm_stamp = value; return MER_OK; }
   if (name && strcmp(name, "gemm_persist") == 0) { mer::g_gemm_persist = value; return MER_OK; }
   if (name && strcmp(name, "gemm_tm") == 0) { mer::g_gemm_tm = value; return MER_OK; }
-  if (name && strcmp(name, "gemm_q_cfg") == 0) { mer::g_gemm_q_cfg = value; return MER_OK; }
   if (name && strcmp(name, "gemm_generic_epi") == 0) { mer::g_gemm_generic_epi = value; return MER_OK; }
   mer::set_error("mer_set_option: unknown option '%s'", name ? name : "(null)");
   return MER_EINVAL;
@@ -42,7 +39,7 @@ extern "C" int mer_set_option(const char* name, int value) {
 extern "C" int mer_get_option(const char* name, int* value) {
   const struct { const char* n; const int* v; } opts[] = {
       {"gemm_glds", &mer::g_gemm_glds}, {"gemm_dbg_skip", &mer::g_gemm_skip}, {"gemm_stamp", &mer::g_gemm_stamp}, {"gemm_persist", &mer::g_gemm_persist},
-      {"gemm_tm", &mer::g_gemm_tm}, {"gemm_q_cfg", &mer::g_gemm_q_cfg}, {"gemm_generic_epi", &mer::g_gemm_generic_epi}};
+      {"gemm_tm", &mer::g_gemm_tm}, {"gemm_generic_epi", &mer::g_gemm_generic_epi}};
   if (name && value)
     for (const auto& o : opts)
       if (strcmp(name, o.n) == 0) { *value = *o.v; return MER_OK; }
@@ -287,7 +284,7 @@ extern "C" int mer_gemm16(const mer_gemm16_args* a, mer_stream_t stream) {
       p.w_hi = wp;
       p.w_lo = nullptr;
       p.w_blk = 2;
-      if (a->dtype == MER_DT_F16) return g_gemm_persist == 2 ? dispatch_q<f16>(p, st) : dispatch_p<f16>(p, st);
+      if (a->dtype == MER_DT_F16) return dispatch_p<f16>(p, st);
       return dispatch_p<bf16>(p, st);
     }
   }

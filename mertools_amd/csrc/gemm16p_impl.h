@@ -64,7 +64,7 @@ __device__ __forceinline__ void gstore16_s(unsigned long long sbase, unsigned vo
 }
 
 // ---- the lean 16-bit epilogue (round 6).  A wave's epilogue is bound by its OWN instruction issue: ~4.75 cycles per instruction whatever
-// the other wave of the SIMD does (profiles/r06_gemm16q_timeline.txt: 3.7 k cycles for the 16 rows of a plain 16-bit tile = ~45
+// the other wave of the SIMD does (profiles/r06_gemm16p_before_lean_epilogue_timeline.txt: 3.7 k cycles for the 16 rows of a plain 16-bit tile = ~45
 // instructions per row and store; 7.5 k with quick_gelu), not by VALU throughput or the store path.  So the fast path below spends
 // instructions, not cycles: rows go in PAIRS — acc[mt][nt] holds rows r .. r + 3 of one column in adjacent registers, so rows (r, r + 1)
 // of a column are a packed-fp32 operand as they sit (v_pk_add / v_pk_mul / v_pk_fma: each half the IEEE result of the scalar instruction,

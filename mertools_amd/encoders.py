@@ -27,8 +27,6 @@ precision (see DESIGN.md §numerics for the measured parity of each):
                 loud one's, a mean-token offset is an absolute error they cannot absorb, and the feature projection's LayerNorm then
                 magnifies it (1e-2 on speech-like loud / quiet audio, tests/test_round3_cpu.py).  So HuBERT's conv stack runs the
                 "mx" scheme under this preset — a per-row correction — and the table is used behind LayerNorms only.
-    "mean_all"  (study / test only) "mean" with the mean-token correction in HuBERT's conv stack too: what "mean" was before the
-                quiet-passage case was tested.
     "mx"        One fp16 pass + the weight-rounding residual w - f16(w) as an MX-fp4 plane (e2m1 + E8M0 per 32 k)
                 applied through v_mfma_scale_f32_16x16x128_f8f6f4 against bf8 copies of the activations: removes the
                 weight-rounding error (coherent across tokens, so it survives the utterance mean) like "balanced",
@@ -45,9 +43,10 @@ precision (see DESIGN.md §numerics for the measured parity of each):
                 activation planes put ~1e-3 on hidden_states[0]
     "a2_conv3"  both of the above
                 The load-time self-check (below) climbs mean -> mean_conv3 -> mean_a2 -> a2_conv3 -> accurate by itself.
-    "mixed" / "balanced3"  HuBERT only: conv stack 3-pass with 1- / 2-pass transformer blocks
-    "mean_a2f", "a2_conv2", "a2f_conv3", "x3_conv4", "mean_blocks", "mean_conv"  study presets (where an error enters:
-                tests/test_encoders_gpu.py::test_activation_outliers_post_ln prints them); "...f" = fp32 attention under passes = 6
+These eight names are the public `precision=` surface.  The numerics studies of rounds 3-5 (which operand an error enters through)
+used further pass combinations — "mixed", "balanced3", "mean_all", "mean_blocks", "mean_conv", "mean_a2f", "a2_conv2", "a2f_conv3",
+"x3_conv4" (`_STUDY_PREC`) — that no deployment should pick ("mean_all" is known-unsound on speech); they resolve only under
+MER_STUDY_PRESETS=1, which tests/conftest.py sets for the suite.
 """
 import ctypes as C
 import functools
@@ -191,14 +190,23 @@ def _tf_config(hidden, heads, ffn, layers, pre_ln, act, eps, dtype, passes, mx_s
 
 # precision preset -> (GEMM passes in the HuBERT conv stack, GEMM passes in the transformer blocks)
 # (a third entry: attention on fp32 q | k | v under tf passes == 6)
-_PREC = {"fast": (1, 1), "f16": (1, 1), "mixed": (3, 1), "balanced": (2, 2), "balanced3": (3, 2), "mx": (4, 4), "mean": (4, 5), "mean_a2": (4, 6), "mean_a2f": (4, 6, 1), "a2_conv2": (2, 6), "a2_conv3": (3, 6), "a2f_conv3": (3, 6, 1), "mean_conv3": (3, 5), "x3_conv4": (4, 3),
-         "mean_all": (5, 5), "mean_blocks": (2, 5), "mean_conv": (5, 2),
-         "accurate": (3, 3), "x3": (3, 3)}
+_PREC = {"fast": (1, 1), "balanced": (2, 2), "mx": (4, 4), "mean": (4, 5), "mean_conv3": (3, 5), "mean_a2": (4, 6), "a2_conv3": (3, 6), "accurate": (3, 3)}
+# study presets (tests / numerics studies only, MER_STUDY_PRESETS=1): "mixed" / "balanced3" conv stack three passes with one- / two-pass
+# blocks; "mean_all" the mean-token table in HuBERT's conv stack too (what "mean" was before the quiet-passage case was tested: unsound);
+# "mean_blocks" / "mean_conv" one side two passes; "...f" = fp32 attention under passes = 6; "x3_conv4" MX conv stack under three-pass blocks
+_STUDY_PREC = {"mixed": (3, 1), "balanced3": (3, 2), "mean_all": (5, 5), "mean_blocks": (2, 5), "mean_conv": (5, 2), "mean_a2f": (4, 6, 1),
+               "a2_conv2": (2, 6), "a2f_conv3": (3, 6, 1), "x3_conv4": (4, 3), "f16": (1, 1), "x3": (3, 3)}
 
 
 def _prec(precision):
     """(conv-stack passes, transformer-block passes, fp32 attention under passes == 6) of a preset name."""
-    t = _PREC[precision]
+    t = _PREC.get(precision)
+    if t is None:
+        if precision not in _STUDY_PREC:
+            raise _lib.MerError(f"unknown precision {precision!r}: one of {sorted(_PREC)}")
+        if os.environ.get("MER_STUDY_PRESETS", "0") != "1":
+            raise _lib.MerError(f"precision {precision!r} is a numerics-study preset (set MER_STUDY_PRESETS=1 to resolve it); deployments use one of {sorted(_PREC)}")
+        t = _STUDY_PREC[precision]
     return t[0], t[1], (t[2] if len(t) > 2 else 0)
 
 

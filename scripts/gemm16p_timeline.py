@@ -22,21 +22,15 @@ def main(path):
         d = lambda i, j: np.median((t[:, :, j] - t[:, :, i])[steady])
         rows = [("tile start -> mid kt0", 0, 1)] + [(f"mid kt{k} -> mid kt{k + 1}", 1 + k, 2 + k) for k in range(7)]
         rows += [("mid kt7 -> K loop done", 8, 9), ("K loop done -> boundary slab issued", 9, 10), ("boundary slab -> epilogue done", 10, 11)]
-        if g == 1 and not QMODE:
+        if g == 1:
             rows = rows[:9] + [("mid kt7 -> K loop done", 8, 9), ("in-loop epilogue (13 -> 14)", 13, 14)]
-        if QMODE:   # gemm16q_kernel: slots 11 .. = past the barrier behind epilogue piece 0 ..
-            rows = rows[:10] + [("boundary pieces issued -> piece 0 done", 10, 11)] + [(f"piece {k} done -> piece {k + 1} done", 11 + k, 12 + k) for k in range(QMODE - 1)]
         for name, i, j in rows:
             print(f"   {name:34s} {d(i, j):9.0f}")
         nxt = (np.roll(t[:, :, 0], -1, axis=1) - t[:, :, 0])[steady]
         print(f"   {'tile start -> next tile start':34s} {np.median(nxt):9.0f}   (p10 {np.percentile(nxt, 10):.0f}, p90 {np.percentile(nxt, 90):.0f})")
 
 
-QMODE = 0
 if __name__ == "__main__":
-    if sys.argv[1].startswith("--q="):     # --q=<epilogue pieces>: stamps of gemm16q_kernel
-        QMODE = int(sys.argv[1][4:])
-        del sys.argv[1]
     for p in sys.argv[1:]:
         print(p)
         main(p)

@@ -148,52 +148,36 @@ static void run_shape(const Shape& s, int warm, int reps) {
       MER(mer_set_option("gemm_tm", 0));
     }
   }
-  if (wblkp && s.passes == 1 && !getenv("MER_NO_Q")) {   // the lagged-group kernel (gemm16q_impl.h): bits against the tile kernel, then its three schedules interleaved with gemm16p
-    const size_t obytes = s.out16 ? (size_t)Mp * s.N * 2 : (size_t)s.M * s.N * 4;
+  if (wblkp && s.passes == 1 && getenv("MER_CHECK")) {   // the persistent kernel's bits against the tile kernel's on this shape (rows < M)
+    const size_t obytes = s.out16 ? (size_t)s.M * s.N * 2 : (size_t)s.M * s.N * 4;
     void* outp = s.out16 ? c16 : (void*)c32;
     void* ref = dev_alloc(obytes, 0);
     unsigned long long* nd = (unsigned long long*)dev_alloc(8, 0);
     MER(mer_set_option("gemm_persist", 0));
     MER(mer_gemm16(&g, nullptr));
     CK(hipMemcpy(ref, outp, obytes, hipMemcpyDeviceToDevice));
-    for (int cfg = 0; cfg < 3; ++cfg)
-      for (int rep = 0; rep < 3; ++rep) {
-        CK(hipMemset(outp, 0xff, obytes));
-        CK(hipMemset(nd, 0, 8));
-        MER(mer_set_option("gemm_persist", 2));
-        MER(mer_set_option("gemm_q_cfg", cfg));
-        MER(mer_gemm16(&g, nullptr));
-        hipLaunchKernelGGL(count_diff, dim3(2048), dim3(256), 0, 0, (const unsigned*)ref, (const unsigned*)outp, obytes / 4, nd);
-        unsigned long long h = 0;
-        CK(hipMemcpy(&h, nd, 8, hipMemcpyDeviceToHost));
-        printf("{\"shape\": \"%s\", \"check\": \"gemm16q cfg %d vs tile kernel\", \"rep\": %d, \"differing_words\": %llu}\n", s.name, cfg, rep, h);
-        fflush(stdout);
-      }
-    for (int round = 0; round < 2; ++round) {
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemset(outp, 0xff, obytes));
+      CK(hipMemset(nd, 0, 8));
       MER(mer_set_option("gemm_persist", 1));
-      report("persistent kernel (gemm16p_kernel)", time_gemm(g, warm, reps));
-      MER(mer_set_option("gemm_persist", 2));
-      for (int cfg = 0; cfg < 3; ++cfg) {
-        MER(mer_set_option("gemm_q_cfg", cfg));
-        report(cfg == 0 ? "lagged groups (gemm16q) D3 S1" : (cfg == 1 ? "lagged groups (gemm16q) D2 S1" : "lagged groups (gemm16q) D2 S2"), time_gemm(g, warm, reps));
-      }
+      MER(mer_gemm16(&g, nullptr));
+      hipLaunchKernelGGL(count_diff, dim3(2048), dim3(256), 0, 0, (const unsigned*)ref, (const unsigned*)outp, obytes / 4, nd);
+      unsigned long long h = 0;
+      CK(hipMemcpy(&h, nd, 8, hipMemcpyDeviceToHost));
+      printf("{\"shape\": \"%s\", \"check\": \"persistent vs tile kernel\", \"rep\": %d, \"differing_words\": %llu}\n", s.name, rep, h);
+      fflush(stdout);
     }
-    MER(mer_set_option("gemm_q_cfg", 0));
-    MER(mer_set_option("gemm_persist", 1));
     CK(hipFree(ref)); CK(hipFree(nd));
   }
   if (const char* sd = getenv("MER_STAMP")) if (wblkp && s.passes == 1) {   // s_memtime timeline of the persistent kernel (gemm16p_impl.h: stamp slots)
     const size_t nb = 256 * 384 * 8;
     void* dbg = dev_alloc(nb, 0);
-    MER(mer_set_option("gemm_persist", getenv("MER_STAMP_Q") ? 2 : 1));   // MER_STAMP_Q=<gemm_q_cfg>: the lagged-group kernel's timeline (D = 2 schedules)
-    if (getenv("MER_STAMP_Q")) MER(mer_set_option("gemm_q_cfg", atoi(getenv("MER_STAMP_Q"))));
+    MER(mer_set_option("gemm_persist", 1));
     for (int i = 0; i < 5; ++i) MER(mer_gemm16(&g, nullptr));
     MER(mer_set_debug_buffer(dbg));
     MER(mer_gemm16(&g, nullptr));
     CK(hipDeviceSynchronize());
     MER(mer_set_debug_buffer(nullptr));
-    MER(mer_set_option("gemm_persist", 1));
-    MER(mer_set_option("gemm_q_cfg", 0));
     std::vector<char> host(nb);
     CK(hipMemcpy(host.data(), dbg, nb, hipMemcpyDeviceToHost));
     char fn[512];
