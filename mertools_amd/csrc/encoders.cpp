@@ -495,7 +495,10 @@ extern "C" int mer_hubert_forward_ragged(const mer_hubert* h, const float* wav, 
   // (behind a LayerNorm: rows of one size, so the per-sequence table applies under "mean" as it does in the blocks; the conv stack above
   //  reads un-normalised GELU outputs and keeps its per-row MX correction — DESIGN.md §4)
   const bool fp_tab = (cps == 5 || ((c.tf.passes == 5 || c.tf.passes == 6) && c.feat_proj_layer_norm)) && p.tf.corr.mean16;
-  MER_TRY(gemm(st, dt, fp_tab ? 5 : cps, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, fp_tab ? &pcw : nullptr));
+  // (where the preset carries the projection's input as hi + lo planes — conv stack three passes: mean_conv3 / a2_conv3, or blocks on
+  //  passes == 6 — the table rides on the two-pass activation split, a_hi*w_hi + a_lo*w_hi, not on the hi plane alone: ADVICE r5)
+  const int fp_passes = fp_tab ? ((cps == 3 || c.tf.passes == 6) ? 6 : 5) : cps;
+  MER_TRY(gemm(st, dt, fp_passes, M, D, C, p.fp16, C, w.fp_w, w.fp_b, MER_ACT_NONE, nullptr, 0, p.hproj, D, none, 0, fp_tab ? &pcw : nullptr));
 
   // positional conv: x + GELU(Conv1d(D, D, k, pad k/2, groups G)(x)[..., :-1])   (HF:...:45-103)
   HsMap hs;

@@ -608,6 +608,13 @@ class HipHubertModel(_HipModule):
         """Lets go of the checkpoint reference kept for the constant-clip twin (constant rows then stay on this object's preset)."""
         self._source = None
 
+    def build_constant_twin(self):
+        """Builds the `accurate` twin that constant rows (digital silence, DC clips) are routed through NOW instead of on the first such
+        row: a second set of weight planes (~3x this object's: hi + lo planes of both operands) is reserved at load time, not in the middle
+        of an extraction.  -> True when a twin exists afterwards.  `drop_source()` afterwards releases the checkpoint
+        reference the lazy path keeps alive."""
+        return self._escalation_twin() is not None
+
     def _escalation_twin(self):
         tw = self.__dict__.get("_twin")
         if tw is None and self.__dict__.get("_source") is not None:

@@ -226,6 +226,27 @@ def constant_rows(arr):
     return out
 
 
+def constant_chunks(raw, do_normalize=True, maxlen=MAXLEN):
+    """Chunk rows (split_into_batch) of a clip longer than `maxlen` that will hold ONE value, found on the host's RAW samples: the
+    whole-clip normalisation is affine, so a constant stretch stays constant.  A full chunk is constant iff its raw samples are; the
+    zero-padded last chunk only when its samples normalise to exactly 0 — the whole clip is one value (then every chunk is zero), or
+    un-normalised digital silence.  (the device path used to skip the detection for chunked clips, leaving a silent
+    chunk on the one-plane preset.)"""
+    a = raw.numpy() if torch.is_tensor(raw) else np.asarray(raw)
+    n = len(a)
+    if n <= maxlen:
+        return constant_rows(a)
+    nfull, tail = divmod(n, maxlen)
+    out = [r for r in constant_rows(a[:nfull * maxlen].reshape(nfull, maxlen))]
+    if tail:
+        t = a[nfull * maxlen:]
+        if t[0] == t[len(t) // 2] == t[-1] and t.min() == t.max():
+            whole = a[0] == a[n // 2] == a[-1] and a.min() == a.max()
+            if (do_normalize and whole) or (not do_normalize and t[0] == 0):
+                out.append(nfull)
+    return out
+
+
 def plan_batches(pending, batch_rows, ragged, final, max_stretch=1.5, keep_at_most=0):
     """Cuts the pending clips (dicts with 'rows', 'len') into batches; returns (batches, still_pending).
     ragged: clips are sorted by length and consecutive ones share a batch while the longest is at most `max_stretch` x the
@@ -285,12 +306,12 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
             got = read_pcm16(audio_file)
             if got is not None:
                 assert got[1] == 16000, 'currently, we only test on 16k audio'
-                return audio_file, got[0], constant_rows(got[0]) if len(got[0]) <= MAXLEN else []
+                return audio_file, got[0], constant_chunks(got[0], do_normalize)
         samples, sr = reader(audio_file)
         assert sr == 16000, 'currently, we only test on 16k audio'
         if device_preprocess:   # (a worker thread: numpy releases the GIL) 16-bit PCM when the file holds exactly that, else fp32
             raw = to_pcm16_or_f32(samples)
-            return audio_file, raw, constant_rows(raw) if len(raw) <= MAXLEN else []
+            return audio_file, raw, constant_chunks(raw, do_normalize)
         iv = split_into_batch(wav2vec2_normalize(samples, do_normalize))
         return audio_file, iv, constant_rows(iv)
 
@@ -389,7 +410,7 @@ def extract(model_name, audio_files, save_dir, feature_level, gpu, model=None, d
                     with torch.cuda.device(model.device):
                         from .. import ops
                         ivd = split_into_batch_any(ops.wave_normalize(torch.from_numpy(iv)[None].to(model.device), do_normalize))
-                    pending.append(dict(vid=vid, iv=ivd, rows=ivd.shape[0], len=ivd.shape[1]))
+                    pending.append(dict(vid=vid, iv=ivd, rows=ivd.shape[0], len=ivd.shape[1], const=const))
                 else:
                     pending.append(dict(vid=vid, raw=iv, rows=1, len=len(iv), const=const))
             else:

@@ -162,27 +162,52 @@ def extract_embedding(model_name, trans_dir, save_dir, feature_level, gpu=-1, pu
     print(f'Total {len(df)} files done! Time used ({model_name}): {time.time() - start_time:.1f}s.')
 
 
-def batch_encoder(tokenizer, probe_sentences=()):
+def batch_encoder(tokenizer, probe_sentences=(), allow_twin=None):
     """-> encode(list of sentences) == [tokenizer(s)['input_ids'] for s in sentences] (the reference's per-row call, :216-225), by the
-    cheapest route a PROBE shows to give the same ids on this corpus' first sentences:
-      1. a Rust-backed tokenizer's backend `encode_batch` called directly — transformers' wrapper spends 4x the tokenisation time
-         turning every Encoding into six Python lists of which the driver reads one;
-      2. for a pure-Python ("slow", what use_fast=False gives under transformers 4) tokenizer: the Rust twin AutoTokenizer loads from
-         the same directory, if it reproduces the slow tokenizer's ids on the probe sentences (up to 256) and the probe sentence;
-      3. otherwise the tokenizer as given, one call over the list."""
+    cheapest route that is the SAME tokenizer:
+      1. a Rust-backed tokenizer's own backend `encode_batch` called directly — transformers' wrapper spends 4x the tokenisation time
+         turning every Encoding into six Python lists of which the driver reads one; taken when a probe (the corpus' first sentences,
+         up to 256, + the probe sentence) gives the ids of the reference's call;
+      2. otherwise the tokenizer as given, one call over the list.
+    A pure-Python ("slow": what use_fast=False gives under the reference's transformers 4.28) tokenizer is NOT silently replaced by
+    the Rust twin of its directory: slow and fast tokenizers can part on rare input (control / format characters, unusual unicode,
+    sentencepiece legacy modes) anywhere in a corpus, and index paths are to be bit-exact.  The twin route
+    is opt-in — `allow_twin=True` or MER_TEXT_TWIN=1 — and then guarded three ways: the probe above, the twin's backend reset to
+    no truncation / no padding (its `__call__` never runs), and a spot check of every chunk (8 sentences spread over it, the longest
+    included) against the given tokenizer; the first mismatch switches to the tokenizer as given, for that chunk and for good."""
+    if allow_twin is None:
+        allow_twin = os.environ.get('MER_TEXT_TWIN', '0') == '1'
     probe = [s for s in list(probe_sentences)[:256] if s] + [PROBE]
 
     def as_given(sents):
         return tokenizer(sents)['input_ids'] if sents else []
 
-    def raw_route(tok):
+    def raw_route(tok, reset=False):
         backend = getattr(tok, 'backend_tokenizer', None)
         if backend is None or not getattr(tok, 'is_fast', False):
             return None
+        if reset:
+            backend.no_truncation()
+            backend.no_padding()
 
         def enc(sents):
             return [e.ids for e in backend.encode_batch(sents, add_special_tokens=True)] if sents else []
         return enc
+
+    def guarded(enc):
+        state = {'ok': True}
+
+        def run(sents):
+            if not state['ok'] or not sents:
+                return as_given(sents)
+            ids = enc(sents)
+            n = len(sents)
+            pick = sorted({0, n - 1, max(range(n), key=lambda i: len(sents[i]))} | {(j * n) // 8 for j in range(8)})
+            if any(ids[i] != tokenizer(sents[i])['input_ids'] for i in pick):
+                state['ok'] = False
+                return as_given(sents)
+            return ids
+        return run
 
     want = None
     for cand_name in ('raw', 'twin'):
@@ -190,19 +215,19 @@ def batch_encoder(tokenizer, probe_sentences=()):
             if cand_name == 'raw':
                 enc = raw_route(tokenizer)
             else:
-                if getattr(tokenizer, 'is_fast', False):
+                if not allow_twin or getattr(tokenizer, 'is_fast', False):
                     break
                 path = getattr(tokenizer, 'name_or_path', '')
                 if not (path and os.path.isdir(path)):
                     break
                 from transformers import AutoTokenizer
-                enc = raw_route(AutoTokenizer.from_pretrained(path, use_fast=True))
+                enc = raw_route(AutoTokenizer.from_pretrained(path, use_fast=True), reset=True)
             if enc is None:
                 continue
             if want is None:
                 want = [tokenizer(s)['input_ids'] for s in probe]      # the reference's call, sentence by sentence
             if enc(probe) == want:
-                return enc
+                return enc if cand_name == 'raw' else guarded(enc)
         except Exception:
             continue
     return as_given

@@ -110,3 +110,52 @@ def test_batch_encoder_gives_the_per_sentence_ids(tmp_path):
                 return {"input_ids": tok(s)["input_ids"]}
             return {"input_ids": [tok(x)["input_ids"] for x in s]}
     assert text.batch_encoder(Odd(), sents[:8])(sents[:20]) == want[:20]
+
+
+def test_slow_tokenizer_is_not_replaced_by_its_rust_twin(tmp_path, monkeypatch):
+    """VERDICT r5 #7 / ADVICE r5: a pure-Python tokenizer (what use_fast=False gives under the reference's transformers 4.28) keeps ITS ids.
+    The Rust twin loaded from the same directory is opt-in (allow_twin / MER_TEXT_TWIN=1), and when opted in a sentence on which the two
+    part — here: one the probe (the corpus' first sentences) never sees — is caught by the per-chunk spot check, after which the
+    tokenizer as given is used for good.  (A spot check is a guard, not a proof: that is why the route is opt-in.)"""
+    tr = pytest.importorskip("transformers")
+    from mertools_amd.extract import text
+    chars = [chr(c) for c in range(0x4E00, 0x4E00 + 200)] + [c for c in text.PROBE if not (0x4E00 <= ord(c) < 0x4E00 + 200)]
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(dict.fromkeys(chars))
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab), encoding="utf-8")
+    fast = tr.BertTokenizer(str(tmp_path / "vocab.txt"))
+    fast.save_pretrained(str(tmp_path))
+    calls = {"twin_loaded": 0}
+
+    class Slow:
+        """a 'slow' tokenizer whose ids differ from the Rust twin's on sentences holding U+200B (zero-width space): it keeps the character
+        as [UNK], the twin's normaliser drops it"""
+        is_fast = False
+        name_or_path = str(tmp_path)
+
+        def _one(self, s):
+            ids = fast(s.replace("​", ""))["input_ids"]
+            return ids[:-1] + [1] * s.count("​") + ids[-1:]
+
+        def __call__(self, s):
+            return {"input_ids": self._one(s) if isinstance(s, str) else [self._one(x) for x in s]}
+
+    real_from = tr.AutoTokenizer.from_pretrained
+
+    def counting(*a, **k):
+        calls["twin_loaded"] += 1
+        return real_from(*a, **k)
+    monkeypatch.setattr(tr.AutoTokenizer, "from_pretrained", counting)
+    slow = Slow()
+    plain = ["".join(vocab[5 + (7 * i + j) % 200] for j in range(3 + i % 40)) for i in range(300)]
+    odd = plain[39][:5] + "​" + plain[39][5:]      # (the longest sentence of its chunk: one of the 8 + 3 the spot check looks at)
+    corpus = plain + [odd] + plain[:50]            # the odd sentence sits behind the probe's 256
+    want = [slow(s)["input_ids"] for s in corpus]
+    monkeypatch.delenv("MER_TEXT_TWIN", raising=False)
+    enc = text.batch_encoder(slow, corpus[:256])
+    assert calls["twin_loaded"] == 0 and enc(corpus) == want           # default: the twin is never even loaded
+    enc = text.batch_encoder(slow, corpus[:256], allow_twin=True)
+    assert calls["twin_loaded"] == 1
+    assert enc(plain[:64]) == want[:64]                                # agrees where the tokenizers agree ...
+    got = enc(corpus[256:])                                            # ... and the chunk that holds the odd sentence (its longest) falls back
+    assert got == want[256:]
+    assert enc([odd]) == [slow(odd)["input_ids"]]
