@@ -82,6 +82,37 @@ _WBLK = os.environ.get("MER_WBLK", "1") != "0"   # pre-blocked weight planes (tu
 _WBLKP = os.environ.get("MER_WBLKP", "1") != "0"   # ... and the row-permuted copy for the persistent one-pass kernel
 
 
+# ---- weight planes shared between the builds of ONE load (VERDICT r5 #6c) ----
+# from_hf() / a self-checking constructor builds the object, its `accurate` twin and — when the preset fails the check — up to three
+# rungs in between; each used to split, upload and pre-block every weight again (a worst-case load packed the checkpoint five times).
+# While a load is in progress the device planes are kept in a cache keyed by the weight's content fingerprint + plane kind: a later
+# build of the same load takes what an earlier one made and only adds the planes it alone needs (the twin's `lo` planes, a rung's MX
+# plane).  The cache dies with the load; planes a discarded candidate alone referenced are freed with it.
+_PLANES = None
+
+
+class _plane_cache:
+    def __enter__(self):
+        global _PLANES
+        self.owner = _PLANES is None
+        if self.owner:
+            _PLANES = {}
+        return self
+
+    def __exit__(self, *a):
+        global _PLANES
+        if self.owner:
+            _PLANES = None
+
+
+def _fingerprint(t):
+    """Content key of a host weight tensor: shape, two fp64 moments and 16 samples (two different weights of one shape agree on none)."""
+    f = t.detach().reshape(-1)
+    n = f.numel()
+    idx = (torch.arange(16, dtype=torch.long) * max(n - 1, 0)) // 15
+    return (tuple(t.shape), str(t.dtype), float(f.sum(dtype=torch.float64)), float((f * f).sum(dtype=torch.float64)), tuple(f[idx].tolist()))
+
+
 class _Holder:
     """Owns the device copies of the weights and hands out raw pointers."""
 
@@ -90,20 +121,40 @@ class _Holder:
         self.dtype = dtype
         self.keep = []
 
+    def _plane(self, key, make):
+        """The device tensor of plane `key` — from the load's cache when an earlier build made it — kept alive by this holder."""
+        if _PLANES is not None and key is not None:
+            d = _PLANES.get(key)
+            if d is None:
+                d = make()
+                if d is not None:
+                    _PLANES[key] = d
+        else:
+            d = make()
+        if d is not None:
+            self.keep.append(d)
+        return d
+
     def f32(self, t):
         if t is None:
             return None
-        d = t.detach().to(torch.float32).contiguous().to(self.device)
-        self.keep.append(d)
-        return d.data_ptr()
+        key = ("f32", _fingerprint(t), str(self.device)) if _PLANES is not None else None
+        return self._plane(key, lambda: t.detach().to(torch.float32).contiguous().to(self.device)).data_ptr()
 
     def w16(self, t, lo, mx=False, out="f16"):
         """out: what the GEMM reading this weight writes — "f16" (one 16-bit plane: QKV, fc1, conv stack), "f32" (fp32 (+ residual): attention
         output, fc2, projections) or "both": selects the row permutation of the persistent kernel's pre-blocked plane."""
         t = t.contiguous()
-        hi, lo_t = split16_host(t, self.dtype, lo)
-        hi = hi.contiguous().to(self.device)
-        self.keep.append(hi)
+        base = (_fingerprint(t), self.dtype, str(self.device)) if _PLANES is not None else None
+        key = (lambda kind: (kind,) + base) if base is not None else (lambda kind: None)
+        halves = {}
+
+        def split(which):
+            if not halves:
+                h, l = split16_host(t, self.dtype, lo)
+                halves["hi"], halves["lo"] = h.contiguous(), (l.contiguous() if l is not None else None)
+            return halves[which]
+        hi = self._plane(key("hi"), lambda: split("hi").to(self.device))
         w = W16()
         w.hi = hi.data_ptr()
         w.lo = None
@@ -112,40 +163,38 @@ class _Holder:
         w.lo_blk = None
         w.hi_blkp = None
         w.hi_blkq = None
+        lo_t = None
         if lo:
-            lo_t = lo_t.contiguous().to(self.device)
-            self.keep.append(lo_t)
+            lo_t = self._plane(key("lo"), lambda: split("lo").to(self.device))
             w.lo = lo_t.data_ptr()
         if t.dim() == 2 and t.shape[0] >= 192 and t.shape[1] % 32 == 0 and self.device.type == "cuda" and _WBLK:
             # pre-blocked copies for the 256-wide LDS-DMA kernels (1 KiB contiguous DMA pieces); the row-major planes stay
             # for the small-batch tiles.  Costs a second copy of the weights in HBM (a few hundred MB at most).
             from .ops import w_block_pack, w_block_pack_p
             with torch.cuda.device(self.device):
-                hb = w_block_pack(hi)
-                lb = w_block_pack(lo_t) if lo and hb is not None else None
+                hb = self._plane(key("hb"), lambda: w_block_pack(hi))
+                lb = self._plane(key("lb"), lambda: w_block_pack(lo_t)) if lo and hb is not None else None
                 # the persistent one-pass kernel's planes (rows permuted per 128: layout 0 for 16-bit outputs, 1 for fp32 outputs)
-                hp = w_block_pack_p(hi, 0) if _WBLKP and out in ("f16", "both") else None
-                hq = w_block_pack_p(hi, 1) if _WBLKP and out in ("f32", "both") else None
+                hp = self._plane(key("hp"), lambda: w_block_pack_p(hi, 0)) if _WBLKP and out in ("f16", "both") else None
+                hq = self._plane(key("hq"), lambda: w_block_pack_p(hi, 1)) if _WBLKP and out in ("f32", "both") else None
                 torch.cuda.current_stream().synchronize()   # the forwards may run on other streams
             if hp is not None:
-                self.keep.append(hp)
                 w.hi_blkp = hp.data_ptr()
             if hq is not None:
-                self.keep.append(hq)
                 w.hi_blkq = hq.data_ptr()
             if hb is not None:
-                self.keep.append(hb)
                 w.hi_blk = hb.data_ptr()
                 if lb is not None:
-                    self.keep.append(lb)
                     w.lo_blk = lb.data_ptr()
         if mx and torch16(self.dtype) == torch.float16 and t.dim() == 2:
             # MX-fp4 plane of the rounding residual for the passes=4 GEMM (shapes without one keep using `lo`)
             from .ops import mx_pack
-            packed = mx_pack(t.to(torch.float32) - hi.to("cpu", torch.float32))
+
+            def make_mx():
+                packed = mx_pack(t.to(torch.float32) - hi.to("cpu", torch.float32))
+                return packed.to(self.device) if packed is not None else None
+            packed = self._plane(key("mx"), make_mx)
             if packed is not None:
-                packed = packed.to(self.device)
-                self.keep.append(packed)
                 w.mx = packed.data_ptr()
         return w
 
@@ -262,6 +311,16 @@ def ln_outlier_ratio(sd):
     return worst
 
 
+def _self_check_may_run(state_dict, mode):
+    """Whether a constructor called with self_check=`mode` may go on to build an `accurate` twin (cheap: 1-D tensors only)."""
+    if mode is False or os.environ.get("MER_SELF_CHECK", "1") == "0":
+        return False
+    if mode == "auto":
+        sd = state_dict.state_dict() if hasattr(state_dict, "state_dict") else state_dict
+        return ln_outlier_ratio(sd) >= 8.0
+    return True
+
+
 def _self_check(model, state_dict, config, args, kwargs, mode):
     import inspect
     import warnings
@@ -283,7 +342,11 @@ def _self_check(model, state_dict, config, args, kwargs, mode):
         torch.cuda.synchronize()
 
     def rel(a, b):
-        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+        """max over the calibration clips of max|a - b| / max|b| of THAT clip: the norm the parity bar is stated in is per saved file
+        (a quiet or short clip must not hide behind a loud one's maximum)."""
+        n = ref[0].shape[0]
+        a, b = a.double().reshape(n, -1), b.double().reshape(n, -1)
+        return float(((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)).max())
     du, df = rel(got[0], ref[0]), rel(got[1], ref[1])
     model.self_check_result = dict(ln_outlier_ratio=ratio, utt=du, frame=df, precision=prec)
     if du > SELF_CHECK_UTT or df > SELF_CHECK_FRAME:
@@ -335,6 +398,10 @@ class _HipModule:
                 # (constructors nest — a subclass's __init__ calls its parent's, both wrapped: the OUTERMOST call, whichever class it
                 #  belongs to, runs the self-check once the object is complete; a subclass without an __init__ of its own is covered too)
                 outermost = "_mer_constructing" not in self.__dict__
+                if outermost and _PLANES is None and _self_check_may_run(state_dict, self_check):
+                    # a load that may build a twin and rungs: they share the weight planes this build makes (_plane_cache)
+                    with _plane_cache():
+                        return checked_init(self, state_dict, config, *a, self_check=self_check, **k)
                 self.__dict__["_mer_constructing"] = True
                 try:
                     init(self, state_dict, config, *a, **k)
@@ -564,18 +631,20 @@ class HipHubertModel(_HipModule):
         return cls(hf_model.state_dict(), hf_model.config, **kw)
 
     def _probe_features(self):
-        """(utterance, frame) features of the built-in calibration batch (load-time self-check): 2 s of noise whose loudness ramps over
-        20 dB with a tone under it, and a tone burst — two clips."""
+        """(utterance, frame) features of the built-in calibration batch (load-time self-check), three clips of 2 s: noise whose loudness
+        ramps over 20 dB with a tone under it; a tone burst; and a speech-like clip — 0.3 s passages 40 dB apart, the dynamics that
+        exposed the conv stack's mean-token bias in round 3 and that stationary noise cannot show (VERDICT r5 #6b)."""
         g = torch.Generator().manual_seed(20260926)
         L = 32000
         t = torch.arange(L, dtype=torch.float32) / 16000.0
         ramp = torch.logspace(-1, 0, L)
         a = 0.1 * torch.randn(L, generator=g) * ramp + 0.05 * torch.sin(2 * 3.14159265 * 220.0 * t)
         b = 0.2 * torch.sin(2 * 3.14159265 * 440.0 * t) * (t % 0.5 < 0.25) + 0.01 * torch.randn(L, generator=g)
-        wav = torch.stack([a, b])
+        c = 0.1 * torch.randn(L, generator=g) * torch.where((torch.arange(L) // 4800) % 2 == 0, 1.0, 0.01)
+        wav = torch.stack([a, b, c])
         wav = (wav - wav.mean(1, keepdim=True)) / torch.sqrt(wav.var(1, unbiased=False, keepdim=True) + 1e-7)
         T = self.out_frames(L)
-        _, fr, pooled = self.forward_raw(wav.to(self.device), frames=True, seg_start=[0, T], seg_len=[T, T])
+        _, fr, pooled = self.forward_raw(wav.to(self.device), frames=True, seg_start=[0, T, 2 * T], seg_len=[T, T, T])
         return pooled, fr
 
     def out_frames(self, L):
@@ -815,11 +884,13 @@ class HipCLIPModel(_HipModule):
         return feats, pooled
 
     def _probe_features(self):
-        """(clip, frame) features of the built-in calibration batch (load-time self-check): 4 frames of blocky noise at CLIP's statistics."""
+        """(clip, frame) features of the built-in calibration batch (load-time self-check): 4 frames of blocky noise at CLIP's statistics
+        and a flat frame (one colour: every patch row identical — the visual tower's degenerate input, VERDICT r5 #6b)."""
         g = torch.Generator().manual_seed(20260926)
         S = self._cfg.image_size
         px = torch.rand((4, self._cfg.channels, S // 8, S // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)[:, :, :S, :S]
         px = (px + 0.1 * torch.rand((4, self._cfg.channels, S, S), generator=g) - 0.45) / 0.27
+        px = torch.cat([px, torch.full((1, self._cfg.channels, S, S), (0.6 - 0.45) / 0.27)], 0)
         feats = self.forward_raw(px.contiguous().to(self.device))[0]
         return feats.mean(0, keepdim=True), feats
 
