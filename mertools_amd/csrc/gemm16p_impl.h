@@ -218,16 +218,6 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   };
 
   f32x4 acc[TM][TN];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-    // (an opaque zero: with a literal one hipcc peels the first iteration of every tile to feed the MFMAs an inline constant — more
-    //  copies of the K loop, and in the fp32 + residual kernel a register allocation that spilled the accumulators)
-    float z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{z, z, z, z};
-  };
 
   v8 af[TM], wf[TN];
   // (row >> 2) & 3 == (li >> 2) for every fragment row of this lane: one swizzle term, fragments 1 KiB apart
@@ -246,6 +236,12 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = T16<T>::mfma(af[mt], wf[nt], acc[mt][nt]);
+  };
+  auto math0 = [&]() __attribute__((always_inline)) {   // slab 0 of a tile: C = 0 (0 + x is exact: the bits of a zeroed accumulator)
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = T16<T>::mfma(af[mt], wf[nt], f32x4{0.f, 0.f, 0.f, 0.f});
   };
 
   // ---- epilogue of tile (tm_, tn_), bias row in parity slot `par`; returns the store allowance for the next counted waits:
@@ -396,6 +392,20 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     }
   };
 
+  // ---- the free stagger (fp32 + residual launches).  Persistent workgroups start together and walk equal tiles, so the whole chip reaches
+  // the epilogue at once: 256 CUs then move their 512 KB each (residual in, fp32 out) at the HBM roofline — 6-7 TB/s for ~100 us of a CLIP
+  // attention-output launch — while the K loops in between leave HBM three quarters idle.  Delaying every second workgroup by half a tile
+  // costs the delayed ones half a tile at the end (round 4: +1.5 % / -5 %).  But nblk % grid workgroups walk one tile MORE than the others
+  // (CLIP fc2 / attention output: 158 of 256 do five tiles, 98 do four): the short walkers can start half a tile late for nothing, and
+  // 38 % of the chip then stores while the rest computes.  (gemm_dbg_skip & 8 turns it off, for A/B.)
+  if constexpr (EPI == 2) {
+    const int rem = nblk % (int)gridDim.x;
+    if (rem > 0 && nblk > (int)gridDim.x && (int)blockIdx.x >= rem && (p.dbg_skip & 8) == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime(), d = (unsigned long long)nk * 700ull + 20000ull;
+      while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+
   // ---- tile walk: one continuous slab stream; slab kt of the current tile lives in ring stage (base + kt) & 3 ----
   int L = blockIdx.x;
   int tm, tn;
@@ -407,7 +417,6 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
   for (int s = 0; s < 4; ++s) glds_slab(ao, tn, s, s);
   wait_vmcnt<12>();                 // slab 0 (and the bias row, older) of this wave's share ...
   __builtin_amdgcn_s_barrier();     // ... and of every wave's
-  zero_acc();
   int seq = 0;                      // tiles done by this workgroup: parity of the bias slot
   int base = 0;                     // ring stage of the current tile's slab 0
   int sx = 0;                       // stores of the last epilogue that the next counted waits may leave in flight
@@ -429,13 +438,15 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     const int Ln = L + (int)gridDim.x;
     const bool has_next = Ln < nblk;
     int ntm = 0, ntn = 0;
-    if (has_next) {
-      tile_of(Ln, ntm, ntn);
-      a_offsets(ntm * TROWS, aon);
-    }
     stamp(0);
 #pragma clang loop unroll(disable)   // (also keeps hipcc from peeling the first three iterations: three more copies of the loop body)
     for (int kt = 0; kt < nk; ++kt) {
+      // the next tile's coordinates and A offsets (integer divisions, 64-bit address math) are worked out HERE, in the slack of a LOAD
+      // phase — not between the epilogue and the next tile's first slab, where every cycle is exposed (first needed at kt = nk - 3 >= 5)
+      if (kt == 1 && has_next) {
+        tile_of(Ln, ntm, ntn);
+        a_offsets(ntm * TROWS, aon);
+      }
       // slab kt + 3 of the stream into the stage slab kt - 1 was read from (iteration 0's went out at the tile boundary).  (Issuing
       // these four DMA pieces BEHIND the twelve fragment reads instead of in front of them was A/B'd in round 5: 1-3 % slower on
       // every shape, profiles/r05_gemm16p_dma_order_ab.txt.)
@@ -459,7 +470,8 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
       if (kt < 8) stamp(1 + kt);
       if (kt == nk - 1 && g1 && has_next) glds_slab(aon, ntn, 3, (base + nk + 3) & 3);   // every LDS read of slab nk - 1 is over
       __builtin_amdgcn_s_setprio(1);
-      math();
+      if (kt == 0) math0();   // (the tile's first slab starts the accumulators: no 128-register clear between the epilogue and the next tile)
+      else math();
       __builtin_amdgcn_s_setprio(0);
       if (!(kt == nk - 1 && g1)) __builtin_amdgcn_s_barrier();   // end (group 1 takes its last one behind its epilogue)
     }
@@ -474,8 +486,6 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     __builtin_amdgcn_sched_barrier(0);   // the fresh accumulators must not be live beside the ones being stored
     stamp(11);
     if (has_next) {
-      zero_acc();
-      __builtin_amdgcn_sched_barrier(0);
       if (g1) __builtin_amdgcn_s_barrier();   // group 1's end barrier of slab nk - 1 == group 0's mid barrier of the next tile's slab 0
     }
     ++seq;

@@ -94,7 +94,7 @@ _PLANES = None
 class _plane_cache:
     def __enter__(self):
         global _PLANES
-        self.owner = _PLANES is None
+        self.owner = _PLANES is None and os.environ.get("MER_PLANE_CACHE", "1") != "0"   # (0: every build packs its own planes — A/B, scripts/load_time_ladder.py)
         if self.owner:
             _PLANES = {}
         return self
@@ -106,11 +106,11 @@ class _plane_cache:
 
 
 def _fingerprint(t):
-    """Content key of a host weight tensor: shape, two fp64 moments and 16 samples (two different weights of one shape agree on none)."""
+    """Content key of a host weight tensor: shape, the fp64 sum (one pass) and 64 samples spread over it."""
     f = t.detach().reshape(-1)
     n = f.numel()
-    idx = (torch.arange(16, dtype=torch.long) * max(n - 1, 0)) // 15
-    return (tuple(t.shape), str(t.dtype), float(f.sum(dtype=torch.float64)), float((f * f).sum(dtype=torch.float64)), tuple(f[idx].tolist()))
+    idx = (torch.arange(64, dtype=torch.long) * max(n - 1, 0)) // 63
+    return (tuple(t.shape), str(t.dtype), float(f.sum(dtype=torch.float64)), tuple(f[idx].tolist()))
 
 
 class _Holder:
@@ -398,10 +398,14 @@ class _HipModule:
                 # (constructors nest — a subclass's __init__ calls its parent's, both wrapped: the OUTERMOST call, whichever class it
                 #  belongs to, runs the self-check once the object is complete; a subclass without an __init__ of its own is covered too)
                 outermost = "_mer_constructing" not in self.__dict__
-                if outermost and _PLANES is None and _self_check_may_run(state_dict, self_check):
+                if outermost and "_mer_cache_scope" not in self.__dict__ and _PLANES is None and _self_check_may_run(state_dict, self_check):
                     # a load that may build a twin and rungs: they share the weight planes this build makes (_plane_cache)
-                    with _plane_cache():
-                        return checked_init(self, state_dict, config, *a, self_check=self_check, **k)
+                    self.__dict__["_mer_cache_scope"] = True
+                    try:
+                        with _plane_cache():
+                            return checked_init(self, state_dict, config, *a, self_check=self_check, **k)
+                    finally:
+                        self.__dict__.pop("_mer_cache_scope", None)
                 self.__dict__["_mer_constructing"] = True
                 try:
                     init(self, state_dict, config, *a, **k)

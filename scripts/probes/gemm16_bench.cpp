@@ -187,6 +187,12 @@ static void run_shape(const Shape& s, int warm, int reps) {
     printf("{\"shape\": \"%s\", \"stamps\": \"%s\"}\n", s.name, fn);
     CK(hipFree(dbg));
   }
+  if (getenv("MER_STAGGER_AB") && wblkp && s.passes == 1 && s.residual) {   // the free stagger of the fp32 + residual launches, off / on, interleaved
+    for (int round = 0; round < 3; ++round) {
+      MER(mer_set_option("gemm_dbg_skip", 8)); report("persistent, free stagger OFF", time_gemm(g, warm, reps));
+      MER(mer_set_option("gemm_dbg_skip", 0)); report("persistent, free stagger on", time_gemm(g, warm, reps));
+    }
+  }
   if (getenv("MER_DECOMP") && wblkp && s.passes == 1) {   // where the persistent kernel's time goes: stores skipped / epilogue skipped
     MER(mer_set_option("gemm_dbg_skip", 1)); report("persistent, stores skipped", time_gemm(g, warm, reps));
     MER(mer_set_option("gemm_dbg_skip", 2)); report("persistent, epilogue skipped", time_gemm(g, warm, reps));
