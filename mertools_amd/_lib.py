@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmer_hip.so")
+# (MER_LIB_PATH: another build of the same ABI — how two library versions are A/B'd on one GPU box, scripts/gpu_ab_lib.sh)
+LIB_PATH = os.environ.get("MER_LIB_PATH") or os.path.join(_HERE, "libmer_hip.so")
 
 MER_OK = 0
 MER_DT_F16, MER_DT_BF16 = 0, 1

@@ -32,7 +32,7 @@ def test_committed_kernel_stats_match_the_kernel_source():
     carries the sha of the library sources it was taken on (scripts/stamp_kernel_stats.py): a summary of another tree fails here."""
     import glob
     b = _bench()
-    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*kernel_stats.json")))
+    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*kernel_stats.json")))   # (the latest round's sorts last)
     assert stamps, "no stamped kernel-stats summary under profiles/"
     d = json.load(open(stamps[-1]))
     assert d["_source_sha"] == b.kernel_source_sha(), (stamps[-1], d["_source_sha"], b.kernel_source_sha())
@@ -49,7 +49,7 @@ def test_stale_pmc_collection_is_refused(tmp_path):
     for f in glob.glob(os.path.join(ROOT, "mertools_amd", "csrc", "*")):
         if f.endswith((".h", ".hip", ".cpp")):
             shutil.copy(f, root / "mertools_amd" / "csrc" / os.path.basename(f))
-    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*pmc_hbm_traffic*.json")))[-1]
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_hbm_traffic*.json")))[-1]
     shutil.copy(pmc, root / "profiles" / os.path.basename(pmc))
     assert b.pmc_traffic("gemm16p", 5e8, root=str(root))[0] is not None
     with open(root / "mertools_amd" / "csrc" / "norm.hip", "a") as f:      # ANY source of the library, not only the GEMM template
@@ -59,5 +59,5 @@ def test_stale_pmc_collection_is_refused(tmp_path):
     # a collection without a stamp (round 1's) is never quoted either
     d = json.load(open(root / "profiles" / os.path.basename(pmc)))
     d.pop("_source_sha")
-    json.dump(d, open(root / "profiles" / "r05_pmc_hbm_traffic.json", "w"))
+    json.dump(d, open(root / "profiles" / os.path.basename(pmc), "w"))
     assert b.pmc_traffic("gemm16p", 5e8, root=str(root))[0] is None
