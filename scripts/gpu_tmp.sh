@@ -1,9 +1,14 @@
-cd "${GRAFT_REPO_ROOT:-.}"; O=gpurun_out/r6e1; mkdir -p $O
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sustained --no-large --no-ladder --e2e 256 > $O/bench_e2e.json 2> $O/err.log; echo rc=$?
-python - $O/bench_e2e.json <<'P'
-import json,sys
-d=json.load(open(sys.argv[1])); e=d["e2e"]
-print("value", d["value"]); print("e2e warm", e.get("clips_per_s"), e.get("frac_of_kernel_only"), "3 threads", e.get("three_threads_at_once"))
-print("tri", e.get("trimodal_pipeline")); print("cold", (e.get("cold") or {}).get("clips_per_s"))
+cd "${GRAFT_REPO_ROOT:-.}"; O=gpurun_out/r6d1; mkdir -p $O
+Q="--no-cpu-baseline --no-sustained --no-large --no-ladder --no-roofline --e2e 0 --steps 20 --warmup 5"
+for round in 1 2 3; do
+  for alt in 0 1; do
+    for m in avt v a t; do
+      MER_OPTIONS=alt_dir=$alt timeout 200 python bench.py $Q --modalities $m > $O/alt${alt}_${m}_$round.json 2>> $O/err.log
+      python - "$O/alt${alt}_${m}_$round.json" $alt $m $round <<'P'
+import json, sys
+x = json.load(open(sys.argv[1])); print("alt_dir", sys.argv[2], sys.argv[3], "round", sys.argv[4], x["value"], x["ms_per_step"], x.get("parity"))
 P
+    done
+  done
+done
 tail -3 $O/err.log
