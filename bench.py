@@ -770,7 +770,12 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
     rccl_ranks = None
-    if world > 1 or args.force_dist:   # --force-dist: a one-rank RCCL group on a 1-GPU box, so that the N > 1 code path (exchange on the
+    json_out = sys.stdout
+    if world > 1 or args.force_dist:
+        # RCCL prints a version banner on C-level stdout (flushed at exit: it lands BEHIND the JSON line): the line the driver parses keeps
+        # the process's real stdout, everything else written to fd 1 goes to stderr
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)   # --force-dist: a one-rank RCCL group on a 1-GPU box, so that the N > 1 code path (exchange on the
         import torch.distributed as dist   # side stream, max-over-ranks reductions) can be exercised where no second GPU exists
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -877,7 +882,7 @@ def main():
                                                      "seconds per clip: " + ", ".join(f"{m}={v:.1f}" for m, v in r["oracle_secs"].items())}
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=json_out, flush=True)
         bad = {k: v for k, v in (("base" if args.config == "base" else args.config, parity), ("large", large.get("parity") if isinstance(large, dict) else None)) if v and max(v.values()) > 1e-3}
         if bad:
             sys.exit(f"bench.py: parity vs the CPU oracle exceeds 1e-3: {bad}")

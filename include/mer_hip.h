@@ -51,7 +51,7 @@ int mer_abi_sizeof(const char* name);
 /* Debug switches — process-global, NOT thread-safe (set them while no forward is in flight); nothing on the product path needs them:
  * "gemm_glds" 1 = global->LDS DMA loader (default), 0 = register-staged; "gemm_generic_epi" 1 = every GEMM takes the generic
  * epilogue (bit-equality tests of the specialised ones); "gemm_dbg_skip" 1 / 2 = skip the epilogue's stores / the whole epilogue
- * (timing decomposition); "gemm_stamp" 1 = s_memtime-instrumented kernels writing into mer_set_debug_buffer's buffer. */
+ * (timing decomposition), + 8 = no free stagger of the persistent fp32 + residual launches (A/B); "gemm_stamp" 1 = s_memtime-instrumented kernels writing into mer_set_debug_buffer's buffer. */
 int mer_set_option(const char* name, int value);
 /* Current value of a mer_set_option switch (so that a caller that flips one can put back what it found, e.g. a user's
  * MER_OPTIONS=gemm_persist=0 kill-switch); MER_EINVAL for an unknown name.  "gemm_persist": 0 = tile kernels only, 1 = the persistent
