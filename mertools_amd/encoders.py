@@ -123,12 +123,13 @@ class _Holder:
 
     def _plane(self, key, make):
         """The device tensor of plane `key` — from the load's cache when an earlier build made it — kept alive by this holder."""
-        if _PLANES is not None and key is not None:
-            d = _PLANES.get(key)
+        cache = _PLANES      # (read once: another thread's load may end — and drop the cache — while this build is under way)
+        if cache is not None and key is not None:
+            d = cache.get(key)
             if d is None:
                 d = make()
                 if d is not None:
-                    _PLANES[key] = d
+                    cache[key] = d
         else:
             d = make()
         if d is not None:
