@@ -42,3 +42,34 @@ def test_study_presets_are_not_on_the_public_surface(monkeypatch):
         encoders._prec("no_such_preset")
     monkeypatch.setenv("MER_STUDY_PRESETS", "1")
     assert encoders._prec("mean_all") == (5, 5, 0)
+
+
+def test_builds_of_one_load_share_their_weight_planes():
+    """VERDICT r5 #6c: inside one load (encoders._plane_cache) a second build takes the planes the first made — the same device tensor for the
+    same weight content and plane kind — and adds only what it alone needs; outside a load nothing is shared; a weight that differs in one
+    element is a different key."""
+    import torch
+    from mertools_amd import encoders as E
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(256, 64, generator=g)
+    w2 = w.clone()
+    w2[17, 3] += 1e-3
+    b = torch.randn(256, generator=g)
+    a, c = E._Holder("cpu", "f16"), E._Holder("cpu", "f16")
+    assert E._PLANES is None
+    x0, y0 = a.w16(w, lo=False), c.w16(w, lo=False)
+    assert x0.hi != y0.hi                                  # no load in progress: every build packs its own planes
+    with E._plane_cache():
+        x = a.w16(w, lo=False)                             # the one-plane object ...
+        y = c.w16(w, lo=True)                              # ... and its twin: same hi plane, its own lo plane
+        z = c.w16(w2, lo=False)
+        assert x.hi == y.hi and y.lo and not x.lo and z.hi != x.hi
+        assert a.f32(b) == c.f32(b) and a.f32(b + 1) != c.f32(b)
+        with E._plane_cache():                             # nested (a rung built inside the self-check): the same cache
+            assert E._Holder("cpu", "f16").w16(w, lo=False).hi == x.hi
+        assert E._PLANES is not None
+    assert E._PLANES is None
+    # the shared plane holds what a private build holds
+    hi_shared = next(t for t in a.keep if t.data_ptr() == x.hi)
+    hi_private = next(t for t in a.keep if t.data_ptr() == x0.hi)
+    assert torch.equal(hi_shared, hi_private)
