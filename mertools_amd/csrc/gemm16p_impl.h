@@ -402,7 +402,9 @@ __global__ __launch_bounds__(512) void gemm16p_kernel(const Gemm16Params p) {
     const int rem = nblk % (int)gridDim.x;
     if (rem > 0 && nblk > (int)gridDim.x && (int)blockIdx.x >= rem && (p.dbg_skip & 8) == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memtime(), d = (unsigned long long)nk * 700ull + 20000ull;
-      while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+      // (bounded twice: by the shader-clock counter and by the sleeps themselves — s_sleep 32 parks the wave for ~2 k cycles — should
+      //  s_memtime ever tick at another rate than the one this delay was sized on)
+      for (int it = (int)(d >> 11) + 8; it > 0 && __builtin_amdgcn_s_memtime() - t0 < d; --it) __builtin_amdgcn_s_sleep(32);
     }
   }
 

@@ -39,7 +39,7 @@ d=$R/gpurun_out/pmc_mfma; rm -rf "$d"; mkdir -p "$d"
 python scripts/pmc_mfma_summarize.py "$d" > "$O/pmc_mfma.txt" 2>&1; tail -8 "$O/pmc_mfma.txt"
 cp "$d/summary.json" "$O/pmc_mfma.json" 2>/dev/null
 find gpurun_out/pmc gpurun_out/pmc_mfma -name "*.csv" -size +20M -delete
-MER_CHECK=1 MER_DECOMP=1 timeout 400 scripts/probes/gemm16_bench.bin 20 20 all > "$O/gemm16_bench.jsonl" 2>&1; echo "gemm16_bench rc=$?"
+MER_CHECK=1 MER_DECOMP=1 MER_STAGGER_AB=1 timeout 500 scripts/probes/gemm16_bench.bin 20 20 all > "$O/gemm16_bench.jsonl" 2>&1; echo "gemm16_bench rc=$?"
 timeout 300 python scripts/load_time_ladder.py > "$O/load_time_ladder.json" 2>/dev/null; echo "load_time rc=$?"
 # the headline line once more, now that the PMC collections of THIS tree exist next to it (roofline.traffic / mfma_busy filled in)
 mkdir -p profiles_tmp && cp "$O/pmc_hbm_traffic.json" profiles/r06_pmc_hbm_traffic.json 2>/dev/null; cp "$O/pmc_mfma.json" profiles/r06_pmc_mfma.json 2>/dev/null; rmdir profiles_tmp
