@@ -7,11 +7,13 @@
 //           single-barrier, software-pipelined K loop would cost per slab next to gemm16's two-phase schedule.
 //   store:  the epilogue's store path in isolation — every wave writes 16-byte lane stores whose lanes cover row
 //           segments of SEG bytes (gemm16 today: 128 B for f16 outputs of a 64-column wave tile).
-// Output: one JSON object per line on stdout.  Numerical results are meaningless (inputs are zero-filled); only the
-// instruction streams and the memory traffic are real.
+//   template8: the guide's 256^2 BK = 64 8-phase template, whole (round 6) — checked against the two-group loop, then timed beside it.
+// Output: one JSON object per line on stdout.  Numerical results are meaningless for the zero-filled sets (only the instruction
+// streams and the memory traffic are real); the phase8 / template8 sets fill the operands pseudo-randomly and template8 compares results.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ceiling_probe.bin ceiling_probe.hip   (scripts/probes/build_probes.sh)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -32,6 +34,7 @@ struct RingParams {
   int M, N, K, tiles_m, tiles_n;
   unsigned long long* stamps;   // 2 per workgroup: start, end (s_memtime)
   float* sink;
+  float* tile_sum;              // optional [tiles]: every thread adds its accumulators' sum to its tile's word (the template8 cross-check)
 };
 
 template <int N>
@@ -472,6 +475,149 @@ __global__ __launch_bounds__(512) void phase_kernel(const RingParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   if (sum == 12345.678f) p.sink[tid] = sum;
+  if (p.tile_sum) atomicAdd(p.tile_sum + t, sum);
+  __syncthreads();
+  if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+}
+
+// template8_kernel (round 6): the guide's 256^2 BK = 64 8-phase template (cdna_hip_programming.md §5, "The 256^2
+// 8-phase template"), built WHOLE from its description — its source (examples/gemm_256sq_8phase_bf16.cpp) is not in this image:
+//   geometry   8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave; LDS = 2 K-tile buffers x 4 half-tiles x 16 KB (128 rows x 64 k,
+//              128-BYTE rows) = 128 KB; a half-tile is what ONE C-quadrant phase needs first: A-half h = the h-th 64 rows of both
+//              wave rows, B-half h = the h-th 32 columns of all four wave columns
+//   K loop     8 phases per iteration = 2 K-tiles; a phase = [ds_read the register sub-tile: 4 (B) or 8 (A) or, when both, 4 x B then
+//              8 x A] [stage ONE half-tile: 2 global_load_lds_dwordx4 per lane] [s_waitcnt] s_barrier [16 MFMAs = one C-quadrant x
+//              K = 64, s_setprio 1] s_barrier; quadrants (0,0) (0,1) (1,1) (1,0): reads 12 / 4 / 8 / 4 (B-half 0 is read again for the
+//              fourth quadrant: no second B register set)
+//   staging    one half-tile per phase, each into its buffer ONE phase after that buffer's last read — which the description allows
+//              when the reads were retired before the reading phase's first barrier, so lgkmcnt(0) sits in FRONT of it here
+//              (round 5 measured where that wait sits at 1-1.5 %): tile t's phases stage B0(t+1), A0(t+2), B1(t+2), A1(t+2);
+//              vmcnt ONCE per K-tile, in its fourth phase, counted: vmcnt(6) = the three newest half-tiles stay in flight (the
+//              guide's formula), the K-tile read from the next phase on is complete; prologue 4 + 3 half-tiles, vmcnt(6)
+//   stagger    the second wave row runs one barrier behind the first (`if (wr == 1) s_barrier`)
+//   swizzle    16-byte chunk index ^ ((row >> 1) & 7) on the DMA's SOURCE side and on the ds_read address (this repo's conflict-
+//              free choice for 128-byte rows; the guide's st_16x32 is 4-way by its own account)
+// BLK: 0 = row-major operands; 1 = W pre-blocked (a half-tile's 16 KB contiguous: [tile n][K-tile][half]); 2 = A as well.
+template <int BLK>
+__global__ __launch_bounds__(512) void template8_kernel(const RingParams p) {
+  constexpr int HT = 16384;
+  constexpr int hA0 = 0, hA1 = 1, hB0 = 2, hB1 = 3;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * HT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, li = lane & 15, lg = lane >> 4;
+  if (tid == 0) p.stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int L = blockIdx.x, xcd = L & 7, loc = L >> 3, q = nblk >> 3, r = nblk & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+  const int nkt = p.K / 64;
+  unsigned src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pi = wave + 8 * i, lr = pi * 8 + (lane >> 3), lc = (lane & 7) ^ ((lr >> 1) & 7);
+    const int wmr = lr >> 6, ra = lr & 63, wnr = lr >> 5, cb = lr & 31;
+    src[hA0][i] = (unsigned)(tm * 256 + wmr * 128 + ra) * (unsigned)p.K + lc * 8;
+    src[hA1][i] = (unsigned)(tm * 256 + wmr * 128 + 64 + ra) * (unsigned)p.K + lc * 8;
+    src[hB0][i] = (unsigned)(tn * 256 + wnr * 64 + cb) * (unsigned)p.K + lc * 8;
+    src[hB1][i] = (unsigned)(tn * 256 + wnr * 64 + 32 + cb) * (unsigned)p.K + lc * 8;
+    if (BLK >= 1) {
+      src[hB0][i] = (unsigned)(tn * nkt * 2 + 0) * 8192u + pi * 512 + lane * 8;
+      src[hB1][i] = (unsigned)(tn * nkt * 2 + 1) * 8192u + pi * 512 + lane * 8;
+    }
+    if (BLK >= 2) {
+      src[hA0][i] = (unsigned)(tm * nkt * 2 + 0) * 8192u + pi * 512 + lane * 8;
+      src[hA1][i] = (unsigned)(tm * nkt * 2 + 1) * 8192u + pi * 512 + lane * 8;
+    }
+  }
+  auto stage = [&](int kt, int d, int ht) {
+    const bool isb = ht >= hB0;
+    const f16* g = isb ? p.w : p.a;
+    const unsigned kstep = (isb ? BLK >= 1 : BLK >= 2) ? 2u * 8192u : 64u;
+    char* base = smem + (d * 4 + ht) * HT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(g + src[ht][i] + (unsigned)kt * kstep), (lds_void_t*)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 fa[4][2], fb[2][2];
+  auto readA = [&](const char* base) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int lr = wm * 64 + mt * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = *reinterpret_cast<const f16x8*>(base + lr * 128 + (((ks * 4 + lg) ^ ((lr >> 1) & 7)) << 4));
+    }
+  };
+  auto readB = [&](const char* base) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int lr = wn * 32 + nt * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = *reinterpret_cast<const f16x8*>(base + lr * 128 + (((ks * 4 + lg) ^ ((lr >> 1) & 7)) << 4));
+    }
+  };
+  auto math = [&](int mi, int nj) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mi * 4 + mt][nj * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt][ks], fb[nt][ks], acc[mi * 4 + mt][nj * 2 + nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define T8_MID()  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier()
+#define T8_END()  __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier()
+  // ---- prologue: K-tile 0 whole, K-tile 1 but its B-half 0
+  stage(0, 0, hA0); stage(0, 0, hB0); stage(0, 0, hB1); stage(0, 0, hA1);
+  if (nkt > 1) {
+    stage(1, 1, hA0); stage(1, 1, hB1); stage(1, 1, hA1);
+    wait_vmcnt<6>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  auto ktile = [&](int kt, auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const bool n1 = kt + 1 < nkt, n2 = kt + 2 < nkt;
+    const char* buf = smem + d * 4 * HT;
+    // phase 1: quadrant (0,0)
+    readB(buf + hB0 * HT); __builtin_amdgcn_sched_barrier(0); readA(buf + hA0 * HT);
+    if (n1) stage(kt + 1, d ^ 1, hB0);
+    T8_MID(); math(0, 0); T8_END();
+    // phase 2: (0,1)
+    readB(buf + hB1 * HT);
+    if (n2) stage(kt + 2, d, hA0);
+    T8_MID(); math(0, 1); T8_END();
+    // phase 3: (1,1)
+    readA(buf + hA1 * HT);
+    if (n2) stage(kt + 2, d, hB1);
+    T8_MID(); math(1, 1); T8_END();
+    // phase 4: (1,0); the one counted wait of the K-tile
+    readB(buf + hB0 * HT);
+    if (n2) { stage(kt + 2, d, hA1); wait_vmcnt<6>(); } else { wait_vmcnt<0>(); }
+    T8_MID(); math(1, 0); T8_END();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    ktile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nkt) ktile(kt + 1, std::integral_constant<int, 1>{});
+  }
+#undef T8_MID
+#undef T8_END
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (sum == 12345.678f) p.sink[tid] = sum;
+  if (p.tile_sum) atomicAdd(p.tile_sum + t, sum);
   __syncthreads();
   if (tid == 0) p.stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
 }
@@ -679,6 +825,51 @@ static void run_phase2(const char* name, const f16* a, const f16* w, int M, int 
   fflush(stdout);
 }
 
+template <int BLK>
+static void run_template8(const char* name, const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int warm, int reps) {
+  RingParams p{a, w, M, N, K, M / 256, N / 256, d_st, sink, nullptr};
+  const int nblk = p.tiles_m * p.tiles_n;
+  float us = time_launches([&] { hipLaunchKernelGGL((template8_kernel<BLK>), dim3(nblk), dim3(512), 0, 0, p); }, warm, reps);
+  std::vector<unsigned long long> st(2 * nblk);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  const double cyc = avg_cycles(st, nblk), nk = K / 32.0;
+  const double bytes = (double)nblk * nk * 32768.0, flops = 2.0 * M * (double)N * K;
+  printf("{\"probe\": \"template8\", \"name\": \"%s\", \"blocked\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, "
+         "\"us\": %.1f, \"cycles_per_tile\": %.0f, \"cycles_per_slab\": %.0f, \"dma_B_per_clk_per_CU\": %.1f, \"dma_TBps_chip\": %.2f, \"mfma_TFLOPs\": %.0f}\n",
+         name, BLK, M, N, K, nblk, us, cyc, cyc / nk, 32768.0 * nk / cyc, bytes / us * 1e-6, flops / us * 1e-6);
+  fflush(stdout);
+}
+
+// the template's tiles against the two-group loop's on the same row-major random operands: per-tile sums of all accumulators (the k
+// order differs: fp32 rounding only).  A staging / swizzle / hazard mistake in the reconstruction shows here, not in the cycle counts.
+static int check_template8(const f16* a, const f16* w, int M, int N, int K, unsigned long long* d_st, float* sink, int rounds) {
+  const int nblk = (M / 256) * (N / 256);
+  float *s_ref, *s_t8;
+  CK(hipMalloc(&s_ref, nblk * 4)); CK(hipMalloc(&s_t8, nblk * 4));
+  std::vector<float> h_ref(nblk), h_t8(nblk);
+  int bad = 0; double worst = 0;
+  for (int rd = 0; rd < rounds; ++rd) {
+    CK(hipMemset(s_ref, 0, nblk * 4)); CK(hipMemset(s_t8, 0, nblk * 4));
+    RingParams pr{a, w, M, N, K, M / 256, N / 256, d_st, sink, s_ref}, pt{a, w, M, N, K, M / 256, N / 256, d_st, sink, s_t8};
+    hipLaunchKernelGGL((phase_kernel<false, true, 0, false, 0>), dim3(nblk), dim3(512), 0, 0, pr);
+    hipLaunchKernelGGL((template8_kernel<0>), dim3(nblk), dim3(512), 0, 0, pt);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h_ref.data(), s_ref, nblk * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h_t8.data(), s_t8, nblk * 4, hipMemcpyDeviceToHost));
+    double scale = 0;
+    for (int i = 0; i < nblk; ++i) scale = fmax(scale, fabs((double)h_ref[i]));
+    for (int i = 0; i < nblk; ++i) {
+      const double e = fabs((double)h_ref[i] - (double)h_t8[i]) / (scale + 1e-30);
+      worst = fmax(worst, e);
+      if (!(e < 2e-3)) ++bad;
+    }
+  }
+  printf("{\"probe\": \"template8_check\", \"M\": %d, \"N\": %d, \"K\": %d, \"tiles\": %d, \"rounds\": %d, \"worst_tile_sum_rel_diff\": %.3g, \"bad_tiles\": %d}\n", M, N, K, nblk, rounds, worst, bad);
+  fflush(stdout);
+  CK(hipFree(s_ref)); CK(hipFree(s_t8));
+  return bad;
+}
+
 template <int NW, int SEG, int ELEM>
 static void run_store(char* c, int M, int N, unsigned long long* d_st, int warm, int reps) {
   StoreParams p{c, (long long)N * ELEM, M / 256, N / 256, d_st};
@@ -735,6 +926,29 @@ int main(int argc, char** argv) {
       P8(M, 2304, 768) P8(M, 3072, 768) P8(M, 768, 3072) P8(4096, 3072, 3072) P8(8192, 3072, 3072)
     }
     return 0;
+  }
+  if (!strcmp(set, "template8")) {
+    // round 6: the guide's 8-phase template, whole, against this repo's loop — pseudo-random operands, interleaved,
+    // no epilogue in either; cycles per 32-deep slab of a 256^2 tile
+    hipLaunchKernelGGL(fill_rand16, dim3(4096), dim3(256), 0, 0, a, (size_t)M * KMAX, 2.0f, 1u);
+    hipLaunchKernelGGL(fill_rand16, dim3(4096), dim3(256), 0, 0, w, (size_t)NMAX * KMAX, 0.05f, 2u);
+    CK(hipDeviceSynchronize());
+    int bad = check_template8(a, w, 8192, 768, 768, st, sink, 3);
+    bad += check_template8(a, w, 8192, 768, 3072, st, sink, 3);
+    bad += check_template8(a, w, M, 2304, 768, st, sink, 2);
+    bad += check_template8(a, w, 2048, 512, 64, st, sink, 1);      // one K-tile, two K-tiles, an odd count: the prologue / drain paths
+    bad += check_template8(a, w, 2048, 512, 128, st, sink, 1);
+    bad += check_template8(a, w, 2048, 512, 192, st, sink, 1);
+    for (int round = 0; round < 2; ++round) {
+#define T8(MM, NN, KK) \
+      run_phase<false, true, 1, false, 0>("this repo's loop: two groups, 32 MFMAs per phase, 4 x 32-KB stages of 64-B rows, W pre-blocked", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_phase<false, true, 0, false, 0>("this repo's loop, row-major operands", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_template8<0>("the guide's 8-phase template (reconstruction), row-major operands", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_template8<1>("the guide's 8-phase template (reconstruction), W pre-blocked per half-tile", a, w, MM, NN, KK, st, sink, warm, reps); \
+      run_template8<2>("the guide's 8-phase template (reconstruction), A and W pre-blocked", a, w, MM, NN, KK, st, sink, warm, reps);
+      T8(M, 2304, 768) T8(M, 3072, 768) T8(M, 768, 3072) T8(4096, 3072, 3072) T8(8192, 3072, 3072)
+    }
+    return bad ? 3 : 0;
   }
   // --- the K loop's data path; shapes: CLIP QKV (N=2304, K=768), fc2 (N=768, K=3072)
 #define RING_SET(NW, NS, MODE, NAME) RING_SET_MF(NW, NS, MODE, 16, NAME)
