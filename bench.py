@@ -712,8 +712,7 @@ def e2e(args, dev):
                     rows = [next(loaded) for _ in range(n)]
                     tk = ids[b0:b0 + n]
                     T = max(len(x) for x in tk)
-                    yield {"names": names[b0:b0 + n], "audio": torch.from_numpy(np.stack([r[0] for r in rows])),
-                           "frames": torch.from_numpy(np.concatenate([r[1] for r in rows], 0)), "frames_per_clip": [8] * n,
+                    yield {"names": names[b0:b0 + n], "audio": [r[0] for r in rows], "frames": [r[1] for r in rows], "frames_per_clip": [8] * n,
                            "input_ids": torch.tensor([x + [0] * (T - len(x)) for x in tk], dtype=torch.int64), "lengths": [len(x) for x in tk]}
             tme = TriModalExtractor(audio=ma, visual=mv, text=mt, device=dev)
             dirs = {"audio": os.path.join(root, "tri_a"), "visual": os.path.join(root, "tri_v"), "text": os.path.join(root, "tri_t")}
@@ -733,7 +732,7 @@ def e2e(args, dev):
             agree = differ["audio"] == 0 and differ["text"] == 0 and vis_rel < 1e-6
             tri = {"seconds": round(t_tri, 3), "clips_per_s": round(ndone / t_tri, 1), "frac_of_three_stream_kernel_only": None,
                    "same_files_as_the_three_drivers": bool(agree), "byte_differing_files_of_64_checked": differ, "visual_max_rel_diff": vis_rel,
-                   "what": "TriModalExtractor over the same files: 8 read-ahead threads, one pinned block per batch and modality on a copy stream, three encoder streams, np.save in line"}
+                   "what": "TriModalExtractor over the same files: 8 read-ahead threads, per-clip arrays gathered into one pinned block per batch and modality (4 copy threads) and sent up on a copy stream, three encoder streams, np.save on 2 worker threads"}
         except Exception as e:
             tri = {"error": repr(e)}
         seq = sum(alone.values())

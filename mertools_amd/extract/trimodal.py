@@ -50,10 +50,12 @@ class TriModalExtractor:
       frames           [B*F, 3, H, W] float32 (processor output) or [B*F, H, W, 3] uint8 BGR (normalised on the GPU)
       frames_per_clip  list of B ints (sum = rows of `frames`)
       input_ids        [B, T] int64, `lengths` list of B ints (tokens incl. specials)
+    `audio` / `frames` may also be LISTS of per-clip arrays of one shape each ([L] / [F, ...]): they are gathered straight into the
+    pinned staging buffer (one host copy instead of stack + copy), on `copy_workers` threads (numpy's memcpy releases the GIL).
     """
 
     def __init__(self, audio=None, visual=None, text=None, device="cuda:0", text_strip=(1, -1), audio_do_normalize=True,
-                 image_mean=None, image_std=None):
+                 image_mean=None, image_std=None, copy_workers=4, save_workers=2):
         self.models = {"audio": audio, "visual": visual, "text": text}
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -61,6 +63,8 @@ class TriModalExtractor:
         self.audio_do_normalize = audio_do_normalize
         self.image_mean, self.image_std = image_mean, image_std
         self.slots = [_Slot(), _Slot()]
+        self.copy_workers, self.save_workers = max(1, int(copy_workers)), max(1, int(save_workers))
+        self._copy_pool = None
         if self.cuda:
             self.copy_stream = torch.cuda.Stream(device=self.device)
             self.streams = {m: torch.cuda.Stream(device=self.device) for m in MODALITIES if self.models[m] is not None}
@@ -94,10 +98,13 @@ class TriModalExtractor:
             t = batch.get(key)
             if t is None:
                 continue
-            t = torch.as_tensor(t)
-            host = self._pinned(slot.pinned_in, key, tuple(t.shape), t.dtype)
-            host.copy_(t)                                           # CPU memcpy into the pinned staging buffer
-            views[key] = (host, self._device(slot, key, tuple(t.shape), t.dtype))
+            if isinstance(t, (list, tuple)) and key != "input_ids":
+                host = self._gather(slot, key, t)                   # per-clip arrays -> their rows of the pinned buffer, in parallel
+            else:
+                t = torch.as_tensor(t)
+                host = self._pinned(slot.pinned_in, key, tuple(t.shape), t.dtype)
+                host.copy_(t)                                       # CPU memcpy into the pinned staging buffer
+            views[key] = (host, self._device(slot, key, tuple(host.shape), host.dtype))
         if self.cuda:
             with torch.cuda.stream(self.copy_stream):
                 for host, dev in views.values():
@@ -108,6 +115,33 @@ class TriModalExtractor:
             for host, dev in views.values():
                 dev.copy_(host)
         slot.views = {k: v[1] for k, v in views.items()}
+
+    def _gather(self, slot, key, parts):
+        parts = [np.asarray(x) for x in parts]
+        first = parts[0]
+        lead = [1 if key == "audio" else x.shape[0] for x in parts]
+        tail = first.shape if key == "audio" else first.shape[1:]
+        for x in parts:
+            if (x.shape if key == "audio" else x.shape[1:]) != tail or x.dtype != first.dtype:
+                raise ValueError(f"TriModalExtractor: the per-clip `{key}` arrays of a batch must share shape and dtype")
+        host = self._pinned(slot.pinned_in, key, (sum(lead),) + tuple(tail), torch.from_numpy(first[:0]).dtype)
+        dst = host.numpy()
+        offs = np.concatenate([[0], np.cumsum(lead)])
+
+        def put(i):
+            if key == "audio":
+                dst[offs[i]] = parts[i]
+            else:
+                dst[offs[i]:offs[i + 1]] = parts[i]
+        if self.copy_workers > 1 and len(parts) > 1:
+            if self._copy_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._copy_pool = ThreadPoolExecutor(self.copy_workers, thread_name_prefix="mer-stage")
+            list(self._copy_pool.map(put, range(len(parts))))
+        else:
+            for i in range(len(parts)):
+                put(i)
+        return host
 
     def _forward(self, m, slot):
         x = slot.views
@@ -176,13 +210,22 @@ class TriModalExtractor:
 
     def extract_to_dirs(self, batches, save_dirs):
         """Writes `<save_dirs[m]>/<clip>.npy` (UTT layout of the reference: float32 [D]) for every modality present."""
+        from concurrent.futures import ThreadPoolExecutor
         for d in save_dirs.values():
             os.makedirs(d, exist_ok=True)
-        n = 0
-        for names, feats in self.run(batches):
+
+        def save(names, feats):                                     # `feats` are copies (run()): nothing overwrites them
             for m, arr in feats.items():
                 if m in save_dirs:
                     for name, row in zip(names, arr):
                         np.save(os.path.join(save_dirs[m], f"{name}.npy"), row)
-            n += len(names)
+        n, inflight = 0, []
+        with ThreadPoolExecutor(self.save_workers, thread_name_prefix="mer-save") as pool:   # the feeding thread keeps feeding
+            for names, feats in self.run(batches):
+                inflight.append(pool.submit(save, names, feats))
+                while len(inflight) > 2 * self.save_workers:       # bounded: a slow disk holds the pipeline back, not memory
+                    inflight.pop(0).result()
+                n += len(names)
+            for f in inflight:
+                f.result()                                          # a write error surfaces here
         return n

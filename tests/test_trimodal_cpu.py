@@ -74,3 +74,39 @@ def test_extract_to_dirs_layout(tmp_path):
         assert files == [f"clip{i:03d}.npy" for i in range(5)]
         x = np.load(os.path.join(d, files[0]))
         assert x.ndim == 1 and x.dtype == np.float32          # the reference's UTT layout: float32 [D]
+
+
+def test_per_clip_lists_equal_stacked_batches(tmp_path):
+    """`audio` / `frames` as lists of per-clip arrays (gathered straight into the pinned block, on copy threads) == the stacked
+    tensors, ragged frame counts and compact dtypes included; the saves run on worker threads and write the same files."""
+    batches = _batches([3, 5, 1, 4], seed=7)
+    listed = []
+    for b in batches:
+        rows, r = [], 0
+        for n in b["frames_per_clip"]:
+            rows.append(b["frames"][r:r + n].numpy())
+            r += n
+        listed.append(dict(b, audio=[x.numpy() for x in b["audio"]], frames=rows))
+    a = TriModalExtractor(_Audio(), _Visual(), _Text(), device="cpu")
+    c = TriModalExtractor(_Audio(), _Visual(), _Text(), device="cpu", copy_workers=3)
+    for (n1, f1), (n2, f2) in zip(a.run(batches), c.run(listed)):
+        assert n1 == n2
+        for m in f1:
+            assert np.array_equal(f1[m], f2[m]), m
+    d1 = {m: str(tmp_path / f"one_{m}") for m in ("audio", "visual", "text")}
+    d2 = {m: str(tmp_path / f"two_{m}") for m in ("audio", "visual", "text")}
+    assert a.extract_to_dirs(batches, d1) == c.extract_to_dirs(listed, d2) == 13
+    for m in d1:
+        assert sorted(os.listdir(d1[m])) == sorted(os.listdir(d2[m])) and len(os.listdir(d1[m])) == 13
+        for f in os.listdir(d1[m]):
+            assert np.array_equal(np.load(os.path.join(d1[m], f)), np.load(os.path.join(d2[m], f)))
+    # compact forms keep their dtype through the gather (int16 PCM, uint8 frames)
+    pcm = [np.arange(40, dtype=np.int16) + i for i in range(3)]
+    u8 = [np.full((2, 4, 4, 3), i, dtype=np.uint8) for i in range(3)]
+    e = TriModalExtractor(None, None, None, device="cpu")
+    assert e._gather(e.slots[0], "audio", pcm).dtype == torch.int16 and tuple(e._gather(e.slots[0], "audio", pcm).shape) == (3, 40)
+    g = e._gather(e.slots[0], "frames", u8)
+    assert g.dtype == torch.uint8 and tuple(g.shape) == (6, 4, 4, 3) and int(g[4, 0, 0, 0]) == 2
+    import pytest
+    with pytest.raises(ValueError):
+        e._gather(e.slots[0], "audio", [pcm[0], pcm[1][:10]])
