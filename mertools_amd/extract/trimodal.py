@@ -211,6 +211,7 @@ class TriModalExtractor:
     def extract_to_dirs(self, batches, save_dirs):
         """Writes `<save_dirs[m]>/<clip>.npy` (UTT layout of the reference: float32 [D]) for every modality present."""
         from concurrent.futures import ThreadPoolExecutor
+        from .pipeline import npy_save
         for d in save_dirs.values():
             os.makedirs(d, exist_ok=True)
 
@@ -218,7 +219,7 @@ class TriModalExtractor:
             for m, arr in feats.items():
                 if m in save_dirs:
                     for name, row in zip(names, arr):
-                        np.save(os.path.join(save_dirs[m], f"{name}.npy"), row)
+                        npy_save(os.path.join(save_dirs[m], f"{name}.npy"), row)   # np.save's bytes without its per-call overhead
         n, inflight = 0, []
         with ThreadPoolExecutor(self.save_workers, thread_name_prefix="mer-save") as pool:   # the feeding thread keeps feeding
             for names, feats in self.run(batches):
